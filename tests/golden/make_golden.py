@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own code.
+
+Run in the build container only (``/root/reference`` does not travel):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference's third-party dependencies that are absent from this image
+(librosa, keras, tensorflow, zarr, humanize, ...) are replaced by empty stub
+modules *before* import; only the reference's own numpy/pandas functions are
+executed (preprocess_spectrogram, compute_aggregated_predictions,
+compute_binary_predictions, compute_labels, find_consecutive_ones,
+save_predictions, filter_predictions) plus ``numpy.percentile`` itself for the
+virtual-index table.  Outputs are data only -- no reference source or bytecode
+is written anywhere.
+"""
+
+from __future__ import annotations
+
+import io
+import json
+import sys
+import types
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+HERE = Path(__file__).resolve().parent
+REFERENCE_SRC = Path("/root/reference/src")
+
+
+class _Dummy:
+    def __getattr__(self, k):
+        return _Dummy()
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return _Dummy()
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy()
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name in ["humanize", "librosa", "keras", "tensorflow", "zarr", "tqdm.keras", "rich_click", "keras_tuner", "soundfile"]:
+        sys.modules.setdefault(name, _Stub(name))
+    sys.path.insert(0, str(REFERENCE_SRC))
+    import orcAI.auxiliary as A
+    import orcAI.predict as P
+    import orcAI.spectrogram as S
+
+    return S, P, A
+
+
+SPEC_PARAM = {"sampling_rate": 48000, "nfft": 512, "n_overlap": 256, "freq_range": [0, 16000], "quantiles": [0.01, 0.999], "duration": 4}
+CALLS = ["BR", "BUZZ", "HERDING", "PHS", "SS", "TAILSLAP", "WHISTLE"]
+ORCAI_PARAM = {"name": "orcai-v1", "model": {"filters": [30, 40, 50, 60]}, "calls": CALLS, "spectrogram": SPEC_PARAM}
+SHAPE = {"input_shape": [736, 171, 1], "num_labels": 7}
+
+
+def synthetic_db(seed: int, T: int, kind: str) -> np.ndarray:
+    """Seeded float32 dB-like array [257, T] in [-80, 0] (what calculate_spectrogram returns)."""
+    rng = np.random.default_rng(seed)
+    if kind == "smooth":
+        x = -40.0 + 12.0 * rng.standard_normal((257, T))
+    elif kind == "ties":  # coarse grid -> many exact ties, heavy mass on the floor
+        x = np.round(-50.0 + 25.0 * rng.standard_normal((257, T)))
+    elif kind == "constant":
+        x = np.full((257, T), -33.25)
+    else:
+        raise ValueError(kind)
+    x = np.clip(x, -80.0, 0.0).astype(np.float32)
+    x[7, 3 % T] = 0.0  # the global max of an amplitude_to_db(ref=max) array is exactly 0
+    return x
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def gen_preprocess(S):
+    freqs = np.fft.rfftfreq(512, 1 / 48000)
+    # small cases: full input and output stored
+    for name, seed, T, kind in [("smooth_T300", 11, 300, "smooth"), ("ties_T200", 12, 200, "ties"), ("constant_T64", 13, 64, "constant")]:
+        x = synthetic_db(seed, T, kind)
+        with np.errstate(all="ignore"):
+            y = S.preprocess_spectrogram(x.copy(), freqs, SPEC_PARAM)
+        np.savez_compressed(HERE / f"preprocess_{name}.npz", db=x, out=np.ascontiguousarray(y), seed=seed, T=T, kind=kind)
+        print("preprocess", name, y.shape, y.dtype, float(np.nanmin(y)), float(np.nanmax(y)))
+    # large cases: input regenerated from the seed (crc pinned), output summarised
+    summary = {}
+    for name, seed, T, kind in [("smooth_T11251", 21, 11251, "smooth"), ("ties_T2000", 22, 2000, "ties")]:
+        x = synthetic_db(seed, T, kind)
+        y = np.ascontiguousarray(S.preprocess_spectrogram(x.copy(), freqs, SPEC_PARAM))
+        rows = [0, 1, T // 2, T - 1]
+        np.savez_compressed(HERE / f"preprocess_{name}.npz", rows=np.array(rows), out_rows=y[rows], seed=seed, T=T, kind=kind)
+        summary[name] = {
+            "seed": seed,
+            "T": T,
+            "kind": kind,
+            "input_crc32": crc(x),
+            "output_crc32": crc(y),
+            "p_lo": float(np.percentile(x[0:171], 1.0, method="nearest")),
+            "p_hi": float(np.percentile(x[0:171], 99.9, method="nearest")),
+            "out_sum_f64": float(y.astype(np.float64).sum()),
+        }
+        print("preprocess", name, summary[name])
+    (HERE / "preprocess_large.json").write_text(json.dumps(summary, indent=1))
+
+
+def gen_virtual_index():
+    """(n, q) -> index that numpy.percentile(method='nearest') selects on float32 data."""
+    table = []
+    for n in [171 * 736, 171 * 11251, 171 * 675001, 171 * 753665, (1 << 24) + 3, 1, 2, 171]:
+        a = (np.arange(n, dtype=np.uint32) + np.uint32(0x3F800000)).view(np.float32)  # strictly increasing
+        for q in [0.01, 0.999, 0.5, 0.0, 1.0]:
+            v = np.percentile(a, 100 * q, method="nearest")
+            idx = int(np.float32(v).view(np.uint32)) - 0x3F800000
+            table.append({"n": n, "q": q, "index": idx})
+        del a
+    (HERE / "virtual_index.json").write_text(json.dumps(table, indent=1))
+    print("virtual_index", table[:6])
+
+
+class FakeModel:
+    """Deterministic stand-in for keras.Model.predict: (n,736,171,1) -> (n,46,7) float32."""
+
+    def predict(self, snippets, verbose=0):
+        s = snippets[..., 0]
+        n = s.shape[0]
+        m = s.reshape(n, 46, 16, 171).mean(axis=(2,))  # (n,46,171)
+        out = np.stack([m[:, :, 13 * l : 13 * l + 24].mean(axis=2) for l in range(7)], axis=2)
+        return out.astype(np.float32)
+
+
+def gen_aggregate(P):
+    from orcAI.auxiliary import Messenger
+
+    fake = FakeModel()
+    for T in [736, 1103, 1104, 1471, 1472, 11251]:
+        rng = np.random.default_rng(1000 + T)
+        spec = rng.random((T, 171), dtype=np.float32)
+        captured = {}
+
+        class Capture(FakeModel):
+            def predict(self, snippets, verbose=0):
+                captured["snippet_sums"] = snippets.astype(np.float64).sum(axis=(1, 2, 3))
+                captured["shape"] = snippets.shape
+                captured["pred"] = super().predict(snippets, verbose)
+                return captured["pred"]
+
+        agg, cnt = P.compute_aggregated_predictions(Path("x.wav"), spec, Capture(), ORCAI_PARAM, SHAPE, msgr=Messenger(verbosity=0))
+        np.savez_compressed(
+            HERE / f"aggregate_T{T}.npz",
+            T=T,
+            seed=1000 + T,
+            spec_crc32=crc(spec),
+            snippet_shape=np.array(captured["shape"]),
+            snippet_sums=captured["snippet_sums"],
+            predictions=captured["pred"],
+            aggregated=agg,
+            overlap_count=cnt,
+        )
+        print("aggregate", T, captured["shape"], agg.shape, agg.dtype, {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))})
+
+
+def gen_labels(P):
+    from orcAI.auxiliary import Messenger
+
+    S_steps = 703
+    rng = np.random.default_rng(77)
+    agg = rng.random((S_steps, 7)) * 0.2  # all below 0.25
+    cnt = np.concatenate([np.ones(23), 2 * np.ones(644), np.ones(23), np.zeros(13)])
+    agg[0:5, 0] = 0.9  # run at index 0
+    agg[690:703, 1] = 0.8  # run ending at S-1
+    agg[100, 2] = 0.3  # single-step run
+    agg[102, 2] = 0.3  # another single-step run one apart
+    agg[200:210, 3] = 0.25  # exactly the threshold: strict > -> NOT a call
+    agg[300:310, 4] = np.nextafter(0.25, 1.0)  # just above
+    agg[300:320, 6] = 0.5  # same start as label 4, longer
+    agg[300:310, 5] = 0.6  # same start and stop as label 4 -> sorted by label
+    starts, stops, names = P.compute_binary_predictions(agg, cnt, CALLS, threshold=0.5)
+    cases = {}
+    for suffix in ["*", "", None, "_pred"]:
+        df = P.compute_labels(starts, stops, names, 16, suffix)
+        delta_t = 256 / 48000
+        buf = io.StringIO()
+        # save_predictions writes to a path; call it with a real temp file to capture bytes
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as d:
+            p = Path(d) / "o.txt"
+            P.save_predictions(df.copy(), p, delta_t, msgr=Messenger(verbosity=0))
+            text = p.read_text()
+        cases[str(suffix)] = {
+            "start": [int(v) for v in df["start"]],
+            "stop": [int(v) for v in df["stop"]],
+            "label": list(df["label"]),
+            "tsv": text,
+        }
+    limits = {"default": [0.05, None], "BR": [None, 0.2], "WHISTLE": [0.1, 1.0], "SS": [0.3, None]}
+    df = P.compute_labels(starts, stops, names, 16, "*")
+    kept = P.filter_predictions(df.copy(), delta_t=256 / 48000, call_duration_limits=limits, label_suffix="*", msgr=Messenger(verbosity=0))
+    out = {
+        "row_starts": [int(v) for v in starts],
+        "row_stops": [int(v) for v in stops],
+        "label_names": names,
+        "cases": cases,
+        "filter_limits": limits,
+        "filter_kept": {"start": [int(v) for v in kept["start"]], "stop": [int(v) for v in kept["stop"]], "label": list(kept["label"])},
+    }
+    np.savez_compressed(HERE / "labels_crafted.npz", aggregated=agg, overlap_count=cnt)
+    (HERE / "labels_crafted.json").write_text(json.dumps(out, indent=1))
+    print("labels", len(starts), cases["*"]["tsv"][:120].replace("\n", "|"))
+    # empty case
+    s0, e0, n0 = P.compute_binary_predictions(np.zeros((50, 7)), np.ones(50), CALLS)
+    df0 = P.compute_labels(s0, e0, n0, 16, "*")
+    (HERE / "labels_empty.json").write_text(json.dumps({"n": len(df0), "columns": list(df0.columns)}))
+
+
+def gen_consecutive(A):
+    cases = [[0, 1, 1, 0, 1], [1, 1, 1], [0, 0, 0], [1], [0], [1, 0, 1, 0, 1], [0, 1, 1, 1, 1, 0, 0, 1, 1]]
+    out = []
+    for c in cases:
+        s, e = A.find_consecutive_ones(np.array(c))
+        out.append({"input": c, "starts": [int(v) for v in s], "stops": [int(v) for v in e]})
+    (HERE / "consecutive_ones.json").write_text(json.dumps({"mask_value": float(A.MASK_VALUE), "cases": out}, indent=1))
+
+
+def main():
+    S, P, A = import_reference()
+    gen_preprocess(S)
+    gen_virtual_index()
+    gen_aggregate(P)
+    gen_labels(P)
+    gen_consecutive(A)
+
+
+if __name__ == "__main__":
+    main()

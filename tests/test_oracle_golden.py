@@ -1,0 +1,100 @@
+"""The CPU oracle against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py).  Bit-exact: these are integer / order-statistic /
+f64-accumulate rows."""
+
+import json
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import frontend_ref as F
+from oracle import postprocess_ref as P
+
+SPEC_PARAM = {"sampling_rate": 48000, "nfft": 512, "n_overlap": 256, "freq_range": [0, 16000], "quantiles": [0.01, 0.999], "duration": 4}
+CALLS = ["BR", "BUZZ", "HERDING", "PHS", "SS", "TAILSLAP", "WHISTLE"]
+FREQS = np.fft.rfftfreq(512, 1 / 48000)
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def synthetic_db(seed, T, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "smooth":
+        x = -40.0 + 12.0 * rng.standard_normal((257, T))
+    elif kind == "ties":
+        x = np.round(-50.0 + 25.0 * rng.standard_normal((257, T)))
+    else:
+        x = np.full((257, T), -33.25)
+    x = np.clip(x, -80.0, 0.0).astype(np.float32)
+    x[7, 3 % T] = 0.0
+    return x
+
+
+@pytest.mark.parametrize("name", ["smooth_T300", "ties_T200", "constant_T64"])
+def test_preprocess_small_bit_exact(golden_dir, name):
+    g = np.load(golden_dir / f"preprocess_{name}.npz")
+    out = np.ascontiguousarray(F.preprocess_spectrogram_ref(g["db"], FREQS, SPEC_PARAM))
+    assert out.dtype == np.float32 and out.shape == g["out"].shape
+    assert np.array_equal(out, g["out"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["smooth_T11251", "ties_T2000"])
+def test_preprocess_large_bit_exact(golden_dir, name):
+    meta = json.loads((golden_dir / "preprocess_large.json").read_text())[name]
+    x = synthetic_db(meta["seed"], meta["T"], meta["kind"])
+    if crc(x) != meta["input_crc32"]:
+        pytest.skip("numpy Generator stream differs from the one the fixture was made with")
+    out = np.ascontiguousarray(F.preprocess_spectrogram_ref(x, FREQS, SPEC_PARAM))
+    assert crc(out) == meta["output_crc32"]
+    g = np.load(golden_dir / f"preprocess_{name}.npz")
+    assert np.array_equal(out[g["rows"]], g["out_rows"])
+
+
+def test_crop_indices():
+    assert F.crop_indices(FREQS, [0, 16000]) == (0, 171)
+    assert F.crop_indices(FREQS, [500, 16000])[0] == 0  # first bin with f <= lo is always bin 0
+
+
+def test_virtual_index_table(golden_dir):
+    for row in json.loads((golden_dir / "virtual_index.json").read_text()):
+        assert F.nearest_rank_index(row["n"], row["q"]) == row["index"], row
+
+
+@pytest.mark.parametrize("T", [736, 1103, 1104, 1471, 1472, 11251])
+def test_aggregate_bit_exact(golden_dir, T):
+    g = np.load(golden_dir / f"aggregate_T{T}.npz")
+    spec = np.random.default_rng(int(g["seed"])).random((T, 171), dtype=np.float32)
+    if crc(spec) == int(g["spec_crc32"]):
+        snippets = P.slice_snippets(spec, 736)
+        assert list(snippets.shape) == list(g["snippet_shape"])
+        assert np.array_equal(snippets.astype(np.float64).sum(axis=(1, 2, 3)), g["snippet_sums"])
+    shift, tpo, plen, n, total = P.snippet_geometry(T, 736, 4)
+    assert (shift, tpo, plen) == (368, 16, 46)
+    assert n == g["predictions"].shape[0] and total == g["aggregated"].shape[0]
+    agg, cnt = P.aggregate_predictions_ref(g["predictions"], T, 736, 4, 7)
+    assert agg.dtype == np.float64
+    assert np.array_equal(agg, g["aggregated"]) and np.array_equal(cnt, g["overlap_count"])
+
+
+def test_labels_crafted(golden_dir):
+    g = np.load(golden_dir / "labels_crafted.npz")
+    j = json.loads((golden_dir / "labels_crafted.json").read_text())
+    s, e, n = P.compute_binary_predictions_ref(g["aggregated"], g["overlap_count"], CALLS)
+    assert [int(v) for v in s] == j["row_starts"] and [int(v) for v in e] == j["row_stops"] and n == j["label_names"]
+    for suffix_key, case in j["cases"].items():
+        suffix = None if suffix_key == "None" else suffix_key
+        df = P.compute_labels_ref(s, e, n, 16, suffix)
+        assert [int(v) for v in df["start"]] == case["start"]
+        assert [int(v) for v in df["stop"]] == case["stop"]
+        assert list(df["label"]) == case["label"]
+        assert P.labels_to_tsv_ref(df, 256 / 48000) == case["tsv"]
+
+
+def test_consecutive_ones(golden_dir):
+    j = json.loads((golden_dir / "consecutive_ones.json").read_text())
+    for c in j["cases"]:
+        s, e = P.find_consecutive_ones_ref(np.array(c["input"]))
+        assert list(s) == c["starts"] and list(e) == c["stops"]
