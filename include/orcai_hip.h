@@ -1,0 +1,104 @@
+/*
+ * orcai_hip.h -- C ABI of liborcai_hip.so, the MI355X (gfx950) implementation of
+ * orcAI's spectrogram -> label hot path.
+ *
+ * The reference (ethz-tb/orcAI v1.0.3) is pure Python and has no FFI layer; its
+ * hot-path arithmetic is delegated to librosa/numpy/Keras calls.  Each entry
+ * point below names the reference call site (file:line under
+ * /root/reference/src/orcAI/) whose arithmetic it replaces.  INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - the caller owns and allocates every buffer (no ownership transfer);
+ *   - the return value is a hipError_t as int (0 = hipSuccess), or a negative
+ *     ORCAI_E_* code for argument errors detected on the host before launch;
+ *   - nothing here allocates, frees or synchronises, so every call may be
+ *     captured into a hipGraph.  The only exceptions are the *_host readback
+ *     helpers, which synchronise the stream and say so.
+ */
+#ifndef ORCAI_HIP_H
+#define ORCAI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORCAI_E_BADARG (-1)      /* null pointer, non-positive size, misaligned buffer */
+#define ORCAI_E_UNSUPPORTED (-2) /* parameter combination the HIP path does not implement */
+
+/* library identification: "orcai_hip <version> gfx950" */
+const char* orcai_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Front end (spectrogram.py:15-87)
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of device workspace the front-end calls need (histograms + selection state).
+ * The workspace must be 256-byte aligned. */
+size_t orcai_frontend_workspace_bytes(void);
+
+/* Zero the workspace (histograms, running max, selection state).  Must precede each
+ * recording's orcai_stft_db / orcai_hist_level1. */
+int orcai_frontend_reset(void* workspace, void* stream);
+
+/* librosa.stft(n_fft=512, hop_length=hop, window="hann", center=True, pad_mode="constant")
+ * followed by the first half of amplitude_to_db (spectrogram.py:34-39, :51-53):
+ *   out_db[t*k_crop + k] = 10*log10(max(|X[k,t]|^2, 1e-10))          k in [0, k_crop)
+ * (the reference level, max-80 floor and normalisation are applied by orcai_clip_normalize).
+ * Also accumulates into the workspace: max |X|^2 over ALL 257 bins and all frames, and the
+ * level-1 selection histogram of the values written.
+ *   pcm        f32[n_samples], mono, already at the target sampling rate
+ *   n_frames   must equal 1 + n_samples / hop
+ *   k_crop     1..257 leading rFFT bins to keep (171 for orcai-V1: first bin with f >= 16 kHz)
+ *   out_db     f32[n_frames * k_crop], layout [frame][bin]  (the transposed layout
+ *              preprocess_spectrogram returns, spectrogram.py:86)
+ * Only n_fft = 512 is implemented (ORCAI_E_UNSUPPORTED otherwise). */
+int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop,
+                  float* out_db, void* workspace, void* stream);
+
+/* Level-1 selection histogram of an arbitrary f32 array (used when the dB array comes from the
+ * caller, i.e. the drop-in preprocess_spectrogram(spectrogram, ...) entry, spectrogram.py:58). */
+int orcai_hist_level1(const float* x, int64_t n, void* workspace, void* stream);
+
+/* Exact order statistics: the rank_lo-th and rank_hi-th smallest (0-based) of x[0..n), i.e. what
+ * np.percentile(x, q, method="nearest") returns for the indices computed on the host
+ * (spectrogram.py:70-75).  Requires the level-1 histogram of exactly these n values to be in
+ * the workspace.  Results stay in the workspace (see orcai_frontend_stats_host). */
+int orcai_quantile_select(const float* x, int64_t n, int64_t rank_lo, int64_t rank_hi, void* workspace, void* stream);
+
+/* Turn the selected raw order statistics into clip bounds.
+ *   use_ref = 1: values are un-referenced dB from orcai_stft_db; ref_db = 10*log10(max(pmax,1e-10)),
+ *                bound = max(selected - ref_db, -top_db)                    (spectrogram.py:51-53)
+ *   use_ref = 0: values already are final dB (drop-in preprocess entry): bound = selected. */
+int orcai_frontend_finalize(int use_ref, float top_db, void* workspace, void* stream);
+
+/* In place: v = max(x - ref_db, -top_db) (when use_ref), clip to [p_lo, p_hi], (v - p_lo)/(p_hi - p_lo)
+ * (spectrogram.py:78-83).  Bounds are read from the workspace on the device. */
+int orcai_clip_normalize(float* x, int64_t n, const void* workspace, void* stream);
+
+/* In place: x = max(x - ref_db, -top_db): the dB array calculate_spectrogram returns
+ * (spectrogram.py:51-53). */
+int orcai_db_reference(float* x, int64_t n, const void* workspace, void* stream);
+
+/* [F, T] -> [T, f_hi - f_lo] crop + transpose (spectrogram.py:68, :86) for the drop-in
+ * preprocess_spectrogram entry whose input is the reference's [freq, time] layout. */
+int orcai_crop_transpose(const float* in_ft, int64_t n_freq, int64_t n_frames, int f_lo, int f_hi, float* out_tf, void* stream);
+
+/* Synchronises `stream` and copies {pmax, ref_db, p_lo, p_hi, sel_lo_raw, sel_hi_raw} to the host. */
+int orcai_frontend_stats_host(const void* workspace, float stats_host[6], void* stream);
+
+/* One call = reset + stft_db + select + finalize + clip_normalize: the whole of make_spectrogram
+ * (spectrogram.py:90-147) after file decode.  rank_lo/rank_hi as for orcai_quantile_select with
+ * n = n_frames * k_crop. */
+int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop,
+                           int64_t rank_lo, int64_t rank_hi, float top_db, float* out, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORCAI_HIP_H */

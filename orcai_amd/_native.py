@@ -1,0 +1,87 @@
+"""ctypes binding of liborcai_hip.so (include/orcai_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails the error is raised.
+Device memory, streams and process groups come from PyTorch-ROCm; the library itself only
+sees raw device pointers and a hipStream_t.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "liborcai_hip.so"
+
+_lib = None
+
+c_i64 = C.c_int64
+c_f32p = C.c_void_p  # device pointers travel as void*
+
+_SIGNATURES = {
+    "orcai_version": (C.c_char_p, []),
+    "orcai_frontend_workspace_bytes": (C.c_size_t, []),
+    "orcai_frontend_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orcai_stft_db": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_hist_level1": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_quantile_select": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_frontend_finalize": (C.c_int, [C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "orcai_clip_normalize": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_db_reference": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_crop_transpose": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_frontend_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
+    "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def exported_symbols() -> list[str]:
+    """Every symbol include/orcai_hip.h declares (kept in sync by tests/test_capi_symbols.py)."""
+    return list(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load liborcai_hip.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m orcai_amd.build` (needs hipcc). " "orcai_amd has no CPU fallback."
+            )
+        try:
+            handle = C.CDLL(str(LIB_PATH))
+        except OSError as e:  # missing ROCm runtime etc.
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code == -1:
+        raise ValueError(f"{what}: bad argument (ORCAI_E_BADARG)")
+    if code == -2:
+        raise NotImplementedError(f"{what}: unsupported parameter combination on the HIP path (ORCAI_E_UNSUPPORTED)")
+    raise RuntimeError(f"{what}: HIP error {code}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (must be contiguous)."""
+    assert t.is_contiguous(), "native ops need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

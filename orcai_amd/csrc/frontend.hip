@@ -1,0 +1,645 @@
+// frontend.hip -- STFT / dB / exact quantile clip / normalise for gfx950 (MI355X).
+//
+// Replaces the arithmetic of /root/reference/src/orcAI/spectrogram.py:34-39 (librosa.stft),
+// :51-53 (amplitude_to_db(ref=np.max)) and :58-87 (preprocess_spectrogram).
+//
+// Data flow (one recording):
+//   pass A  stft_db_kernel      PCM f32 -> L[t][k] = 10*log10(max(|X|^2,1e-10)), k < k_crop   (HBM: R pcm, W L)
+//                               + max |X|^2 over all 257 bins (atomicMax) + level-1 histogram of L (LDS)
+//   scan1   select_scan1_kernel level-1 histogram -> key interval of each wanted rank
+//   pass C  hist2_kernel        re-read L, histogram the keys inside the two intervals (<= 2 rounds)
+//   scan2   select_scan2_kernel interval -> exact key
+//   final   clip_normalize      in place: max(L - ref_db, -80) -> clip -> (v - lo)/(hi - lo)     (HBM: R L, W out)
+//
+// The order statistic is selected on the un-referenced values L: v = max(L - ref_db, -80) is monotone
+// non-decreasing in L, so the k-th smallest v is that function of the k-th smallest L (exact).
+//
+// STFT kernel layout: a wavefront (64 lanes) transforms 4 consecutive frames at once, 16 lanes per
+// frame.  A 512-point real frame is packed as 256 complex points z[n] = x[2n] + i x[2n+1] and
+// transformed as 16 x 16 (four-step): FFT-16 in registers over n2 (n = n1 + 16 n2, n1 = lane),
+// twiddle W256^(n1 k2), 16x16 transpose through a wave-private padded LDS tile, FFT-16 in registers
+// over n1, then the real-FFT split with the mirrored bin fetched by ds_bpermute.  The 4 frames' 171
+// kept bins are staged in the same LDS tile and leave as one contiguous 2736-byte run of dwordx4 stores.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+
+#include "orcai_hip.h"
+
+namespace {
+
+constexpr int NFFT = 512;
+constexpr int NB1 = 2561;    // level-1 buckets: 1280 negative + 1 around zero + 1280 positive
+constexpr int NB1_PAD = 2568;
+constexpr int NB2 = 65536;   // level-2 bins per round
+constexpr float AMIN_POW = 1e-10f;
+constexpr float DB_PER_LOG2 = 3.0102999566398120f;  // 10*log10(2)
+
+struct SelState {
+  uint32_t klo;       // first key of the current interval
+  uint32_t done;      // 1 once the interval is a single key
+  uint64_t width;     // number of keys in the interval
+  uint64_t rank;      // 0-based rank of the wanted element inside the interval
+};
+
+struct Workspace {
+  uint32_t hist1[NB1_PAD];
+  uint32_t hist2[2][NB2];
+  SelState sel[2];
+  uint32_t pmax_bits;  // max |X|^2 (non-negative float, so uint order == float order)
+  uint32_t use_ref;
+  float ref_db;        // 10*log10(max(pmax, 1e-10))
+  float floor_db;      // -top_db
+  float p_lo, p_hi;    // clip bounds in final dB
+  float sel_raw[2];    // selected raw order statistics
+};
+
+__device__ float g_window[NFFT];
+__device__ float2 g_tw256[256];  // [k2*16 + n1] = exp(-2 pi i n1 k2 / 256)
+__device__ float2 g_tw512[260];  // [k] = (cos, sin)(2 pi k / 512), k = 0..256
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float power_to_db(float p) {
+  return __builtin_amdgcn_logf(fmaxf(p, AMIN_POW)) * DB_PER_LOG2;
+}
+// Monotone map key -> level-1 bucket: 128 buckets per octave for 0.125 <= |x| < 128, one bucket around 0.
+__device__ __forceinline__ int bucket1(uint32_t key) {
+  uint32_t k16 = key >> 16;
+  if (k16 < 0x3D00u) return 0;
+  if (k16 <= 0x41FFu) return (int)(k16 - 0x3D00u);
+  if (k16 < 0xBE00u) return 1280;
+  if (k16 <= 0xC2FFu) return 1281 + (int)(k16 - 0xBE00u);
+  return 2560;
+}
+__device__ __forceinline__ void bucket1_range(int b, uint32_t& klo, uint64_t& width) {
+  if (b == 0) { klo = 0u; width = 0x3D010000ull; }
+  else if (b < 1280) { klo = (0x3D00u + (uint32_t)b) << 16; width = 65536ull; }
+  else if (b == 1280) { klo = 0x42000000u; width = 0xBE000000ull - 0x42000000ull; }
+  else if (b < 2560) { klo = (0xBE00u + (uint32_t)(b - 1281)) << 16; width = 65536ull; }
+  else { klo = 0xC2FF0000u; width = 0x100000000ull - 0xC2FF0000ull; }
+}
+__device__ __forceinline__ int shift_for(uint64_t width) {
+  int s = 0;
+  while ((width >> s) > (uint64_t)NB2) ++s;
+  return s;
+}
+
+// ---------------------------------------------------------------- FFT-16 in registers
+__device__ __forceinline__ void bfly4(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr, float& di) {
+  float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+  float t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+  ar = t0r + t2r; ai = t0i + t2i;
+  cr = t0r - t2r; ci = t0i - t2i;
+  br = t1r + t3i; bi = t1i - t3r;
+  dr = t1r - t3i; di = t1i + t3r;
+}
+__device__ __forceinline__ void cmul(float& r, float& i, float wr, float wi) {
+  float tr = r * wr - i * wi;
+  i = r * wi + i * wr;
+  r = tr;
+}
+// In-place forward FFT-16; output bin k ends up at position P16(k).
+#define P16(k) (4 * ((k) & 3) + ((k) >> 2))
+__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) bfly4(re[a], im[a], re[a + 4], im[a + 4], re[a + 8], im[a + 8], re[a + 12], im[a + 12]);
+  // position a + 4q holds y[a][q]; multiply by W16^(a q)
+  cmul(re[1 + 4], im[1 + 4], C1, -S1);    // a=1,q=1 : W^1
+  cmul(re[1 + 8], im[1 + 8], R2, -R2);    // a=1,q=2 : W^2
+  cmul(re[1 + 12], im[1 + 12], S1, -C1);  // a=1,q=3 : W^3
+  cmul(re[2 + 4], im[2 + 4], R2, -R2);    // a=2,q=1 : W^2
+  { float t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }  // a=2,q=2 : W^4 = -i
+  cmul(re[2 + 12], im[2 + 12], -R2, -R2); // a=2,q=3 : W^6
+  cmul(re[3 + 4], im[3 + 4], S1, -C1);    // a=3,q=1 : W^3
+  cmul(re[3 + 8], im[3 + 8], -R2, -R2);   // a=3,q=2 : W^6
+  cmul(re[3 + 12], im[3 + 12], -C1, S1);  // a=3,q=3 : W^9
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bfly4(re[4 * q], im[4 * q], re[4 * q + 1], im[4 * q + 1], re[4 * q + 2], im[4 * q + 2], re[4 * q + 3], im[4 * q + 3]);
+}
+
+constexpr int ROW_BYTES = 144;               // 16 complex (128 B) + 16 B pad: conflict-free b128 row reads
+constexpr int FRAME_BYTES = 16 * ROW_BYTES;  // 2304
+constexpr int WAVE_BYTES = 4 * FRAME_BYTES;  // 9216, also holds the 4 x k_crop output staging (<= 4112 B)
+
+struct __attribute__((aligned(16))) StftLds {
+  unsigned char tile[4][WAVE_BYTES];
+  float2 tw256[256];
+  float2 tw512[260];
+  uint32_t hist[NB1_PAD];
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool EVEN_HOP>
+__global__ __launch_bounds__(256) void stft_db_kernel(const float* __restrict__ pcm, int64_t n_samples, int hop, int64_t n_frames,
+                                                       int k_crop, float* __restrict__ out, Workspace* __restrict__ ws) {
+  __shared__ StftLds lds;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int l16 = lane & 15;  // n1, later k2
+  const int fsub = lane >> 4; // frame within the wave
+
+  for (int i = tid; i < 256; i += 256) lds.tw256[i] = g_tw256[i];
+  for (int i = tid; i < 257; i += 256) lds.tw512[i] = g_tw512[i];
+  for (int i = tid; i < NB1_PAD; i += 256) lds.hist[i] = 0u;
+
+  // window: lane needs w[2n], w[2n+1] for n = n1 + 16 j
+  float wre[16], wim[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float2 w = *reinterpret_cast<const float2*>(&g_window[2 * (l16 + 16 * j)]);
+    wre[j] = w.x;
+    wim[j] = w.y;
+  }
+  __syncthreads();
+
+  unsigned char* my_tile = lds.tile[wave];
+  unsigned char* my_frame = my_tile + fsub * FRAME_BYTES;
+  float pmax = 0.0f;
+
+  const int64_t n_groups = (n_frames + 15) >> 4;
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
+    const int64_t t = t0w + fsub;
+    const bool valid = t < n_frames;
+    const int64_t s0 = t * (int64_t)hop - (NFFT / 2);
+
+    float re[16], im[16];
+    const bool interior = (t0w * (int64_t)hop - (NFFT / 2) >= 0) && ((t0w + 3) * (int64_t)hop + (NFFT / 2) <= n_samples) &&
+                          (t0w + 3 < n_frames);
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int64_t s = s0 + 2 * (l16 + 16 * j);
+        float x0, x1;
+        if (EVEN_HOP) {
+          float2 v = *reinterpret_cast<const float2*>(pcm + s);
+          x0 = v.x; x1 = v.y;
+        } else {
+          x0 = pcm[s]; x1 = pcm[s + 1];
+        }
+        re[j] = x0 * wre[j];
+        im[j] = x1 * wim[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int64_t s = s0 + 2 * (l16 + 16 * j);
+        float x0 = (valid && s >= 0 && s < n_samples) ? pcm[s] : 0.0f;
+        float x1 = (valid && s + 1 >= 0 && s + 1 < n_samples) ? pcm[s + 1] : 0.0f;
+        re[j] = x0 * wre[j];
+        im[j] = x1 * wim[j];
+      }
+    }
+
+    // step 1: FFT-16 over n2 -> Y[n1][k2] at position P16(k2); step 2: twiddle W256^(n1 k2)
+    fft16(re, im);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) {
+      float2 w = lds.tw256[k2 * 16 + l16];
+      cmul(re[P16(k2)], im[P16(k2)], w.x, w.y);
+    }
+    // step 3: transpose through the wave-private tile: row k2, column n1
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2)
+      *reinterpret_cast<float2*>(my_frame + k2 * ROW_BYTES + l16 * 8) = make_float2(re[P16(k2)], im[P16(k2)]);
+    wave_lds_fence();
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      float4 v = *reinterpret_cast<const float4*>(my_frame + l16 * ROW_BYTES + h * 16);
+      re[2 * h] = v.x; im[2 * h] = v.y; re[2 * h + 1] = v.z; im[2 * h + 1] = v.w;
+    }
+    // step 4: FFT-16 over n1 -> Z[16 k1 + k2] at position P16(k1), lane = k2
+    fft16(re, im);
+    wave_lds_fence();  // all lanes have read the tile before it is reused as output staging
+
+    // step 5: real-FFT split.  A = Z[k], B = Z[256-k]: lane (16-k2)&15, register 15-k1 (k2 != 0) or (16-k1)&15 (k2 == 0).
+    const int src_lane = (lane & 48) | ((16 - l16) & 15);
+    float* stage = reinterpret_cast<float*>(my_tile) + fsub * k_crop;
+    const float z0r = re[P16(0)], z0i = im[P16(0)];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const float ar = re[P16(k1)], ai = im[P16(k1)];
+      float br = __shfl(re[P16(15 - k1)], src_lane, 64);
+      float bi = __shfl(im[P16(15 - k1)], src_lane, 64);
+      if (l16 == 0) { br = re[P16((16 - k1) & 15)]; bi = im[P16((16 - k1) & 15)]; }
+      const int k = 16 * k1 + l16;
+      const float2 cs = lds.tw512[k];
+      const float er = 0.5f * (ar + br), ei = 0.5f * (ai - bi);
+      const float orr = 0.5f * (ai + bi), oi = -0.5f * (ar - br);
+      const float xr = er + (cs.x * orr + cs.y * oi);
+      const float xi = ei + (cs.x * oi - cs.y * orr);
+      const float p = xr * xr + xi * xi;
+      if (valid) pmax = fmaxf(pmax, p);
+      if (k < k_crop) {
+        const float L = power_to_db(p);
+        stage[k] = L;
+        if (valid) atomicAdd(&lds.hist[bucket1(f2key(L))], 1u);
+      }
+    }
+    if (l16 == 0) {  // Nyquist bin 256: X = Re Z0 - Im Z0
+      const float x = z0r - z0i;
+      const float p = x * x;
+      if (valid) pmax = fmaxf(pmax, p);
+      if (256 < k_crop) {
+        const float L = power_to_db(p);
+        stage[256] = L;
+        if (valid) atomicAdd(&lds.hist[bucket1(f2key(L))], 1u);
+      }
+    }
+    wave_lds_fence();
+
+    // step 6: the wave's valid frames are one contiguous run of out[]
+    int64_t nv = n_frames - t0w;
+    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    const int count = (int)nv * k_crop;
+    float* dst = out + t0w * (int64_t)k_crop;  // 16-byte aligned: t0w % 4 == 0
+    const float* src = reinterpret_cast<const float*>(my_tile);
+    const int n4 = count >> 2;
+    for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int i = (n4 << 2) + lane; i < count; i += 64) dst[i] = src[i];
+    wave_lds_fence();
+  }
+
+  // wave max -> one atomic per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
+  if (lane == 0) atomicMax(&ws->pmax_bits, __float_as_uint(pmax));
+  __syncthreads();
+  for (int i = tid; i < NB1; i += 256) {
+    uint32_t c = lds.hist[i];
+    if (c) atomicAdd(&ws->hist1[i], c);
+  }
+}
+
+// ---------------------------------------------------------------- generic level-1 histogram
+__global__ __launch_bounds__(256) void hist1_kernel(const float* __restrict__ x, int64_t n, Workspace* __restrict__ ws) {
+  __shared__ uint32_t h[NB1_PAD];
+  for (int i = threadIdx.x; i < NB1_PAD; i += 256) h[i] = 0u;
+  __syncthreads();
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    atomicAdd(&h[bucket1(f2key(v.x))], 1u);
+    atomicAdd(&h[bucket1(f2key(v.y))], 1u);
+    atomicAdd(&h[bucket1(f2key(v.z))], 1u);
+    atomicAdd(&h[bucket1(f2key(v.w))], 1u);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) atomicAdd(&h[bucket1(f2key(x[i]))], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB1; i += 256) {
+    uint32_t c = h[i];
+    if (c) atomicAdd(&ws->hist1[i], c);
+  }
+}
+
+// ---------------------------------------------------------------- block-wide "which bin holds rank r"
+// 1024 threads; hist has nb bins; returns (bin, exclusive prefix of that bin) to every thread.
+// If zero_after, bins are reset to 0 after being read (ready for the next round).
+__device__ void find_bin(uint32_t* hist, int nb, uint64_t rank, bool zero_after, int& bin_out, uint64_t& prefix_out) {
+  __shared__ uint64_t wave_tot[16];
+  __shared__ int s_bin;
+  __shared__ uint64_t s_prefix;
+  const int tid = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int b0 = tid * per;
+  uint64_t sum = 0;
+  for (int i = 0; i < per; ++i) {
+    int b = b0 + i;
+    if (b < nb) sum += hist[b];
+  }
+  // inclusive scan of `sum` over the block
+  uint64_t incl = sum;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint64_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  if (tid == 0) { s_bin = nb - 1; s_prefix = 0; }
+  __syncthreads();
+  uint64_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  const uint64_t excl = base + incl - sum;
+  if (rank >= excl && rank < excl + sum) {
+    uint64_t run = excl;
+    for (int i = 0; i < per; ++i) {
+      int b = b0 + i;
+      if (b >= nb) break;
+      uint64_t c = hist[b];
+      if (rank < run + c) { s_bin = b; s_prefix = run; break; }
+      run += c;
+    }
+  }
+  __syncthreads();
+  bin_out = s_bin;
+  prefix_out = s_prefix;
+  if (zero_after) {
+    for (int i = 0; i < per; ++i) {
+      int b = b0 + i;
+      if (b < nb) hist[b] = 0u;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void select_scan1_kernel(Workspace* __restrict__ ws, int64_t rank_lo, int64_t rank_hi) {
+  for (int q = 0; q < 2; ++q) {
+    int bin; uint64_t prefix;
+    const uint64_t rank = (uint64_t)(q == 0 ? rank_lo : rank_hi);
+    find_bin(ws->hist1, NB1, rank, false, bin, prefix);
+    if (threadIdx.x == 0) {
+      uint32_t klo; uint64_t width;
+      bucket1_range(bin, klo, width);
+      ws->sel[q].klo = klo;
+      ws->sel[q].width = width;
+      ws->sel[q].rank = rank - prefix;
+      ws->sel[q].done = (width == 1) ? 1u : 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hist2_kernel(const float* __restrict__ x, int64_t n, Workspace* __restrict__ ws) {
+  const SelState s0 = ws->sel[0], s1 = ws->sel[1];
+  if (s0.done && s1.done) return;
+  const int sh0 = shift_for(s0.width), sh1 = shift_for(s1.width);
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n_round = ((n + stride - 1) / stride) * stride;  // keep whole waves in the loop for the ballots
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_round; i += stride) {
+    const bool live = i < n;
+    const uint32_t key = live ? f2key(x[i]) : 0u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const SelState& s = q ? s1 : s0;
+      if (s.done) continue;
+      const uint32_t d = key - s.klo;
+      const bool in = live && key >= s.klo && (uint64_t)d < s.width;
+      const uint32_t bin = d >> (q ? sh1 : sh0);
+      const unsigned long long mask = __ballot(in);
+      if (mask == 0ull) continue;
+      const int first = __ffsll((long long)mask) - 1;
+      const uint32_t b0 = __shfl(bin, first, 64);
+      const bool uniform = __all(!in || bin == b0);
+      if (uniform) {
+        if (lane == first) atomicAdd(&ws->hist2[q][b0], (uint32_t)__popcll(mask));
+      } else if (in) {
+        atomicAdd(&ws->hist2[q][bin], 1u);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void select_scan2_kernel(Workspace* __restrict__ ws) {
+  for (int q = 0; q < 2; ++q) {
+    SelState s = ws->sel[q];
+    if (s.done) continue;  // uniform across the block
+    const int sh = shift_for(s.width);
+    const int nb = (int)((s.width + ((1ull << sh) - 1)) >> sh);
+    int bin; uint64_t prefix;
+    find_bin(ws->hist2[q], nb, s.rank, true, bin, prefix);
+    if (threadIdx.x == 0) {
+      const uint64_t off = (uint64_t)bin << sh;
+      uint64_t w = 1ull << sh;
+      if (off + w > s.width) w = s.width - off;
+      ws->sel[q].klo = s.klo + (uint32_t)off;
+      ws->sel[q].width = w;
+      ws->sel[q].rank = s.rank - prefix;
+      ws->sel[q].done = (w == 1) ? 1u : 0u;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void finalize_kernel(Workspace* __restrict__ ws, int use_ref, float top_db) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float lo = key2f(ws->sel[0].klo), hi = key2f(ws->sel[1].klo);
+  ws->sel_raw[0] = lo;
+  ws->sel_raw[1] = hi;
+  ws->use_ref = (uint32_t)use_ref;
+  if (use_ref) {
+    const float ref_db = power_to_db(__uint_as_float(ws->pmax_bits));
+    ws->ref_db = ref_db;
+    ws->floor_db = -top_db;
+    ws->p_lo = fmaxf(lo - ref_db, -top_db);
+    ws->p_hi = fmaxf(hi - ref_db, -top_db);
+  } else {
+    ws->ref_db = 0.0f;
+    ws->floor_db = -INFINITY;
+    ws->p_lo = lo;
+    ws->p_hi = hi;
+  }
+}
+
+__device__ __forceinline__ float norm1(float x, float ref_db, float floor_db, float lo, float hi, float range) {
+  float v = fmaxf(x - ref_db, floor_db);
+  v = fminf(fmaxf(v, lo), hi);
+  return (v - lo) / range;
+}
+
+__global__ __launch_bounds__(256) void clip_normalize_kernel(float* __restrict__ x, int64_t n, const Workspace* __restrict__ ws) {
+  const float ref_db = ws->ref_db, floor_db = ws->floor_db, lo = ws->p_lo, hi = ws->p_hi;
+  const float range = hi - lo;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    v.x = norm1(v.x, ref_db, floor_db, lo, hi, range);
+    v.y = norm1(v.y, ref_db, floor_db, lo, hi, range);
+    v.z = norm1(v.z, ref_db, floor_db, lo, hi, range);
+    v.w = norm1(v.w, ref_db, floor_db, lo, hi, range);
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) x[i] = norm1(x[i], ref_db, floor_db, lo, hi, range);
+}
+
+__global__ __launch_bounds__(256) void db_reference_kernel(float* __restrict__ x, int64_t n, const Workspace* __restrict__ ws) {
+  const float ref_db = ws->ref_db, floor_db = ws->floor_db;  // set by finalize_kernel(use_ref = 1)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] = fmaxf(x[i] - ref_db, floor_db);
+}
+
+// [F,T] -> [T,K]: 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void crop_transpose_kernel(const float* __restrict__ in, int64_t n_freq, int64_t n_frames, int f_lo, int K,
+                                                              float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int64_t t0 = (int64_t)blockIdx.x * 32;
+  const int k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r;
+    const int64_t t = t0 + tx;
+    tile[r][tx] = (k < K && t < n_frames) ? in[(int64_t)(f_lo + k) * n_frames + t] : 0.0f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t t = t0 + r;
+    const int k = k0 + tx;
+    if (k < K && t < n_frames) out[t * K + k] = tile[tx][r];
+  }
+}
+
+std::once_flag g_tables_once;
+int g_tables_err = 0;
+
+void init_tables() {
+  static float window[NFFT];
+  static float2 tw256[256];
+  static float2 tw512[260];
+  const double PI = 3.14159265358979323846;
+  for (int n = 0; n < NFFT; ++n) window[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / NFFT));  // periodic Hann
+  for (int k2 = 0; k2 < 16; ++k2)
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const double a = -2.0 * PI * (double)(n1 * k2) / 256.0;
+      tw256[k2 * 16 + n1] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+  for (int k = 0; k < 260; ++k) {
+    const double a = 2.0 * PI * (double)k / 512.0;
+    tw512[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_window), window, sizeof(window));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw256), tw256, sizeof(tw256));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_tw512), tw512, sizeof(tw512));
+  g_tables_err = (int)e;
+}
+
+inline int grid_for(int64_t items_per_block_unit, int64_t n_units) {
+  (void)items_per_block_unit;
+  int64_t g = n_units;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t orcai_frontend_workspace_bytes(void) { return (sizeof(Workspace) + 255) & ~(size_t)255; }
+
+int orcai_frontend_reset(void* workspace, void* stream) {
+  if (!workspace) return ORCAI_E_BADARG;
+  return (int)hipMemsetAsync(workspace, 0, sizeof(Workspace), (hipStream_t)stream);
+}
+
+int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop, float* out_db, void* workspace,
+                  void* stream) {
+  if (!pcm || !out_db || !workspace || n_samples <= 0 || hop <= 0 || k_crop < 1 || k_crop > 257) return ORCAI_E_BADARG;
+  if (n_fft != NFFT) return ORCAI_E_UNSUPPORTED;
+  if (n_frames != 1 + n_samples / hop) return ORCAI_E_BADARG;
+  if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 7)) return ORCAI_E_BADARG;
+  std::call_once(g_tables_once, init_tables);
+  if (g_tables_err) return g_tables_err;
+  const int64_t n_groups = (n_frames + 15) / 16;
+  int grid = (int)(n_groups < 256 * 3 ? n_groups : 256 * 3);
+  Workspace* ws = (Workspace*)workspace;
+  if ((hop & 1) == 0)
+    hipLaunchKernelGGL(stft_db_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, hop, n_frames, k_crop, out_db, ws);
+  else
+    hipLaunchKernelGGL(stft_db_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, hop, n_frames, k_crop, out_db, ws);
+  return (int)hipGetLastError();
+}
+
+int orcai_hist_level1(const float* x, int64_t n, void* workspace, void* stream) {
+  if (!x || !workspace || n <= 0 || ((uintptr_t)x & 15)) return ORCAI_E_BADARG;
+  int grid = grid_for(0, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(hist1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (Workspace*)workspace);
+  return (int)hipGetLastError();
+}
+
+int orcai_quantile_select(const float* x, int64_t n, int64_t rank_lo, int64_t rank_hi, void* workspace, void* stream) {
+  if (!x || !workspace || n <= 0 || rank_lo < 0 || rank_hi < 0 || rank_lo >= n || rank_hi >= n) return ORCAI_E_BADARG;
+  Workspace* ws = (Workspace*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(select_scan1_kernel, dim3(1), dim3(1024), 0, s, ws, rank_lo, rank_hi);
+  int grid = grid_for(0, (n + 255) / 256);
+  for (int round = 0; round < 2; ++round) {  // a level-1 bucket is at most 2^31 keys wide: two 16-bit rounds
+    hipLaunchKernelGGL(hist2_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
+    hipLaunchKernelGGL(select_scan2_kernel, dim3(1), dim3(1024), 0, s, ws);
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_frontend_finalize(int use_ref, float top_db, void* workspace, void* stream) {
+  if (!workspace) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (Workspace*)workspace, use_ref, top_db);
+  return (int)hipGetLastError();
+}
+
+int orcai_clip_normalize(float* x, int64_t n, const void* workspace, void* stream) {
+  if (!x || !workspace || n <= 0 || ((uintptr_t)x & 15)) return ORCAI_E_BADARG;
+  int grid = grid_for(0, (n / 4 + 255) / 256);
+  hipLaunchKernelGGL(clip_normalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (const Workspace*)workspace);
+  return (int)hipGetLastError();
+}
+
+int orcai_db_reference(float* x, int64_t n, const void* workspace, void* stream) {
+  if (!x || !workspace || n <= 0) return ORCAI_E_BADARG;
+  int grid = grid_for(0, (n + 255) / 256);
+  hipLaunchKernelGGL(db_reference_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (const Workspace*)workspace);
+  return (int)hipGetLastError();
+}
+
+int orcai_crop_transpose(const float* in_ft, int64_t n_freq, int64_t n_frames, int f_lo, int f_hi, float* out_tf, void* stream) {
+  if (!in_ft || !out_tf || n_freq <= 0 || n_frames <= 0 || f_lo < 0 || f_hi <= f_lo || f_hi > n_freq) return ORCAI_E_BADARG;
+  const int K = f_hi - f_lo;
+  dim3 grid((unsigned)((n_frames + 31) / 32), (unsigned)((K + 31) / 32));
+  hipLaunchKernelGGL(crop_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in_ft, n_freq, n_frames, f_lo, K, out_tf);
+  return (int)hipGetLastError();
+}
+
+int orcai_frontend_stats_host(const void* workspace, float stats_host[6], void* stream) {
+  if (!workspace || !stats_host) return ORCAI_E_BADARG;
+  Workspace* h = new Workspace;
+  hipError_t e = hipMemcpyAsync(h, workspace, sizeof(Workspace), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) {
+    float pm;
+    std::memcpy(&pm, &h->pmax_bits, 4);
+    stats_host[0] = pm;
+    stats_host[1] = h->ref_db;
+    stats_host[2] = h->p_lo;
+    stats_host[3] = h->p_hi;
+    stats_host[4] = h->sel_raw[0];
+    stats_host[5] = h->sel_raw[1];
+  }
+  delete h;
+  return (int)e;
+}
+
+int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop, int64_t rank_lo,
+                           int64_t rank_hi, float top_db, float* out, void* workspace, void* stream) {
+  int e = orcai_frontend_reset(workspace, stream);
+  if (e) return e;
+  e = orcai_stft_db(pcm, n_samples, n_fft, hop, n_frames, k_crop, out, workspace, stream);
+  if (e) return e;
+  const int64_t n = n_frames * (int64_t)k_crop;
+  e = orcai_quantile_select(out, n, rank_lo, rank_hi, workspace, stream);
+  if (e) return e;
+  e = orcai_frontend_finalize(1, top_db, workspace, stream);
+  if (e) return e;
+  return orcai_clip_normalize(out, n, workspace, stream);
+}
+
+}  // extern "C"
