@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the orcAI hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend|predict]
+
+One "step" = one pass of the hot path over one synthetic recording already resident in HBM.
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own
+recording (independent objects: weak scaling, no data-path collective); the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
+
+The CPU baseline leg times the CPU oracle (``oracle/``: numpy/scipy/torch-CPU restatement of the
+reference path -- "port", NOT Keras/TF/librosa, which cannot be installed here) on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+SPEC_PARAM = {"sampling_rate": 48000, "nfft": 512, "n_overlap": 256, "freq_range": [0, 16000], "quantiles": [0.01, 0.999], "duration": 4}
+SNIPPET_FRAMES = 736
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def synth_pcm_device(n_samples: int, seed: int, device) -> torch.Tensor:
+    """White noise + chirps generated on the device (same recipe as orcai_amd.synthetic)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = 0.2 * torch.randn(n_samples, generator=g, device=device, dtype=torch.float32)
+    sr = 48000
+    t = torch.arange(int(0.5 * sr), device=device, dtype=torch.float32) / sr
+    chirp = 0.5 * torch.sin(2 * np.pi * (1000.0 * t + 0.5 * 16000.0 * t * t))
+    for start in range(5 * sr, n_samples - len(chirp), 17 * sr):
+        x[start : start + len(chirp)] += chirp
+    x = torch.clamp(x / 1.6, -1.0, 1.0)
+    return (torch.round(x * 32767.0) / 32768.0).contiguous()  # PCM16-representable
+
+
+class FrontendWorkload:
+    """configs[1]: STFT + dB + exact percentile clip + normalise of 1024 snippets of audio."""
+
+    name = "frontend_1024_snippets_48kHz"
+    metric = "audio_seconds_per_s"
+    unit = "audio-s/s"
+    dtype = "f32"
+
+    def __init__(self, device, rank):
+        from orcai_amd import _native as N
+        from orcai_amd.frontend import TOP_DB, FrontEnd, nearest_rank_index
+
+        self.N, self.TOP_DB = N, TOP_DB
+        self.fe = FrontEnd(device)
+        self.lib = self.fe.lib
+        self.n_snippets = 1024
+        self.n_samples = self.n_snippets * SNIPPET_FRAMES * 256
+        self.T = 1 + self.n_samples // 256
+        self.K = 171
+        self.pcm = synth_pcm_device(self.n_samples, 2 + rank, device)
+        self.out = torch.empty((self.T, self.K), dtype=torch.float32, device=device)
+        total = self.T * self.K
+        self.r_lo = nearest_rank_index(total, 0.01)
+        self.r_hi = nearest_rank_index(total, 0.999)
+        self.units_per_step = self.n_samples / 48000.0  # audio seconds
+        # PCM read once (753 664 B/snippet) + [T,171] f32 written once (503 424 B/snippet)
+        self.kernel_alg_bytes = 1257088.0 * self.n_snippets
+        self.kernel_name = "stft_db_kernel"
+        self.ev = []
+
+    def step(self, timed: bool):
+        N, lib = self.N, self.lib
+        s = N.stream_ptr()
+        ws = N.ptr(self.fe.workspace)
+        n = self.T * self.K
+        N.check(lib.orcai_frontend_reset(ws, s), "reset")
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        N.check(lib.orcai_stft_db(N.ptr(self.pcm), self.n_samples, 512, 256, self.T, self.K, N.ptr(self.out), ws, s), "stft_db")
+        if timed:
+            e1.record()
+            self.ev.append((e0, e1))
+        N.check(lib.orcai_quantile_select(N.ptr(self.out), n, self.r_lo, self.r_hi, ws, s), "select")
+        N.check(lib.orcai_frontend_finalize(1, self.TOP_DB, ws, s), "finalize")
+        N.check(lib.orcai_clip_normalize(N.ptr(self.out), n, ws, s), "normalize")
+
+    def roofline(self):
+        ms = [a.elapsed_time(b) for a, b in self.ev]
+        avg_s = float(np.mean(ms)) * 1e-3
+        achieved = self.kernel_alg_bytes / avg_s / 1e9
+        return {"bound": "hbm", "kernel": self.kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(avg_s * 1e3, 4)}
+
+    def cpu_baseline(self):
+        from oracle import frontend_ref as F
+
+        seconds = 240.0
+        rng = np.random.default_rng(7)
+        y = (np.round(np.clip(0.125 * rng.standard_normal(int(seconds * 48000)), -1, 1) * 32767) / 32768).astype(np.float32)
+        F.make_spectrogram_ref(y[: 48000 * 5], {"spectrogram": SPEC_PARAM})  # warm-up
+        t0 = time.perf_counter()
+        F.make_spectrogram_ref(y, {"spectrogram": SPEC_PARAM})
+        dt = time.perf_counter() - t0
+        return {"value": round(seconds / dt, 1), "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": f"oracle.frontend_ref.make_spectrogram_ref (numpy/scipy) on {seconds:.0f} s of 48 kHz noise, {dt:.1f} s wall"}
+
+
+WORKLOADS = {"frontend": FrontendWorkload}
+try:
+    from bench_predict import PredictWorkload  # added once the model forward exists
+
+    WORKLOADS["predict"] = PredictWorkload
+except ImportError:
+    pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="predict" if "predict" in WORKLOADS else "frontend", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    wl = WORKLOADS[args.workload](device, rank)
+    for _ in range(args.warmup):
+        wl.step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = wl.units_per_step * args.steps * world / elapsed
+        line = {
+            "metric": wl.metric, "value": round(value, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": wl.dtype, "data": "synthetic",
+            "config": {"workload": wl.name, "units_per_step_per_gpu": round(wl.units_per_step, 3), "parallelism": f"independent recordings x{world}"},
+            "roofline": wl.roofline(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,54 @@ int orcai_frontend_stats_host(const void* workspace, float stats_host[6], void* 
 int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop,
                            int64_t rank_lo, int64_t rank_hi, float top_db, float* out, void* workspace, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Model forward, inference (architectures.py:162-241 as executed by model.predict, predict.py:265-268)
+ * Activations are planar fp32 [snippet][channel][H = time][W = freq].  BatchNormalization is folded on
+ * the host into per-channel (scale, shift): scale = gamma*rsqrt(var + 1e-3),
+ * shift = beta - mean*scale + conv_bias*scale.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
+ *   in              f32, snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
+ *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is
+ *                   materialised (predict.py:253-261 makes one)
+ *   w               f32[k*k][16] (Keras kernel (k,k,1,16) flattened); scale/shift f32[16]
+ *   out             f32[B][16][H][W] */
+int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
+                        const float* shift, float* out, void* stream);
+
+/* [ReLU] -> SeparableConv2D(Cout, k, same) -> BN -> [ReLU]   (architectures.py:174-189, :198-206)
+ *   dw   f32[Cin][k*k]   (Keras depthwise kernel (k,k,Cin,1) transposed)
+ *   pw   f32[Cin][Cout]  (Keras pointwise kernel (1,1,Cin,Cout))
+ *   out_layout 0: f32[B][Cout][H][W];  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
+ *   Reshape((-1, W*C)) of the NHWC tensor (architectures.py:208).  Cout <= 64, k in {3,5,7}. */
+int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
+                     const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream);
+
+/* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
+ *   s f32[B][C][H][W], prev f32[B][Cp][H][W], wr f32[Cp][C], br f32[C] -> out f32[B][C][ceil(H/2)][ceil(W/2)] */
+int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, const float* wr, const float* br, float* out,
+                       void* stream);
+
+/* C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]; act 0 = identity, 1 = ReLU; bias/scale/shift may be NULL.
+ * Used for the LSTM input projections x*W + b (architectures.py:210-229) and Dense(128, relu) + BN (:231-237). */
+int orcai_gemm_bias_act(const float* A, const float* Bm, const float* bias, const float* scale, const float* shift, float* C, int64_t M, int N,
+                        int K, int act, void* stream);
+
+/* Both directions of one Bidirectional(LSTM(units, return_sequences=True)) given xz = x*W + b.
+ *   xz  f32[B][T][2][4*units], Uw f32[2][units][4*units], both with the gate columns in the kernel's order:
+ *       column 32*w + 16*nt + j  <-  Keras column (2*nt + (j>>3))*units + 8*w + (j&7)     (gate order i,f,c,o)
+ *   out f32[B][T][2*units] = concat(forward, backward) at each time step.  units in {64, 128}. */
+int orcai_lstm_recurrent(const float* xz, const float* Uw, int B, int T, int units, float* out, void* stream);
+
+/* out[M][N] = sigmoid(x[M][K] * w[K][N] + b[N]),  N <= 8   (architectures.py:239) */
+int orcai_dense_sigmoid(const float* x, const float* w, const float* bias, int64_t M, int K, int N, float* out, void* stream);
+
+/* predict.py:276-293: overlay the n snippet predictions [n][P][L] at offsets i*step, count overlaps, divide.
+ *   agg f64[S][L], cnt f64[S];  float64 accumulation in snippet order (bit-exact with the numpy loop). */
+int orcai_overlap_average(const float* pred, int n, int P, int L, int step, int64_t S, double* agg, double* cnt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,23 @@ def random_params(seed=1, randomize_bn=True, **arch):
     return out
 
 
+def calibrated_params(seed=1, calib_batch=2, **arch):
+    """random_params + BN moving statistics set from the activations of a seeded calibration batch (jittered),
+    so that every layer's output is O(1) as in a trained network.  Without this the synthetic network's
+    features reach ~1e3 and the LSTM becomes ill-conditioned (fp32 vs fp64 differ by 1e-4 on the CPU too)."""
+    global _CALIBRATE
+    p = random_params(seed=seed, **arch)
+    shape = arch.get("input_shape", (736, 171, 1))
+    rng = np.random.default_rng(seed + 1000)
+    x = rng.random((calib_batch, *shape), dtype=np.float32)
+    _CALIBRATE = rng
+    try:
+        forward_ref(p, x, dtype=torch.float64)
+    finally:
+        _CALIBRATE = None
+    return p
+
+
 def same_pad(n, k, s):
     """TF/Keras padding="same": (out, pad_before, pad_after)."""
     out = -(-n // s)
@@ -111,8 +128,16 @@ def _conv_same(x, kernel, bias, stride, dtype, groups=1):
     return F.conv2d(x, w, b, stride=stride, groups=groups)
 
 
+_CALIBRATE = None  # set by calibrated_params(): np.random.Generator used to jitter the measured statistics
+
+
 def _bn_infer(x, p, name, dtype, axis=1):
     """tf.nn.batch_normalization form: inv = gamma*rsqrt(var+eps); x*inv + (beta - mean*inv)."""
+    if _CALIBRATE is not None:  # give the BN layer the statistics a trained network would have (activations stay O(1))
+        dims = [d for d in range(x.dim()) if d != axis]
+        c = x.shape[axis]
+        p[name + "/mean"] = (x.mean(dim=dims).numpy() + 0.1 * _CALIBRATE.standard_normal(c)).astype(np.float32)
+        p[name + "/var"] = (x.var(dim=dims, unbiased=False).numpy() * _CALIBRATE.uniform(0.8, 1.25, c) + 1e-3).astype(np.float32)
     inv = _t(p[name + "/gamma"], dtype) * torch.rsqrt(_t(p[name + "/var"], dtype) + BN_EPS)
     shift = _t(p[name + "/beta"], dtype) - _t(p[name + "/mean"], dtype) * inv
     shape = [1] * x.dim()

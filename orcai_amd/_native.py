@@ -29,6 +29,13 @@ _SIGNATURES = {
     "orcai_db_reference": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_crop_transpose": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_frontend_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
+    "orcai_conv0_bn_relu": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_sepconv_bn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "orcai_lstm_recurrent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_dense_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_overlap_average": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -46,6 +53,10 @@ def lib() -> C.CDLL:
     """Load liborcai_hip.so once; raise loudly when it is absent (no fallback path exists)."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64; it must be in the process BEFORE this library is dlopen'ed so both
+        # share ONE HIP runtime (otherwise /opt/rocm's copy is pulled in and torch's device pointers are
+        # foreign to it: hipErrorNoDevice).
+        import torch  # noqa: F401
         if not LIB_PATH.exists():
             raise NativeLibraryError(
                 f"{LIB_PATH} not found: build it with `python -m orcai_amd.build` (needs hipcc). " "orcai_amd has no CPU fallback."

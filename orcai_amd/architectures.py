@@ -1,0 +1,376 @@
+"""Model definitions.  Mirrors reference ``src/orcAI/architectures.py`` for the hot path:
+``res_net_LSTM_arch`` (:120-241), ``build_model`` (:316-359), the architecture registry (:307-312).
+
+The returned object is duck-type compatible with what the reference's callers use of a keras.Model
+(``predict``, ``count_params``, ``trainable_weights``, ``non_trainable_weights``, ``input_shape``,
+``output_shape``, ``save``/``load_weights``); all arithmetic runs in the HIP kernels of
+``csrc/model_fwd.hip`` behind the C ABI -- there is no CPU path.
+
+Weights are kept on the host as a dict of numpy arrays with Keras variable layouts (so a converter from
+``.keras`` only has to rename), and are folded / permuted into the kernels' layouts when uploaded.
+"""
+
+from __future__ import annotations
+
+import math
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from orcai_amd import _native as N
+from orcai_amd.auxiliary import MASK_VALUE, Messenger  # noqa: F401  (re-exported like the reference)
+
+BN_EPS = 1e-3  # keras BatchNormalization default epsilon
+ENTRY_FILTERS = 16  # architectures.py:164
+FINAL_FILTERS = 36  # architectures.py:199
+DENSE_UNITS = 128  # architectures.py:232
+
+
+def _bn_names(prefix):
+    return [f"{prefix}/gamma", f"{prefix}/beta", f"{prefix}/mean", f"{prefix}/var"]
+
+
+def lstm_column_permutation(units: int) -> np.ndarray:
+    """perm[p] = Keras gate column held by kernel column p (see orcai_lstm_recurrent in orcai_hip.h)."""
+    p = np.arange(4 * units)
+    w, nt, j = p // 32, (p // 16) % 2, p % 16
+    return (2 * nt + (j >> 3)) * units + 8 * w + (j & 7)
+
+
+class ResNetLSTM:
+    """CNN with residual connections + 2 bidirectional LSTM layers (architectures.py:120-241)."""
+
+    architecture = "ResNetLSTM"
+
+    def __init__(self, input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, lstm_units=128,
+                 conv_initializer="he_normal", lstm_initializer="glorot_uniform", seed=None, **unused):
+        self.input_hw = (int(input_shape[0]), int(input_shape[1]))
+        if int(input_shape[2]) != 1:
+            raise ValueError("ResNetLSTM expects a single input channel")
+        self.num_labels = int(num_labels)
+        self.filters = [int(f) for f in filters]
+        self.kernel_size = int(kernel_size)
+        self.dropout_rate = float(dropout_rate)
+        self.lstm_units = int(lstm_units)
+        if self.kernel_size not in (3, 5, 7):
+            raise NotImplementedError("HIP kernels implement kernel_size 3, 5 and 7")
+        if self.lstm_units not in (64, 128):
+            raise NotImplementedError("HIP LSTM kernel implements lstm_units 64 and 128")
+        if max(self.filters + [FINAL_FILTERS]) > 64:
+            raise NotImplementedError("HIP separable-conv kernel implements up to 64 filters")
+        if self.num_labels > 8:
+            raise NotImplementedError("HIP head kernel implements up to 8 labels")
+        self.weights: dict[str, np.ndarray] = {}
+        self._init_weights(np.random.default_rng(seed))
+        self._dev = None  # folded device copies
+        self._ws = {}
+
+    # ------------------------------------------------------------------ structure
+    @property
+    def input_shape(self):
+        return (None, self.input_hw[0], self.input_hw[1], 1)
+
+    @property
+    def output_shape(self):
+        return (None, self.out_steps, self.num_labels)
+
+    @property
+    def time_reduction(self) -> int:
+        return 2 ** len(self.filters)
+
+    def stage_shapes(self):
+        """[(H, W, C)] after the entry conv and after each block (SAME pooling: ceil(n/2))."""
+        h, w = self.input_hw
+        shapes = [(h, w, ENTRY_FILTERS)]
+        for f in self.filters:
+            h, w = -(-h // 2), -(-w // 2)
+            shapes.append((h, w, f))
+        return shapes
+
+    @property
+    def out_steps(self) -> int:
+        return self.stage_shapes()[-1][0]
+
+    def variable_spec(self):
+        """Ordered (name, shape, initializer-kind, trainable)."""
+        k, u = self.kernel_size, self.lstm_units
+        spec = [("conv0/kernel", (k, k, 1, ENTRY_FILTERS), "he", True), ("conv0/bias", (ENTRY_FILTERS,), "zeros", True)]
+        spec += self._bn_spec("bn0", ENTRY_FILTERS)
+        c = ENTRY_FILTERS
+        for b, s in enumerate(self.filters, start=1):
+            spec += [(f"b{b}/sep_a/depthwise", (k, k, c, 1), "he", True), (f"b{b}/sep_a/pointwise", (1, 1, c, s), "he", True), (f"b{b}/sep_a/bias", (s,), "zeros", True)]
+            spec += self._bn_spec(f"b{b}/bn_a", s)
+            spec += [(f"b{b}/sep_b/depthwise", (k, k, s, 1), "he", True), (f"b{b}/sep_b/pointwise", (1, 1, s, s), "he", True), (f"b{b}/sep_b/bias", (s,), "zeros", True)]
+            spec += self._bn_spec(f"b{b}/bn_b", s)
+            spec += [(f"b{b}/res/kernel", (1, 1, c, s), "he", True), (f"b{b}/res/bias", (s,), "zeros", True)]
+            c = s
+        spec += [("sep_f/depthwise", (k, k, c, 1), "he", True), ("sep_f/pointwise", (1, 1, c, FINAL_FILTERS), "he", True), ("sep_f/bias", (FINAL_FILTERS,), "zeros", True)]
+        spec += self._bn_spec("bn_f", FINAL_FILTERS)
+        feat = self.stage_shapes()[-1][1] * FINAL_FILTERS
+        for layer, fin in ((1, feat), (2, 2 * u)):
+            for d in ("fwd", "bwd"):
+                spec += [(f"lstm{layer}/{d}/kernel", (fin, 4 * u), "glorot", True), (f"lstm{layer}/{d}/recurrent", (u, 4 * u), "orthogonal", True),
+                         (f"lstm{layer}/{d}/bias", (4 * u,), "lstm_bias", True)]
+        spec += [("dense1/kernel", (2 * u, DENSE_UNITS), "he", True), ("dense1/bias", (DENSE_UNITS,), "zeros", True)]
+        spec += self._bn_spec("bn_d", DENSE_UNITS)
+        spec += [("dense2/kernel", (DENSE_UNITS, self.num_labels), "glorot", True), ("dense2/bias", (self.num_labels,), "zeros", True)]
+        return spec
+
+    @staticmethod
+    def _bn_spec(name, c):
+        return [(f"{name}/gamma", (c,), "ones", True), (f"{name}/beta", (c,), "zeros", True), (f"{name}/mean", (c,), "zeros", False), (f"{name}/var", (c,), "ones", False)]
+
+    def _init_weights(self, rng):
+        """Keras initialisers: he_normal (truncated normal, stddev sqrt(2/fan_in)/.8796), glorot_uniform,
+        orthogonal recurrent kernels, unit_forget_bias (architectures.py:126-127, 210-229)."""
+        for name, shape, kind, _ in self.variable_spec():
+            if kind == "he":
+                if len(shape) == 4:
+                    fan_in = shape[0] * shape[1] * shape[2]
+                else:
+                    fan_in = shape[0]
+                std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+                w = np.clip(rng.standard_normal(shape), -2.0, 2.0) * std
+            elif kind == "glorot":
+                limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+                w = rng.uniform(-limit, limit, shape)
+            elif kind == "orthogonal":
+                a = rng.standard_normal((shape[1], shape[0]))
+                q, r = np.linalg.qr(a)
+                q = q * np.sign(np.diag(r))
+                w = q.T[: shape[0], : shape[1]]
+            elif kind == "lstm_bias":
+                u = shape[0] // 4
+                w = np.zeros(shape)
+                w[u : 2 * u] = 1.0
+            elif kind == "ones":
+                w = np.ones(shape)
+            else:
+                w = np.zeros(shape)
+            self.weights[name] = np.ascontiguousarray(w, dtype=np.float32)
+
+    # ------------------------------------------------------------------ keras-shaped accessors
+    @property
+    def trainable_weights(self):
+        return [self.weights[n] for n, _, _, t in self.variable_spec() if t]
+
+    @property
+    def non_trainable_weights(self):
+        return [self.weights[n] for n, _, _, t in self.variable_spec() if not t]
+
+    def count_params(self) -> int:
+        return int(sum(int(np.prod(s)) for _, s, _, _ in self.variable_spec()))
+
+    def set_weights_dict(self, weights: dict) -> None:
+        for name, shape, _, _ in self.variable_spec():
+            if name not in weights:
+                raise ValueError(f"missing weight {name}")
+            w = np.asarray(weights[name], dtype=np.float32)
+            if tuple(w.shape) != tuple(shape):
+                raise ValueError(f"weight {name}: shape {w.shape} != {shape}")
+            self.weights[name] = np.ascontiguousarray(w)
+        self._dev = None
+
+    def save_weights(self, path) -> None:
+        np.savez(path, **self.weights)
+
+    def load_weights(self, path) -> None:
+        with np.load(path) as z:
+            self.set_weights_dict({k: z[k] for k in z.files})
+
+    def save(self, path, include_optimizer: bool = True) -> None:
+        """Stores ``<path minus .keras>.weights.npz`` (Keras' zip/HDF5 container cannot be written here)."""
+        path = Path(path)
+        if path.suffix == ".keras":
+            path = path.with_suffix("")
+        from orcai_amd.io import WEIGHTS_SUFFIX
+
+        self.save_weights(str(path) + WEIGHTS_SUFFIX)
+
+    # ------------------------------------------------------------------ device side
+    def _upload(self, a) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    def _fold_bn(self, bn, bias=None):
+        w = self.weights
+        g, b, m, v = (w[n].astype(np.float64) for n in _bn_names(bn))
+        scale = g / np.sqrt(v + BN_EPS)
+        shift = b - m * scale
+        if bias is not None:
+            shift = shift + bias.astype(np.float64) * scale
+        return self._upload(scale), self._upload(shift)
+
+    def prepare(self) -> dict:
+        """Fold BN, transpose / permute weights into kernel layouts, upload.  Cached until weights change."""
+        if self._dev is not None:
+            return self._dev
+        if not torch.cuda.is_available():
+            raise RuntimeError("orcai_amd model needs a ROCm GPU: there is no CPU fallback")
+        N.lib()
+        w = self.weights
+        k = self.kernel_size
+        d = {}
+        d["conv0/w"] = self._upload(w["conv0/kernel"].reshape(k * k, ENTRY_FILTERS))
+        d["conv0/scale"], d["conv0/shift"] = self._fold_bn("bn0", w["conv0/bias"])
+
+        def sep(name, bn):
+            dwk = w[name + "/depthwise"]  # (k,k,c,1)
+            c = dwk.shape[2]
+            d[name + "/dw"] = self._upload(dwk[:, :, :, 0].transpose(2, 0, 1).reshape(c, k * k))
+            d[name + "/pw"] = self._upload(w[name + "/pointwise"][0, 0])
+            d[name + "/scale"], d[name + "/shift"] = self._fold_bn(bn, w[name + "/bias"])
+
+        for b in range(1, len(self.filters) + 1):
+            sep(f"b{b}/sep_a", f"b{b}/bn_a")
+            sep(f"b{b}/sep_b", f"b{b}/bn_b")
+            d[f"b{b}/res/w"] = self._upload(w[f"b{b}/res/kernel"][0, 0])
+            d[f"b{b}/res/b"] = self._upload(w[f"b{b}/res/bias"])
+        sep("sep_f", "bn_f")
+        perm = lstm_column_permutation(self.lstm_units)
+        for layer in (1, 2):
+            ks = [w[f"lstm{layer}/{dd}/kernel"][:, perm] for dd in ("fwd", "bwd")]
+            bs = [w[f"lstm{layer}/{dd}/bias"][perm] for dd in ("fwd", "bwd")]
+            us = [w[f"lstm{layer}/{dd}/recurrent"][:, perm] for dd in ("fwd", "bwd")]
+            d[f"lstm{layer}/W"] = self._upload(np.concatenate(ks, axis=1))  # [Fin][2*4u]
+            d[f"lstm{layer}/b"] = self._upload(np.concatenate(bs))
+            d[f"lstm{layer}/U"] = self._upload(np.stack(us))  # [2][u][4u]
+        d["dense1/W"] = self._upload(w["dense1/kernel"])
+        d["dense1/b"] = self._upload(w["dense1/bias"])
+        d["dense1/scale"], d["dense1/shift"] = self._fold_bn("bn_d")
+        d["dense2/W"] = self._upload(w["dense2/kernel"])
+        d["dense2/b"] = self._upload(w["dense2/bias"])
+        self._dev = d
+        return d
+
+    def _buffers(self, B: int) -> dict:
+        """Activation workspace for a chunk of B snippets (allocated once per chunk size)."""
+        if B in self._ws:
+            return self._ws[B]
+        shapes = self.stage_shapes()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ws = {}
+        ws["prev0"] = torch.empty((B, ENTRY_FILTERS, shapes[0][0], shapes[0][1]), dtype=torch.float32, device=dev)
+        for b, f in enumerate(self.filters, start=1):
+            h, wd, _ = shapes[b - 1]
+            ws[f"a{b}"] = torch.empty((B, f, h, wd), dtype=torch.float32, device=dev)
+            ws[f"b{b}"] = torch.empty((B, f, h, wd), dtype=torch.float32, device=dev)
+            ws[f"prev{b}"] = torch.empty((B, f, shapes[b][0], shapes[b][1]), dtype=torch.float32, device=dev)
+        h, wd, _ = shapes[-1]
+        u = self.lstm_units
+        ws["feat"] = torch.empty((B, h, wd * FINAL_FILTERS), dtype=torch.float32, device=dev)
+        ws["xz"] = torch.empty((B, h, 2, 4 * u), dtype=torch.float32, device=dev)
+        ws["h1"] = torch.empty((B, h, 2 * u), dtype=torch.float32, device=dev)
+        ws["h2"] = torch.empty((B, h, 2 * u), dtype=torch.float32, device=dev)
+        ws["d1"] = torch.empty((B, h, DENSE_UNITS), dtype=torch.float32, device=dev)
+        self._ws = {B: ws}  # keep only the latest chunk size resident
+        return ws
+
+    def forward_device(self, src: torch.Tensor, snippet_stride: int, B: int, out: torch.Tensor, keep: dict | None = None) -> None:
+        """One chunk: B snippets starting at ``src`` (f32 cuda), snippet b at element offset b*snippet_stride,
+        each [H][W] row-major.  Writes probabilities into out[B][steps][labels]."""
+        lib = N.lib()
+        d = self.prepare()
+        ws = self._buffers(B)
+        st = N.stream_ptr()
+        H, W = self.input_hw
+        k = self.kernel_size
+        shapes = self.stage_shapes()
+        N.check(lib.orcai_conv0_bn_relu(src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]), N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]),
+                                        N.ptr(ws["prev0"]), st), "orcai_conv0_bn_relu")
+        c = ENTRY_FILTERS
+        for b, f in enumerate(self.filters, start=1):
+            h, wd, _ = shapes[b - 1]
+            prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
+            pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
+            N.check(lib.orcai_sepconv_bn(N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
+                                         N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st), "orcai_sepconv_bn")
+            N.check(lib.orcai_sepconv_bn(N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
+                                         N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st), "orcai_sepconv_bn")
+            N.check(lib.orcai_pool_res_add(N.ptr(bb), N.ptr(prev), B, f, c, h, wd, N.ptr(d[f"b{b}/res/w"]), N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st),
+                    "orcai_pool_res_add")
+            c = f
+        h, wd, _ = shapes[-1]
+        last = ws[f"prev{len(self.filters)}"]
+        N.check(lib.orcai_sepconv_bn(N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]), N.ptr(d["sep_f/scale"]),
+                                     N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, N.ptr(ws["feat"]), st), "orcai_sepconv_bn")
+        u = self.lstm_units
+        M = B * h
+        x, fin = ws["feat"], wd * FINAL_FILTERS
+        for layer, hout in ((1, ws["h1"]), (2, ws["h2"])):
+            N.check(lib.orcai_gemm_bias_act(N.ptr(x), N.ptr(d[f"lstm{layer}/W"]), N.ptr(d[f"lstm{layer}/b"]), None, None, N.ptr(ws["xz"]), M, 8 * u, fin, 0, st),
+                    "orcai_gemm_bias_act")
+            N.check(lib.orcai_lstm_recurrent(N.ptr(ws["xz"]), N.ptr(d[f"lstm{layer}/U"]), B, h, u, N.ptr(hout), st), "orcai_lstm_recurrent")
+            x, fin = hout, 2 * u
+        N.check(lib.orcai_gemm_bias_act(N.ptr(ws["h2"]), N.ptr(d["dense1/W"]), N.ptr(d["dense1/b"]), N.ptr(d["dense1/scale"]), N.ptr(d["dense1/shift"]),
+                                        N.ptr(ws["d1"]), M, DENSE_UNITS, 2 * u, 1, st), "orcai_gemm_bias_act")
+        N.check(lib.orcai_dense_sigmoid(N.ptr(ws["d1"]), N.ptr(d["dense2/W"]), N.ptr(d["dense2/b"]), M, DENSE_UNITS, self.num_labels, out.data_ptr(), st),
+                "orcai_dense_sigmoid")
+        if keep is not None:
+            for name, t in ws.items():
+                keep[name] = t.clone()
+
+    def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 64) -> torch.Tensor:
+        """All 50 %-overlapping snippets of a device spectrogram [T][W] -> f32 cuda [n][steps][labels].
+        Snippet i = rows [i*H/2, i*H/2 + H) (predict.py:244-261), read in place (no snippet copy)."""
+        H, W = self.input_hw
+        assert spectrogram.is_cuda and spectrogram.dtype == torch.float32 and spectrogram.is_contiguous()
+        assert spectrogram.shape[1] == W
+        shift = H // 2
+        n = (spectrogram.shape[0] - H) // shift + 1
+        out = torch.empty((max(n, 0), self.out_steps, self.num_labels), dtype=torch.float32, device=spectrogram.device)
+        for s in range(0, n, chunk):
+            B = min(chunk, n - s)
+            self.forward_device(spectrogram[s * shift :], shift * W, B, out[s:])
+        return out
+
+    def predict(self, snippets, batch_size: int = 64, verbose: int = 0, **unused) -> np.ndarray:
+        """keras.Model.predict for materialised snippets: ndarray [n, H, W, 1] -> ndarray [n, steps, labels] (float32)."""
+        x = np.asarray(snippets, dtype=np.float32)
+        H, W = self.input_hw
+        if x.ndim != 4 or x.shape[1:] != (H, W, 1):
+            raise ValueError(f"expected input of shape (n, {H}, {W}, 1), got {x.shape}")
+        n = x.shape[0]
+        out = np.empty((n, self.out_steps, self.num_labels), dtype=np.float32)
+        for s in range(0, n, batch_size):
+            B = min(batch_size, n - s)
+            xd = torch.from_numpy(np.ascontiguousarray(x[s : s + B, :, :, 0])).cuda()
+            od = torch.empty((B, self.out_steps, self.num_labels), dtype=torch.float32, device=xd.device)
+            self.forward_device(xd, H * W, B, od)
+            out[s : s + B] = od.cpu().numpy()
+        return out
+
+
+def res_net_LSTM_arch(input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, lstm_units=128, conv_initializer="he_normal",
+                      lstm_initializer="glorot_uniform", **unused) -> ResNetLSTM:
+    """architectures.py:120-241."""
+    return ResNetLSTM(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units, conv_initializer, lstm_initializer, **unused)
+
+
+def res_net_1Dconv_arch(*args, **kwargs):
+    raise NotImplementedError("ResNet1DConv (architectures.py:18-117) is not on the orcai-V1 hot path yet (SURVEY 8f row 1)")
+
+
+ORCAI_ARCHITECTURES_FN = {"ResNet1DConv": res_net_1Dconv_arch, "ResNetLSTM": res_net_LSTM_arch}
+ORCAI_ARCHITECTURES = list(ORCAI_ARCHITECTURES_FN.keys())
+
+
+def build_model(input_shape, orcai_parameter: dict, msgr: Messenger = Messenger(verbosity=0)):
+    """architectures.py:316-359."""
+    num_labels = len(orcai_parameter["calls"])
+    if orcai_parameter["architecture"] in ORCAI_ARCHITECTURES:
+        model = ORCAI_ARCHITECTURES_FN[orcai_parameter["architecture"]](input_shape, num_labels, **orcai_parameter["model"])
+    else:
+        raise ValueError(f"Unknown model architecture: {orcai_parameter['architecture']}")
+    n_filters = len(orcai_parameter["model"]["filters"])
+    output_shape = (input_shape[0] // 2**n_filters, num_labels)
+    msgr.part("Building model architecture")
+    msgr.info(f"model name:          {orcai_parameter['name']}")
+    msgr.info(f"model architecture:  {orcai_parameter['architecture']}")
+    msgr.info(f"model input shape:   {model.input_shape}")
+    msgr.info(f"model output shape:  {model.output_shape}")
+    msgr.info(f"actual input_shape:  {input_shape}")
+    msgr.info(f"actual output_shape: {output_shape}")
+    msgr.info(f"n_filters:           {n_filters}")
+    msgr.info(f"num_labels:          {num_labels}")
+    return model

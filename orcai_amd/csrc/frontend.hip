@@ -35,6 +35,7 @@ constexpr int NFFT = 512;
 constexpr int NB1 = 2561;    // level-1 buckets: 1280 negative + 1 around zero + 1280 positive
 constexpr int NB1_PAD = 2568;
 constexpr int NB2 = 65536;   // level-2 bins per round
+constexpr int NB2C = NB2 / 256;
 constexpr float AMIN_POW = 1e-10f;
 constexpr float DB_PER_LOG2 = 3.0102999566398120f;  // 10*log10(2)
 
@@ -48,6 +49,7 @@ struct SelState {
 struct Workspace {
   uint32_t hist1[NB1_PAD];
   uint32_t hist2[2][NB2];
+  uint32_t hist2c[2][NB2C];  // coarse: one counter per 256 fine bins
   SelState sel[2];
   uint32_t pmax_bits;  // max |X|^2 (non-negative float, so uint order == float order)
   uint32_t use_ref;
@@ -379,34 +381,55 @@ __global__ __launch_bounds__(1024) void select_scan1_kernel(Workspace* __restric
   }
 }
 
+// One element against both pending intervals.  All 64 lanes of the wave call this together.
+__device__ __forceinline__ void hist2_add(uint32_t key, bool live, const SelState& s0, const SelState& s1, int sh0, int sh1, int lane,
+                                          Workspace* __restrict__ ws) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const SelState& s = q ? s1 : s0;
+    if (s.done) continue;  // wave-uniform
+    const uint32_t d = key - s.klo;
+    const bool in = live && key >= s.klo && (uint64_t)d < s.width;
+    const uint32_t bin = d >> (q ? sh1 : sh0);
+    const unsigned long long mask = __ballot(in);
+    if (mask == 0ull) continue;
+    const int first = __ffsll((long long)mask) - 1;
+    const uint32_t b0 = __shfl(bin, first, 64);
+    const bool uniform = __all(!in || bin == b0);
+    if (uniform) {  // ties / constant input: one atomic per wave instead of 64 on one address
+      if (lane == first) {
+        const uint32_t c = (uint32_t)__popcll(mask);
+        atomicAdd(&ws->hist2[q][b0], c);
+        atomicAdd(&ws->hist2c[q][b0 >> 8], c);
+      }
+    } else if (in) {
+      atomicAdd(&ws->hist2[q][bin], 1u);
+      atomicAdd(&ws->hist2c[q][bin >> 8], 1u);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void hist2_kernel(const float* __restrict__ x, int64_t n, Workspace* __restrict__ ws) {
   const SelState s0 = ws->sel[0], s1 = ws->sel[1];
   if (s0.done && s1.done) return;
   const int sh0 = shift_for(s0.width), sh1 = shift_for(s1.width);
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t n_round = ((n + stride - 1) / stride) * stride;  // keep whole waves in the loop for the ballots
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_round; i += stride) {
+  const int64_t n4 = n >> 2;
+  const int64_t n4_round = ((n4 + stride - 1) / stride) * stride;  // whole waves stay in the loop for the ballots
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4_round; i += stride) {
+    const bool live = i < n4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) v = reinterpret_cast<const float4*>(x)[i];
+    hist2_add(f2key(v.x), live, s0, s1, sh0, sh1, lane, ws);
+    hist2_add(f2key(v.y), live, s0, s1, sh0, sh1, lane, ws);
+    hist2_add(f2key(v.z), live, s0, s1, sh0, sh1, lane, ws);
+    hist2_add(f2key(v.w), live, s0, s1, sh0, sh1, lane, ws);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {  // tail (< 4 elements), one full wave
+    const int64_t i = (n4 << 2) + threadIdx.x;
     const bool live = i < n;
-    const uint32_t key = live ? f2key(x[i]) : 0u;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const SelState& s = q ? s1 : s0;
-      if (s.done) continue;
-      const uint32_t d = key - s.klo;
-      const bool in = live && key >= s.klo && (uint64_t)d < s.width;
-      const uint32_t bin = d >> (q ? sh1 : sh0);
-      const unsigned long long mask = __ballot(in);
-      if (mask == 0ull) continue;
-      const int first = __ffsll((long long)mask) - 1;
-      const uint32_t b0 = __shfl(bin, first, 64);
-      const bool uniform = __all(!in || bin == b0);
-      if (uniform) {
-        if (lane == first) atomicAdd(&ws->hist2[q][b0], (uint32_t)__popcll(mask));
-      } else if (in) {
-        atomicAdd(&ws->hist2[q][bin], 1u);
-      }
-    }
+    hist2_add(live ? f2key(x[i]) : 0u, live, s0, s1, sh0, sh1, lane, ws);
   }
 }
 
@@ -415,9 +438,11 @@ __global__ __launch_bounds__(1024) void select_scan2_kernel(Workspace* __restric
     SelState s = ws->sel[q];
     if (s.done) continue;  // uniform across the block
     const int sh = shift_for(s.width);
-    const int nb = (int)((s.width + ((1ull << sh) - 1)) >> sh);
-    int bin; uint64_t prefix;
-    find_bin(ws->hist2[q], nb, s.rank, true, bin, prefix);
+    int cbin, bin; uint64_t cprefix, prefix;
+    find_bin(ws->hist2c[q], NB2C, s.rank, false, cbin, cprefix);              // which group of 256 fine bins
+    find_bin(ws->hist2[q] + cbin * 256, 256, s.rank - cprefix, false, bin, prefix);  // which bin inside it
+    bin += cbin * 256;
+    prefix += cprefix;
     if (threadIdx.x == 0) {
       const uint64_t off = (uint64_t)bin << sh;
       uint64_t w = 1ull << sh;
@@ -573,8 +598,11 @@ int orcai_quantile_select(const float* x, int64_t n, int64_t rank_lo, int64_t ra
   Workspace* ws = (Workspace*)workspace;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(select_scan1_kernel, dim3(1), dim3(1024), 0, s, ws, rank_lo, rank_hi);
-  int grid = grid_for(0, (n + 255) / 256);
+  if ((uintptr_t)x & 15) return ORCAI_E_BADARG;
+  int grid = grid_for(0, (n / 4 + 255) / 256);
   for (int round = 0; round < 2; ++round) {  // a level-1 bucket is at most 2^31 keys wide: two 16-bit rounds
+    hipError_t e = hipMemsetAsync(ws->hist2, 0, sizeof(ws->hist2) + sizeof(ws->hist2c), s);  // hist2c follows hist2
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hist2_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
     hipLaunchKernelGGL(select_scan2_kernel, dim3(1), dim3(1024), 0, s, ws);
   }

@@ -1,0 +1,509 @@
+// model_fwd.hip -- inference forward of orcAI's ResNetLSTM (architectures.py:162-241) for gfx950.
+//
+// Activation layout in HBM: planar fp32 [snippet][channel][time H][freq W]  (W innermost).
+// The pointwise (1x1) convolutions, the LSTM projections/recurrence and the dense layers are f32-input
+// MFMA contractions (v_mfma_f32_16x16x4_f32: exact f32, same rounding as an fmaf chain), with the
+// OUTPUT-CHANNEL index on the MFMA row and the PIXEL (or batch) index on the MFMA column/lane, so a
+// D fragment register holds 16 consecutive pixels of one channel -> planar stores need no transpose.
+//
+// Keras semantics restated (no Keras in this image; oracle/model_ref.py is the checker):
+//   Conv2D/SeparableConv2D padding="same" stride 1 -> symmetric zero pad (k-1)/2
+//   MaxPooling2D((3,2), strides 2, "same")       -> out = ceil(in/2), -inf pad, pad_before = total/2
+//   Conv2D(1x1, strides 2, "same")               -> no pad, samples rows/cols 0,2,4,...
+//   BatchNormalization (inference)               -> y = x*scale + shift, folded on the host
+//   LSTM gate order i,f,c,o; Bidirectional concat [fwd, bwd]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "orcai_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// =========================================================================================
+// conv0: Conv2D(16, k x k, same) on a single-channel input + folded BN + ReLU   (architectures.py:164-168)
+// =========================================================================================
+template <int KS>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W,
+                                                     const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][16][H][W]*/) {
+  constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP = HW + 1;
+  __shared__ float halo[HH][HP];
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const float* src = in + (int64_t)b * snippet_stride;
+  for (int i = threadIdx.x; i < HH * HW; i += 256) {
+    const int r = i / HW, c = i % HW;
+    const int y = y0 + r - R, x = x0 + c - R;
+    halo[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(int64_t)y * W + x] : 0.0f;
+  }
+  __syncthreads();
+  const int py = threadIdx.x / TW, px = threadIdx.x % TW;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      const float v = halo[py + dy][px + dx];
+      const float* wt = w + (dy * KS + dx) * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
+    }
+  const int y = y0 + py, x = x0 + px;
+  if (y < H && x < W) {
+    float* o = out + (int64_t)b * 16 * H * W + (int64_t)y * W + x;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[(int64_t)c * H * W] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.0f);
+  }
+}
+
+// =========================================================================================
+// sepconv: [ReLU] -> depthwise k x k (same) -> pointwise 1x1 + bias -> folded BN -> [ReLU]
+//          (architectures.py:174-189, :198-206)
+// One workgroup = one TH x TW pixel tile of one snippet; input channels are processed in chunks of 16:
+//   halo tile of the chunk -> LDS, depthwise by VALU into dwbuf[16][256], then MFMA
+//   D[cout][pixel] += Wpw^T[cout][cin] * dwbuf[cin][pixel].
+// =========================================================================================
+constexpr int DW_PITCH = 272;  // 256 pixels + 16: rows k and k+1 land 16 banks apart -> conflict-free B-fragment reads
+
+template <int KS, int TW, int MT>
+__global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][Cin][H][W]*/, int Cin, int H, int W, int relu_in,
+                                                       const float* __restrict__ dw /*[Cin][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                       int out_layout, float* __restrict__ out) {
+  constexpr int TH = 256 / TW, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP = HW + 1, CH = 16;
+  __shared__ float halo[CH][HH][HP];
+  __shared__ float dwbuf[CH][DW_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const int64_t plane = (int64_t)H * W;
+  const float* src = in + (int64_t)b * Cin * plane;
+  const int py = tid / TW, px = tid % TW;
+  const int lk = lane >> 4, lj = lane & 15;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < Cin; c0 += CH) {
+    // ---- stage the chunk's halo tile (zero outside the image and past the last channel)
+    for (int i = tid; i < CH * HH * HW; i += 256) {
+      const int c = i / (HH * HW), rem = i % (HH * HW), r = rem / HW, q = rem % HW;
+      const int y = y0 + r - R, x = x0 + q - R, ch = c0 + c;
+      float v = 0.0f;
+      if (ch < Cin && y >= 0 && y < H && x >= 0 && x < W) {
+        v = src[(int64_t)ch * plane + (int64_t)y * W + x];
+        if (relu_in) v = fmaxf(v, 0.0f);
+      }
+      halo[c][r][q] = v;
+    }
+    // A fragments of this chunk (pointwise weights, transposed): A[i = cout][k = cin]
+    float afrag[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ci = c0 + kk * 4 + lk, co = m * 16 + lj;
+        afrag[m][kk] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
+      }
+    __syncthreads();
+    // ---- depthwise: thread = pixel, loop over the chunk's channels (weights are wave-uniform)
+#pragma unroll 4
+    for (int c = 0; c < CH; ++c) {
+      const int ch = c0 + c;
+      float s = 0.0f;
+      if (ch < Cin) {
+        const float* wd = dw + ch * (KS * KS);
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < KS; ++dx) s = fmaf(halo[c][py + dy][px + dx], wd[dy * KS + dx], s);
+      }
+      dwbuf[c][tid] = s;
+    }
+    __syncthreads();
+    // ---- pointwise: wave owns pixels [64*wave, 64*wave+64) = 4 column tiles
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float bfrag[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bfrag[n] = dwbuf[kk * 4 + lk][wave * 64 + n * 16 + lj];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = mfma16(afrag[m][kk], bfrag[n], acc[m][n]);
+    }
+  }
+  // ---- epilogue: D[row = 4*(lane>>4)+r -> cout][col = lane&15 -> pixel]
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int p = wave * 64 + n * 16 + lj;
+    const int y = y0 + p / TW, x = x0 + p % TW;
+    if (y >= H || x >= W) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m * 16 + lk * 4 + r;
+        if (co < Cout) {
+          float v = fmaf(acc[m][n][r], scale[co], shift[co]);
+          if (relu_out) v = fmaxf(v, 0.0f);
+          if (out_layout == 0)
+            out[((int64_t)b * Cout + co) * plane + (int64_t)y * W + x] = v;
+          else  // Keras Reshape((-1, W*C)) of NHWC: feature = x*Cout + co   (architectures.py:208)
+            out[((int64_t)b * H + y) * ((int64_t)W * Cout) + (int64_t)x * Cout + co] = v;
+        }
+      }
+  }
+}
+
+// =========================================================================================
+// pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
+// thread = output pixel; grid.y = chunk of 16 output channels; grid.z = snippet
+// =========================================================================================
+__global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s /*[B][C][H][W]*/, const float* __restrict__ prev /*[B][Cp][H][W]*/,
+                                                            int C, int Cp, int H, int W, int Ho, int Wo, int pad_top, int pad_left,
+                                                            const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
+                                                            float* __restrict__ out /*[B][C][Ho][Wo]*/) {
+  const int b = blockIdx.z, co0 = blockIdx.y * 16;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Ho * Wo) return;
+  const int i = idx / Wo, j = idx % Wo;
+  const int64_t plane = (int64_t)H * W;
+  // residual 1x1 stride-2 conv: no padding, samples (2i, 2j)
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+  const float* pp = prev + (int64_t)b * Cp * plane + (int64_t)(2 * i) * W + 2 * j;
+  for (int ci = 0; ci < Cp; ++ci) {
+    const float v = pp[(int64_t)ci * plane];
+    const float* wrow = wr + ci * C + co0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (co0 + c < C) acc[c] = fmaf(v, wrow[c], acc[c]);
+  }
+  const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int co = co0 + c;
+    if (co >= C) break;
+    const float* sp = s + ((int64_t)b * C + co) * plane;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int y = ys + dy, x = xs + dx;
+        if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, sp[(int64_t)y * W + x]);
+      }
+    out[((int64_t)b * C + co) * ((int64_t)Ho * Wo) + idx] = m + (acc[c] + br[co]);
+  }
+}
+
+// =========================================================================================
+// gemm: C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]     (LSTM input projections, Dense-128)
+// 128 x 128 block tile, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (4 x 4 MFMA 16x16x4 tiles).
+// MFMA row = M index, MFMA column = N index.
+// =========================================================================================
+constexpr int GP = 128 + 16;  // LDS pitch: rows k and k+1 16 banks apart
+
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ bias,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ C,
+                                                    int M, int N, int K, int act) {
+  __shared__ float As[16][GP];
+  __shared__ float Bs[16][GP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int64_t m0 = (int64_t)blockIdx.y * 128;
+  const int n0 = blockIdx.x * 128;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // A tile: 128 rows x 16 k; thread loads 8 consecutive k of one row half
+    {
+      const int row = tid >> 1, kh = (tid & 1) * 8;
+      const int64_t m = m0 + row;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = k0 + kh + q;
+        As[kh + q][row] = (m < M && k < K) ? A[m * K + k] : 0.0f;
+      }
+    }
+    // B tile: 16 k x 128 n; thread loads 8 consecutive n of one k row
+    {
+      const int k = tid >> 4, nn = (tid & 15) * 8;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int n = n0 + nn + q;
+        Bs[k][nn + q] = (k0 + k < K && n < N) ? Bm[(int64_t)(k0 + k) * N + n] : 0.0f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float a[4], bq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk * 4 + lk][wm * 64 + i * 16 + lj];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bq[j] = Bs[kk * 4 + lk][wn * 64 + j * 16 + lj];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], bq[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + wm * 64 + i * 16 + lk * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + lj;
+        if (n >= N) continue;
+        float v = acc[i][j][r] + (bias ? bias[n] : 0.0f);
+        if (act == 1) v = fmaxf(v, 0.0f);
+        if (scale) v = fmaf(v, scale[n], shift[n]);
+        C[m * N + n] = v;
+      }
+    }
+}
+
+// =========================================================================================
+// lstm_recurrent: one direction of one Bidirectional(LSTM(u)) layer for a tile of 16 snippets.
+// xz = x*W + b is precomputed by gemm_kernel with PERMUTED gate columns: column p = 32*w + 16*nt + j holds
+//   unit 8*w + (j&7), gate 2*nt + (j>>3)  (gate order i,f,g,o), so wave w owns all four gates of units
+//   [8w, 8w+8).  The recurrent kernel U (u x 4u, same column permutation) stays in registers for all T steps
+//   (u/4 k-steps x 2 column tiles = 64 VGPRs at u = 128); h lives in LDS, c in registers.
+// =========================================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
+                                                      int B, int T, float* __restrict__ out /*[B][T][2U]*/) {
+  constexpr int KSTEPS = U / 4, HP = U + 2;
+  __shared__ float hbuf[2][16][HP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+
+  float ufrag[2][KSTEPS];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) ufrag[nt][kk] = Ud[(int64_t)(kk * 4 + lk) * (4 * U) + wave * 32 + nt * 16 + lj];
+
+  for (int i = tid; i < 2 * 16 * HP; i += U * 8) (&hbuf[0][0][0])[i] = 0.0f;
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int unit = wave * 8 + (lj & 7);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + lk * 4 + r;
+        acc[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+      }
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const float a = hbuf[cur][lj][kk * 4 + lk];  // A[i = batch][k]
+      acc[0] = mfma16(a, ufrag[0][kk], acc[0]);
+      acc[1] = mfma16(a, ufrag[1][kk], acc[1]);
+    }
+    // lane j<8 holds (i, g), lane j+8 holds (f, o) of the same unit: swap across the pair
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mine0 = acc[0][r], mine1 = acc[1][r];
+      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
+      const bool low = lj < 8;
+      const float zi = low ? mine0 : oth0, zf = low ? oth0 : mine0;
+      const float zg = low ? mine1 : oth1, zo = low ? oth1 : mine1;
+      const float c = sigmoidf_(zf) * cst[r] + sigmoidf_(zi) * tanhf_(zg);
+      const float h = sigmoidf_(zo) * tanhf_(c);
+      cst[r] = c;
+      if (low) {
+        const int row = lk * 4 + r;
+        hbuf[cur ^ 1][row][unit] = h;
+        const int bb = b0 + row;
+        if (bb < B) out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =========================================================================================
+// dense_sigmoid: out[m][n] = sigmoid(x[m][:] . w[:][n] + b[n]),  N <= 8   (architectures.py:239)
+// =========================================================================================
+__global__ __launch_bounds__(256) void dense_sigmoid_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             int64_t M, int K, int N, float* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  float acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = 0.0f;
+  const float* xr = x + m * K;
+  for (int k = 0; k < K; ++k) {
+    const float v = xr[k];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+      if (n < N) acc[n] = fmaf(v, w[k * N + n], acc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    if (n < N) out[m * N + n] = 1.0f / (1.0f + expf(-(acc[n] + bias[n])));
+}
+
+// =========================================================================================
+// overlap_average: predict.py:276-293.  Output step s is covered by snippets i with step*i <= s < step*i + P.
+// float64 accumulate in snippet order, then divide by the count (bit-exact with the numpy loop).
+// =========================================================================================
+__global__ __launch_bounds__(256) void overlap_average_kernel(const float* __restrict__ pred /*[n][P][L]*/, int n, int P, int L, int step, int64_t S,
+                                                               double* __restrict__ agg /*[S][L]*/, double* __restrict__ cnt /*[S]*/) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * L) return;
+  const int64_t s = idx / L;
+  const int l = (int)(idx % L);
+  // snippets i with i*step <= s and s - i*step < P
+  int64_t i_hi = s / step;
+  if (i_hi > n - 1) i_hi = n - 1;
+  int64_t i_lo = (s - P + step) / step;  // ceil((s - P + 1)/step)
+  if (s - P + 1 <= 0) i_lo = 0;
+  double sum = 0.0;
+  int c = 0;
+  for (int64_t i = i_lo; i <= i_hi; ++i) {
+    const int64_t off = s - i * step;
+    if (off >= 0 && off < P) {
+      sum += (double)pred[(i * P + off) * L + l];
+      ++c;
+    }
+  }
+  if (c > 0) sum /= (double)c;
+  agg[idx] = sum;
+  if (l == 0) cnt[s] = (double)c;
+}
+
+template <int KS, int TW>
+int launch_sepconv_mt(int MT, dim3 grid, hipStream_t st, const float* in, int Cin, int H, int W, int relu_in, const float* dw, const float* pw,
+                      const float* scale, const float* shift, int Cout, int relu_out, int out_layout, float* out) {
+  switch (MT) {
+    case 1: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 1>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
+    case 2: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 2>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
+    case 3: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 3>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
+    case 4: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 4>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+template <int KS>
+int launch_sepconv(int B, hipStream_t st, const float* in, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale,
+                   const float* shift, int Cout, int relu_out, int out_layout, float* out) {
+  const int MT = (Cout + 15) / 16;
+  if (W > 48) {
+    dim3 grid((W + 31) / 32, (H + 7) / 8, B);
+    return launch_sepconv_mt<KS, 32>(MT, grid, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+  }
+  dim3 grid((W + 15) / 16, (H + 15) / 16, B);
+  return launch_sepconv_mt<KS, 16>(MT, grid, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
+                        const float* shift, float* out, void* stream) {
+  if (!in || !w || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  dim3 grid((W + 31) / 32, (H + 7) / 8, B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
+    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
+    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
+                     const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream) {
+  if (!in || !dw || !pw || !scale || !shift || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
+  if (Cout > 64) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  switch (ksize) {
+    case 3: return launch_sepconv<3>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+    case 5: return launch_sepconv<5>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+    case 7: return launch_sepconv<7>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+}
+
+int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, const float* wr, const float* br, float* out,
+                       void* stream) {
+  if (!s || !prev || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
+  if (tot_h < 0) tot_h = 0;
+  if (tot_w < 0) tot_w = 0;
+  dim3 grid((Ho * Wo + 255) / 256, (C + 15) / 16, B);
+  hipLaunchKernelGGL(pool_res_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, s, prev, C, Cp, H, W, Ho, Wo, tot_h / 2, tot_w / 2, wr, br, out);
+  return (int)hipGetLastError();
+}
+
+int orcai_gemm_bias_act(const float* A, const float* Bm, const float* bias, const float* scale, const float* shift, float* C, int64_t M, int N,
+                        int K, int act, void* stream) {
+  if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0 || (scale && !shift)) return ORCAI_E_BADARG;
+  dim3 grid((N + 127) / 128, (unsigned)((M + 127) / 128));
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, Bm, bias, scale, shift, C, (int)M, N, K, act);
+  return (int)hipGetLastError();
+}
+
+int orcai_lstm_recurrent(const float* xz, const float* Uw, int B, int T, int units, float* out, void* stream) {
+  if (!xz || !Uw || !out || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  dim3 grid((B + 15) / 16, 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (units) {
+    case 128: hipLaunchKernelGGL(lstm_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out); break;
+    case 64: hipLaunchKernelGGL(lstm_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_dense_sigmoid(const float* x, const float* w, const float* bias, int64_t M, int K, int N, float* out, void* stream) {
+  if (!x || !w || !bias || !out || M <= 0 || K <= 0 || N <= 0) return ORCAI_E_BADARG;
+  if (N > 8) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dense_sigmoid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, M, K, N, out);
+  return (int)hipGetLastError();
+}
+
+int orcai_overlap_average(const float* pred, int n, int P, int L, int step, int64_t S, double* agg, double* cnt, void* stream) {
+  if (!pred || !agg || !cnt || n < 0 || P <= 0 || L <= 0 || step <= 0 || S <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(overlap_average_kernel, dim3((unsigned)((S * L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, n, P, L, step, S, agg, cnt);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""CPU tests of the host-side mirror of the reference API (no GPU, no compute calls through the C ABI):
+label extraction against the reference's golden vectors, WAV decode, config handling, C-ABI symbols."""
+
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CALLS = ["BR", "BUZZ", "HERDING", "PHS", "SS", "TAILSLAP", "WHISTLE"]
+
+
+def test_capi_exports_every_declared_symbol():
+    from orcai_amd import _native as N
+
+    header = (ROOT / "include" / "orcai_hip.h").read_text()
+    declared = set(re.findall(r"\b(orcai_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = N.lib()  # loads liborcai_hip.so (built by __graft_entry__.build / orcai_amd.build)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"liborcai_hip.so does not export {name}"
+    assert declared == set(N.exported_symbols()), declared ^ set(N.exported_symbols())
+    assert b"gfx950" in lib.orcai_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from orcai_amd import _native as N
+
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(N.NativeLibraryError):
+        N.lib()
+
+
+def test_label_extraction_matches_reference_golden(golden_dir, tmp_path):
+    from orcai_amd import predict as P
+
+    g = np.load(golden_dir / "labels_crafted.npz")
+    j = json.loads((golden_dir / "labels_crafted.json").read_text())
+    s, e, n = P.compute_binary_predictions(g["aggregated"], g["overlap_count"], CALLS, threshold=0.5)
+    assert [int(v) for v in s] == j["row_starts"] and [int(v) for v in e] == j["row_stops"] and n == j["label_names"]
+    for key, case in j["cases"].items():
+        suffix = None if key == "None" else key
+        df = P.compute_labels(s, e, n, 16, suffix)
+        assert [int(v) for v in df["start"]] == case["start"] and [int(v) for v in df["stop"]] == case["stop"]
+        assert list(df["label"]) == case["label"]
+        out = tmp_path / f"o_{key.replace('*', 'star')}.txt"
+        P.save_predictions(df, out, 256 / 48000)
+        assert out.read_text() == case["tsv"]
+    df = P.compute_labels(s, e, n, 16, "*")
+    kept = P.filter_predictions(df.copy(), delta_t=256 / 48000, call_duration_limits=j["filter_limits"], label_suffix="*", verbosity=0)
+    assert [int(v) for v in kept["start"]] == j["filter_kept"]["start"]
+    assert [int(v) for v in kept["stop"]] == j["filter_kept"]["stop"]
+    assert list(kept["label"]) == j["filter_kept"]["label"]
+
+
+def test_labels_empty(golden_dir):
+    from orcai_amd import predict as P
+
+    s, e, n = P.compute_binary_predictions(np.zeros((50, 7)), np.ones(50), CALLS)
+    df = P.compute_labels(s, e, n, 16, "*")
+    j = json.loads((golden_dir / "labels_empty.json").read_text())
+    assert len(df) == j["n"] and list(df.columns) == j["columns"]
+
+
+def test_find_consecutive_ones_golden(golden_dir):
+    from orcai_amd.auxiliary import MASK_VALUE, find_consecutive_ones
+
+    j = json.loads((golden_dir / "consecutive_ones.json").read_text())
+    assert MASK_VALUE == j["mask_value"]
+    for c in j["cases"]:
+        s, e = find_consecutive_ones(np.array(c["input"]))
+        assert list(s) == c["starts"] and list(e) == c["stops"]
+
+
+def test_rank_index_and_crop_match_numpy(golden_dir):
+    from orcai_amd.frontend import crop_indices, fft_frequencies, frames_to_time, nearest_rank_index
+
+    for row in json.loads((golden_dir / "virtual_index.json").read_text()):
+        assert nearest_rank_index(row["n"], row["q"]) == row["index"]
+    f = fft_frequencies(48000, 512)
+    assert crop_indices(f, [0, 16000]) == (0, 171)
+    t = frames_to_time(11251, 48000, 256)
+    assert t[1] - t[0] == 256 / 48000 and len(t) == 11251
+
+
+def test_wav_roundtrip_and_scaling(tmp_path):
+    from orcai_amd.wavio import read_wav, write_wav_pcm16
+
+    x = np.array([[0, 1, -1, 32767, -32768, 12345], [5, 6, 7, 8, 9, 10]], dtype=np.int16)
+    write_wav_pcm16(tmp_path / "a.wav", x, 22050)
+    y, sr = read_wav(tmp_path / "a.wav")
+    assert sr == 22050 and y.shape == (2, 6) and y.dtype == np.float32
+    assert np.array_equal(y, x.astype(np.float32) / np.float32(32768))
+    with pytest.raises(ValueError):
+        (tmp_path / "b.wav").write_bytes(b"not a wav file at all")
+        read_wav(tmp_path / "b.wav")
+
+
+def test_model_structure_without_gpu():
+    from orcai_amd.architectures import ResNetLSTM, build_model, lstm_column_permutation
+    from orcai_amd.io import read_json
+
+    param = read_json(ROOT / "orcai_amd" / "models" / "orcai-V1" / "orcai_parameter.json")
+    m = build_model((736, 171, 1), param)
+    assert isinstance(m, ResNetLSTM)
+    assert m.count_params() == 996039 and m.out_steps == 46 and m.time_reduction == 16
+    assert [s[:2] for s in m.stage_shapes()] == [(736, 171), (368, 86), (184, 43), (92, 22), (46, 11)]
+    perm = lstm_column_permutation(128)
+    assert sorted(perm) == list(range(512))
+    assert perm[0] == 0 and perm[8] == 128 and perm[16] == 256 and perm[24] == 384 and perm[32] == 8
+    with pytest.raises(ValueError):
+        build_model((736, 171, 1), dict(param, architecture="nope"))
+
+
+def test_predict_rejects_bad_suffix_and_existing_output(tmp_path):
+    from orcai_amd import predict as P
+
+    wdir = tmp_path / "m"
+    wdir.mkdir()
+    for n in ("orcai_parameter.json", "model_shape.json"):
+        (wdir / n).write_text((ROOT / "orcai_amd" / "models" / "orcai-V1" / n).read_text())
+    with pytest.raises(ValueError):  # no weights in the directory
+        P.predict(tmp_path / "x.wav", model_dir=wdir, verbosity=0)

@@ -1,0 +1,119 @@
+"""GPU parity of the HIP ResNetLSTM forward (through the C ABI) against the CPU oracle
+(oracle/model_ref.py, torch-CPU restatement of the Keras layers; parity unpinned at the Keras boundary).
+
+Tolerance: float32 throughout on both sides, different accumulation order:
+  |delta| <= 2e-5 * max(1, max|ref|) per intermediate tensor, |delta p| <= 1e-5 on the output probabilities
+  (BASELINE north_star: "within a stated fp32 tolerance"; SURVEY 8d states 1e-4 for the output).
+"""
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import model_ref as M  # noqa: E402
+
+
+def make_model(seed, input_shape=(736, 171, 1), filters=(30, 40, 50, 60), kernel_size=3, lstm_units=128, num_labels=7):
+    from orcai_amd.architectures import ResNetLSTM
+
+    p = M.calibrated_params(seed=seed, input_shape=input_shape, num_labels=num_labels, filters=filters, kernel_size=kernel_size, lstm_units=lstm_units)
+    model = ResNetLSTM(input_shape, num_labels, list(filters), kernel_size, 0.0, lstm_units)
+    model.set_weights_dict(p)
+    return model, p
+
+
+def close(a, b, rel=2e-5):
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= rel * scale, (err, scale)
+    return err
+
+
+def test_param_count_matches_reference_architecture():
+    model, p = make_model(1)
+    assert model.count_params() == 996039
+    assert sum(int(w.size) for w in model.trainable_weights) == 994959
+    assert sum(int(w.size) for w in model.non_trainable_weights) == 1080
+    assert model.output_shape == (None, 46, 7) and model.input_shape == (None, 736, 171, 1)
+
+
+def test_forward_intermediates_orcai_v1():
+    model, p = make_model(3)
+    rng = np.random.default_rng(0)
+    x = rng.random((3, 736, 171, 1), dtype=np.float32)
+    ref, inter = M.forward_ref(p, x, return_intermediates=True)
+    xd = torch.from_numpy(x[..., 0].copy()).cuda()
+    out = torch.empty((3, 46, 7), dtype=torch.float32, device="cuda")
+    keep = {}
+    model.forward_device(xd, 736 * 171, 3, out, keep=keep)
+    got = {k: v.cpu().numpy() for k, v in keep.items()}
+    close(got["prev0"], inter["conv0"])
+    for b in range(1, 5):
+        close(got[f"a{b}"], inter[f"b{b}/a"])
+        close(got[f"b{b}"], inter[f"b{b}/b"])
+        close(got[f"prev{b}"], inter[f"b{b}"])
+    close(got["feat"], inter["features"])
+    close(got["h1"], inter["lstm1"])
+    close(got["h2"], inter["lstm2"])
+    o = out.cpu().numpy()
+    assert np.abs(o - ref).max() <= 1e-5, np.abs(o - ref).max()
+    ref64 = M.forward_ref(p, x, dtype=torch.float64)
+    assert np.abs(o - ref64).max() <= 1e-5
+
+
+def test_predict_api_and_chunking():
+    model, p = make_model(4)
+    rng = np.random.default_rng(1)
+    x = rng.random((5, 736, 171, 1), dtype=np.float32)
+    ref = M.forward_ref(p, x)
+    out = model.predict(x, batch_size=2, verbose=0)
+    assert out.shape == (5, 46, 7) and out.dtype == np.float32
+    assert np.abs(out - ref).max() <= 1e-5
+    with pytest.raises(ValueError):
+        model.predict(x[:, :700])
+
+
+def test_sliding_view_equals_materialised_snippets():
+    """Snippet indexing is bit-exact: reading snippets in place from the [T,171] spectrogram gives the same
+    bits as predicting the materialised copies the reference builds (predict.py:253-261)."""
+    from oracle.postprocess_ref import slice_snippets
+
+    model, p = make_model(5)
+    T = 736 + 368 * 3 + 100
+    spec = np.random.default_rng(2).random((T, 171), dtype=np.float32)
+    a = model.predict_spectrogram(torch.from_numpy(spec).cuda(), chunk=3).cpu().numpy()
+    snippets = slice_snippets(spec, 736)
+    assert snippets.shape[0] == a.shape[0] == 4
+    b = model.predict(snippets, batch_size=4)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize(
+    "cfg",
+    [
+        dict(input_shape=(64, 43, 1), filters=(10, 20, 30, 40), kernel_size=5, lstm_units=64, num_labels=3),
+        dict(input_shape=(96, 37, 1), filters=(20, 30, 40, 50), kernel_size=7, lstm_units=128, num_labels=8),
+        dict(input_shape=(48, 50, 1), filters=(30, 40), kernel_size=3, lstm_units=64, num_labels=7),
+    ],
+)
+def test_forward_other_hyperparameters(cfg):
+    """hpsearch variants (hps defaults: filters sets, kernel 3/5/7, lstm_units 64/128) and odd sizes."""
+    model, p = make_model(7, **cfg)
+    rng = np.random.default_rng(3)
+    x = rng.random((18, *cfg["input_shape"]), dtype=np.float32)  # 18 > one LSTM batch tile of 16
+    ref = M.forward_ref(p, x)
+    out = model.predict(x, batch_size=18)
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 1e-5, np.abs(out - ref).max()
+
+
+def test_overlap_average_bit_exact(golden_dir):
+    from orcai_amd.predict import aggregate_predictions_device
+
+    for T in [736, 1103, 1104, 1471, 1472, 11251]:
+        g = np.load(golden_dir / f"aggregate_T{T}.npz")
+        pred = torch.from_numpy(g["predictions"]).cuda()
+        agg, cnt = aggregate_predictions_device(pred, T, 736, 4)
+        assert np.array_equal(agg, g["aggregated"]) and np.array_equal(cnt, g["overlap_count"])
