@@ -148,6 +148,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     wl = WORKLOADS[args.workload](device, rank)
+    if hasattr(wl, "events"):
+        wl.events = {}
     for _ in range(args.warmup):
         wl.step(False)
     torch.cuda.synchronize()

@@ -1,0 +1,130 @@
+"""bench.py workload "predict": BASELINE configs[2] -- orcai-V1 inference over one synthetic 1 h recording
+(172 800 000 samples @ 48 kHz -> 675 001 frames -> 1 833 snippets), inputs resident in HBM.
+
+One step = front end (STFT/dB/percentile clip/normalise) + ResNetLSTM forward over all 50 %-overlap snippets
++ overlap average + label extraction = everything ``predict_wav`` (predict.py:367-471) does after file decode.
+Weights: orcai-V1 architecture with seeded synthetic weights (the trained orcai-v1.keras is absent from the
+reference mount, .MISSING_LARGE_BLOBS).
+"""
+
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+SPEC_PARAM = {"sampling_rate": 48000, "nfft": 512, "n_overlap": 256, "freq_range": [0, 16000], "quantiles": [0.01, 0.999], "duration": 4}
+CALLS = ["BR", "BUZZ", "HERDING", "PHS", "SS", "TAILSLAP", "WHISTLE"]
+FILTERS = [30, 40, 50, 60]
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+FWD_FLOP_PER_SNIPPET = 0.972e9  # 485.8 M MAC
+
+
+def _sep_cost(cin, cout, h, w):
+    """(algorithmic bytes, flops) per snippet of one fused separable-conv launch: read in, write out; dw + pw MACs."""
+    return 4.0 * h * w * (cin + cout), 2.0 * h * w * (9 * cin + cin * cout)
+
+
+def kernel_costs():
+    """label -> (algorithmic HBM bytes, FLOPs) per snippet, fp32 planar activations, each tensor read/written once."""
+    shapes = [(736, 171, 16), (368, 86, 30), (184, 43, 40), (92, 22, 50), (46, 11, 60)]
+    costs = {"conv0": (4.0 * 736 * 171 * (1 + 16), 2.0 * 736 * 171 * 9 * 16)}
+    for b in range(1, 5):
+        h, w, cin = shapes[b - 1]
+        ho, wo, f = shapes[b]
+        costs[f"b{b}/sep_a"] = _sep_cost(cin, f, h, w)
+        costs[f"b{b}/sep_b"] = _sep_cost(f, f, h, w)
+        # pool + residual: read s (all), read prev at stride 2 (counted as the sampled quarter), write out
+        costs[f"b{b}/pool_res"] = (4.0 * (h * w * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
+    costs["sep_f"] = _sep_cost(60, 36, 46, 11)
+    return costs
+
+
+class PredictWorkload:
+    name = "orcai-V1 predict, 1 h synthetic recording @48 kHz, 1833 snippets"
+    metric = "audio_seconds_per_s"
+    unit = "audio-s/s"
+    dtype = "f32"
+
+    def __init__(self, device, rank):
+        from bench import synth_pcm_device
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.frontend import FrontEnd
+
+        self.device = device
+        self.seconds = float(os.environ.get("ORCAI_BENCH_SECONDS", "3600"))
+        self.n_samples = int(self.seconds * 48000)
+        self.pcm = synth_pcm_device(self.n_samples, 3 + rank, device)
+        self.fe = FrontEnd(device)
+        self.model = ResNetLSTM((736, 171, 1), 7, FILTERS, 3, 0.0, 128, seed=1)
+        self.model.prepare()
+        self.chunk = int(os.environ.get("ORCAI_BENCH_CHUNK", "64"))
+        self.T = 1 + self.n_samples // 256
+        self.n_snippets = (self.T - 736) // 368 + 1
+        self.units_per_step = self.seconds
+        self.last = None
+
+    def step(self, timed: bool):
+        from orcai_amd.predict import aggregate_predictions_device, compute_binary_predictions, compute_labels
+
+        self.model.kernel_events = self.events if timed else None
+        spec = self.fe.make_spectrogram(self.pcm, SPEC_PARAM)
+        pred = self.model.predict_spectrogram(spec, chunk=self.chunk)
+        agg, cnt = aggregate_predictions_device(pred, self.T, 736, 4)
+        s, e, n = compute_binary_predictions(agg, cnt, CALLS, 0.5)
+        self.last = compute_labels(s, e, n, 16, "*")
+        self.model.kernel_events = None
+
+    events: dict = {}
+
+    def roofline(self):
+        totals = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}  # ms over all timed steps
+        n_steps = max(1, len(next(iter(self.events.values()))) // max(1, -(-self.n_snippets // self.chunk)))
+        dominant = max(totals, key=totals.get)
+        costs = kernel_costs()
+        launches = len(self.events[dominant])
+        avg_ms = totals[dominant] / launches
+        snippets_per_launch = self.n_snippets * n_steps / launches
+        out = {"kernel": dominant, "kernel_ms": round(avg_ms, 4), "snippets_per_launch": round(snippets_per_launch, 2)}
+        if dominant in costs:
+            nbytes, flops = costs[dominant]
+            achieved = nbytes * snippets_per_launch / (avg_ms * 1e-3) / 1e9
+            out.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "kernel_tflops": round(flops * snippets_per_launch / (avg_ms * 1e-3) / 1e12, 2)})
+        else:
+            out.update({"bound": "mfma", "achieved": None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None})
+        model_ms = sum(totals.values()) / n_steps
+        out["model_ms_per_step"] = round(model_ms, 3)
+        out["model_tflops"] = round(FWD_FLOP_PER_SNIPPET * self.n_snippets / (model_ms * 1e-3) / 1e12, 2)
+        out["per_kernel_ms_per_step"] = {k: round(v / n_steps, 3) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
+        return out
+
+    def cpu_baseline(self):
+        """Oracle (numpy front end + torch-CPU fp32 model) on a bounded sample: 120 s of audio for the front end,
+        32 snippets for the model; audio-s/s = sample seconds / (front-end time + model time scaled to the same audio)."""
+        from oracle import frontend_ref as F
+        from oracle import model_ref as M
+
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("ORCAI_BENCH_CPU_THREADS", "16")))
+        torch.set_num_threads(cores)
+        rng = np.random.default_rng(7)
+        seconds = 120.0
+        y = (np.round(np.clip(0.125 * rng.standard_normal(int(seconds * 48000)), -1, 1) * 32767) / 32768).astype(np.float32)
+        t0 = time.perf_counter()
+        spec, _, _ = F.make_spectrogram_ref(y, {"spectrogram": SPEC_PARAM})
+        t_fe = time.perf_counter() - t0
+        p = M.random_params(seed=1)
+        n_snip = 32
+        snippets = np.stack([spec[i * 368 : i * 368 + 736] for i in range(n_snip)])[..., None]
+        M.forward_ref(p, snippets[:4])  # warm-up
+        t0 = time.perf_counter()
+        for s in range(0, n_snip, 16):
+            M.forward_ref(p, snippets[s : s + 16])
+        t_model = time.perf_counter() - t0
+        audio_per_snippet = 368 * 256 / 48000.0  # stride between snippets in seconds
+        t_total_per_audio_s = t_fe / seconds + (t_model / n_snip) / audio_per_snippet
+        return {"value": round(1.0 / t_total_per_audio_s, 1), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"oracle (numpy/scipy front end on {seconds:.0f} s: {t_fe:.1f} s; torch-CPU fp32 model on {n_snip} snippets, {cores} threads: {t_model:.1f} s)"}

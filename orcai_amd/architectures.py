@@ -65,6 +65,7 @@ class ResNetLSTM:
         self._init_weights(np.random.default_rng(seed))
         self._dev = None  # folded device copies
         self._ws = {}
+        self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
 
     # ------------------------------------------------------------------ structure
     @property
@@ -266,6 +267,18 @@ class ResNetLSTM:
         self._ws = {B: ws}  # keep only the latest chunk size resident
         return ws
 
+    def _launch(self, label: str, what: str, fn, *args) -> None:
+        """Call one C-ABI launcher; optionally bracket it with HIP events on the launch stream (bench.py)."""
+        ev = self.kernel_events
+        if ev is None:
+            N.check(fn(*args), what)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(fn(*args), what)
+        e1.record()
+        ev.setdefault(label, []).append((e0, e1))
+
     def forward_device(self, src: torch.Tensor, snippet_stride: int, B: int, out: torch.Tensor, keep: dict | None = None) -> None:
         """One chunk: B snippets starting at ``src`` (f32 cuda), snippet b at element offset b*snippet_stride,
         each [H][W] row-major.  Writes probabilities into out[B][steps][labels]."""
@@ -276,36 +289,33 @@ class ResNetLSTM:
         H, W = self.input_hw
         k = self.kernel_size
         shapes = self.stage_shapes()
-        N.check(lib.orcai_conv0_bn_relu(src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]), N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]),
-                                        N.ptr(ws["prev0"]), st), "orcai_conv0_bn_relu")
+        self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]), N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]),
+                                        N.ptr(ws["prev0"]), st)
         c = ENTRY_FILTERS
         for b, f in enumerate(self.filters, start=1):
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
-            N.check(lib.orcai_sepconv_bn(N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
-                                         N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st), "orcai_sepconv_bn")
-            N.check(lib.orcai_sepconv_bn(N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
-                                         N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st), "orcai_sepconv_bn")
-            N.check(lib.orcai_pool_res_add(N.ptr(bb), N.ptr(prev), B, f, c, h, wd, N.ptr(d[f"b{b}/res/w"]), N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st),
-                    "orcai_pool_res_add")
+            self._launch(f"{pa}", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
+                                         N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
+            self._launch(f"{pb}", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
+                                         N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st)
+            self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, N.ptr(d[f"b{b}/res/w"]), N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
             c = f
         h, wd, _ = shapes[-1]
         last = ws[f"prev{len(self.filters)}"]
-        N.check(lib.orcai_sepconv_bn(N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]), N.ptr(d["sep_f/scale"]),
-                                     N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, N.ptr(ws["feat"]), st), "orcai_sepconv_bn")
+        self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]), N.ptr(d["sep_f/scale"]),
+                                     N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, N.ptr(ws["feat"]), st)
         u = self.lstm_units
         M = B * h
         x, fin = ws["feat"], wd * FINAL_FILTERS
         for layer, hout in ((1, ws["h1"]), (2, ws["h2"])):
-            N.check(lib.orcai_gemm_bias_act(N.ptr(x), N.ptr(d[f"lstm{layer}/W"]), N.ptr(d[f"lstm{layer}/b"]), None, None, N.ptr(ws["xz"]), M, 8 * u, fin, 0, st),
-                    "orcai_gemm_bias_act")
-            N.check(lib.orcai_lstm_recurrent(N.ptr(ws["xz"]), N.ptr(d[f"lstm{layer}/U"]), B, h, u, N.ptr(hout), st), "orcai_lstm_recurrent")
+            self._launch(f"lstm{layer}/gemm", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(x), N.ptr(d[f"lstm{layer}/W"]), N.ptr(d[f"lstm{layer}/b"]), None, None, N.ptr(ws["xz"]), M, 8 * u, fin, 0, st)
+            self._launch(f"lstm{layer}/rec", "orcai_lstm_recurrent", lib.orcai_lstm_recurrent, N.ptr(ws["xz"]), N.ptr(d[f"lstm{layer}/U"]), B, h, u, N.ptr(hout), st)
             x, fin = hout, 2 * u
-        N.check(lib.orcai_gemm_bias_act(N.ptr(ws["h2"]), N.ptr(d["dense1/W"]), N.ptr(d["dense1/b"]), N.ptr(d["dense1/scale"]), N.ptr(d["dense1/shift"]),
-                                        N.ptr(ws["d1"]), M, DENSE_UNITS, 2 * u, 1, st), "orcai_gemm_bias_act")
-        N.check(lib.orcai_dense_sigmoid(N.ptr(ws["d1"]), N.ptr(d["dense2/W"]), N.ptr(d["dense2/b"]), M, DENSE_UNITS, self.num_labels, out.data_ptr(), st),
-                "orcai_dense_sigmoid")
+        self._launch("dense1", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(ws["h2"]), N.ptr(d["dense1/W"]), N.ptr(d["dense1/b"]), N.ptr(d["dense1/scale"]), N.ptr(d["dense1/shift"]),
+                                        N.ptr(ws["d1"]), M, DENSE_UNITS, 2 * u, 1, st)
+        self._launch("dense2", "orcai_dense_sigmoid", lib.orcai_dense_sigmoid, N.ptr(ws["d1"]), N.ptr(d["dense2/W"]), N.ptr(d["dense2/b"]), M, DENSE_UNITS, self.num_labels, out.data_ptr(), st)
         if keep is not None:
             for name, t in ws.items():
                 keep[name] = t.clone()
