@@ -82,7 +82,7 @@ class PredictWorkload:
 
     def roofline(self):
         totals = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}  # ms over all timed steps
-        n_steps = max(1, len(next(iter(self.events.values()))) // max(1, -(-self.n_snippets // self.chunk)))
+        n_steps = max(1, len(self.events["dense2"]))  # the head runs once per step
         dominant = max(totals, key=totals.get)
         costs = kernel_costs()
         launches = len(self.events[dominant])

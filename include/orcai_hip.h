@@ -106,27 +106,35 @@ int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int h
  * shift = beta - mean*scale + conv_bias*scale.
  * ------------------------------------------------------------------------------------------ */
 
+/* Padded plane layout used by every convolutional activation tensor: an H x W plane is stored as HP x WP floats,
+ * HP = H + 2*(k/2) (k/2 zero rows above and below), WP = orcai_padded_width(W, k) = roundup4(W + k/2) (zero columns
+ * on the right); image pixel (y, x) is at (y + k/2)*WP + x.  The CALLER zero-fills the buffers once; the kernels
+ * never write the pads, so "same" zero padding costs no bounds checks and every tile halo is one contiguous run. */
+int orcai_padded_width(int W, int ksize);
+
 /* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
- *   in              f32, snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
+ *   in              f32, UNPADDED: snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
  *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is
  *                   materialised (predict.py:253-261 makes one)
  *   w               f32[k*k][16] (Keras kernel (k,k,1,16) flattened); scale/shift f32[16]
- *   out             f32[B][16][H][W] */
+ *   out             f32[B][16][HP][WP] padded planes */
 int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
                         const float* shift, float* out, void* stream);
 
 /* [ReLU] -> SeparableConv2D(Cout, k, same) -> BN -> [ReLU]   (architectures.py:174-189, :198-206)
+ *   in   f32[B][Cin][HP][WP] padded planes
  *   dw   f32[Cin][k*k]   (Keras depthwise kernel (k,k,Cin,1) transposed)
  *   pw   f32[Cin][Cout]  (Keras pointwise kernel (1,1,Cin,Cout))
- *   out_layout 0: f32[B][Cout][H][W];  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
+ *   out_layout 0: f32[B][Cout][HP][WP] padded planes;  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
  *   Reshape((-1, W*C)) of the NHWC tensor (architectures.py:208).  Cout <= 64, k in {3,5,7}. */
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream);
 
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
- *   s f32[B][C][H][W], prev f32[B][Cp][H][W], wr f32[Cp][C], br f32[C] -> out f32[B][C][ceil(H/2)][ceil(W/2)] */
-int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, const float* wr, const float* br, float* out,
-                       void* stream);
+ *   s f32[B][C][HP][WP], prev f32[B][Cp][HP][WP] (padded for kernel size k), wr f32[Cp][C], br f32[C]
+ *   -> out f32[B][C][ceil(H/2) + 2*(k/2)][orcai_padded_width(ceil(W/2), k)] padded planes */
+int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br,
+                       float* out, void* stream);
 
 /* C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]; act 0 = identity, 1 = ReLU; bias/scale/shift may be NULL.
  * Used for the LSTM input projections x*W + b (architectures.py:210-229) and Dense(128, relu) + BN (:231-237). */

@@ -218,7 +218,9 @@ class ResNetLSTM:
         def sep(name, bn):
             dwk = w[name + "/depthwise"]  # (k,k,c,1)
             c = dwk.shape[2]
-            d[name + "/dw"] = self._upload(dwk[:, :, :, 0].transpose(2, 0, 1).reshape(c, k * k))
+            dwt = np.zeros((4 * ((c + 3) // 4), k * k), dtype=np.float32)  # channels past c inside the last quad: zero taps
+            dwt[:c] = dwk[:, :, :, 0].transpose(2, 0, 1).reshape(c, k * k)
+            d[name + "/dw"] = self._upload(dwt)
             d[name + "/pw"] = self._upload(w[name + "/pointwise"][0, 0])
             d[name + "/scale"], d[name + "/shift"] = self._fold_bn(bn, w[name + "/bias"])
 
@@ -244,26 +246,27 @@ class ResNetLSTM:
         self._dev = d
         return d
 
+    def padded_width(self, w: int) -> int:
+        return (w + self.kernel_size // 2 + 3) & ~3
+
     def _buffers(self, B: int) -> dict:
-        """Activation workspace for a chunk of B snippets (allocated once per chunk size)."""
+        """Zero-padded activation planes for a trunk chunk of B snippets (see "Padded plane layout" in
+        csrc/model_fwd.hip).  Allocated ZEROED once per chunk size; the kernels never write the pads."""
         if B in self._ws:
             return self._ws[B]
         shapes = self.stage_shapes()
         dev = torch.device("cuda", torch.cuda.current_device())
-        ws = {}
-        ws["prev0"] = torch.empty((B, ENTRY_FILTERS, shapes[0][0], shapes[0][1]), dtype=torch.float32, device=dev)
+        R = self.kernel_size // 2
+
+        def planes(c, h, w):  # [B][channel quad][HP][WP][4]
+            return torch.zeros((B, (c + 3) // 4, h + 2 * R, self.padded_width(w), 4), dtype=torch.float32, device=dev)
+
+        ws = {"prev0": planes(ENTRY_FILTERS, shapes[0][0], shapes[0][1])}
         for b, f in enumerate(self.filters, start=1):
             h, wd, _ = shapes[b - 1]
-            ws[f"a{b}"] = torch.empty((B, f, h, wd), dtype=torch.float32, device=dev)
-            ws[f"b{b}"] = torch.empty((B, f, h, wd), dtype=torch.float32, device=dev)
-            ws[f"prev{b}"] = torch.empty((B, f, shapes[b][0], shapes[b][1]), dtype=torch.float32, device=dev)
-        h, wd, _ = shapes[-1]
-        u = self.lstm_units
-        ws["feat"] = torch.empty((B, h, wd * FINAL_FILTERS), dtype=torch.float32, device=dev)
-        ws["xz"] = torch.empty((B, h, 2, 4 * u), dtype=torch.float32, device=dev)
-        ws["h1"] = torch.empty((B, h, 2 * u), dtype=torch.float32, device=dev)
-        ws["h2"] = torch.empty((B, h, 2 * u), dtype=torch.float32, device=dev)
-        ws["d1"] = torch.empty((B, h, DENSE_UNITS), dtype=torch.float32, device=dev)
+            ws[f"a{b}"] = planes(f, h, wd)
+            ws[f"b{b}"] = planes(f, h, wd)
+            ws[f"prev{b}"] = planes(f, shapes[b][0], shapes[b][1])
         self._ws = {B: ws}  # keep only the latest chunk size resident
         return ws
 
@@ -279,9 +282,9 @@ class ResNetLSTM:
         e1.record()
         ev.setdefault(label, []).append((e0, e1))
 
-    def forward_device(self, src: torch.Tensor, snippet_stride: int, B: int, out: torch.Tensor, keep: dict | None = None) -> None:
-        """One chunk: B snippets starting at ``src`` (f32 cuda), snippet b at element offset b*snippet_stride,
-        each [H][W] row-major.  Writes probabilities into out[B][steps][labels]."""
+    def trunk_device(self, src: torch.Tensor, snippet_stride: int, B: int, feat: torch.Tensor, keep: dict | None = None) -> None:
+        """Convolutional trunk for one chunk of B snippets: entry conv, the residual separable-conv blocks, final
+        separable conv; writes the LSTM input features feat[B][steps][W_last*36]."""
         lib = N.lib()
         d = self.prepare()
         ws = self._buffers(B)
@@ -289,36 +292,77 @@ class ResNetLSTM:
         H, W = self.input_hw
         k = self.kernel_size
         shapes = self.stage_shapes()
-        self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]), N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]),
-                                        N.ptr(ws["prev0"]), st)
+        self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]),
+                     N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(ws["prev0"]), st)
         c = ENTRY_FILTERS
         for b, f in enumerate(self.filters, start=1):
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
-            self._launch(f"{pa}", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
-                                         N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
-            self._launch(f"{pb}", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
-                                         N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st)
-            self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, N.ptr(d[f"b{b}/res/w"]), N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
+            self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
+                         N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
+            self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
+                         N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st)
+            self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
+                         N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
             c = f
         h, wd, _ = shapes[-1]
         last = ws[f"prev{len(self.filters)}"]
-        self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]), N.ptr(d["sep_f/scale"]),
-                                     N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, N.ptr(ws["feat"]), st)
-        u = self.lstm_units
-        M = B * h
-        x, fin = ws["feat"], wd * FINAL_FILTERS
-        for layer, hout in ((1, ws["h1"]), (2, ws["h2"])):
-            self._launch(f"lstm{layer}/gemm", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(x), N.ptr(d[f"lstm{layer}/W"]), N.ptr(d[f"lstm{layer}/b"]), None, None, N.ptr(ws["xz"]), M, 8 * u, fin, 0, st)
-            self._launch(f"lstm{layer}/rec", "orcai_lstm_recurrent", lib.orcai_lstm_recurrent, N.ptr(ws["xz"]), N.ptr(d[f"lstm{layer}/U"]), B, h, u, N.ptr(hout), st)
-            x, fin = hout, 2 * u
-        self._launch("dense1", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(ws["h2"]), N.ptr(d["dense1/W"]), N.ptr(d["dense1/b"]), N.ptr(d["dense1/scale"]), N.ptr(d["dense1/shift"]),
-                                        N.ptr(ws["d1"]), M, DENSE_UNITS, 2 * u, 1, st)
-        self._launch("dense2", "orcai_dense_sigmoid", lib.orcai_dense_sigmoid, N.ptr(ws["d1"]), N.ptr(d["dense2/W"]), N.ptr(d["dense2/b"]), M, DENSE_UNITS, self.num_labels, out.data_ptr(), st)
-        if keep is not None:
+        self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]),
+                     N.ptr(d["sep_f/scale"]), N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, feat.data_ptr(), st)
+        if keep is not None:  # test hook: planes back to [B][C][H][W]
+            R = k // 2
+            chans = {"prev0": ENTRY_FILTERS}
+            widths = {"prev0": shapes[0][1]}
+            for i, f in enumerate(self.filters, start=1):
+                chans.update({f"a{i}": f, f"b{i}": f, f"prev{i}": f})
+                widths.update({f"a{i}": shapes[i - 1][1], f"b{i}": shapes[i - 1][1], f"prev{i}": shapes[i][1]})
             for name, t in ws.items():
-                keep[name] = t.clone()
+                Bq, CQ, HPp, WPp, _ = t.shape
+                hh = HPp - 2 * R
+                full = t.permute(0, 1, 4, 2, 3).reshape(Bq, CQ * 4, HPp, WPp)
+                keep[name] = full[:, : chans[name], R : R + hh, : widths[name]].clone()
+                pads = full.clone()
+                pads[:, : chans[name], R : R + hh, : widths[name]] = 0
+                keep[name + "/pads"] = pads
+
+    def head_device(self, feat: torch.Tensor, out: torch.Tensor, keep: dict | None = None) -> None:
+        """Both BiLSTM layers, Dense(128)+BN and Dense(labels)+sigmoid for ALL n snippets at once
+        (the recurrence kernel wants >= 128 snippet tiles in flight to fill the chip)."""
+        lib = N.lib()
+        d = self.prepare()
+        st = N.stream_ptr()
+        n, h, fin = int(feat.shape[0]), int(feat.shape[1]), int(feat.shape[2])
+        u = self.lstm_units
+        dev = feat.device
+        xz = torch.empty((n, h, 2, 4 * u), dtype=torch.float32, device=dev)
+        h1 = torch.empty((n, h, 2 * u), dtype=torch.float32, device=dev)
+        h2 = torch.empty((n, h, 2 * u), dtype=torch.float32, device=dev)
+        M = n * h
+        x = feat
+        for layer, hout in ((1, h1), (2, h2)):
+            self._launch(f"lstm{layer}/gemm", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(x), N.ptr(d[f"lstm{layer}/W"]), N.ptr(d[f"lstm{layer}/b"]),
+                         None, None, N.ptr(xz), M, 8 * u, fin, 0, st)
+            self._launch(f"lstm{layer}/rec", "orcai_lstm_recurrent", lib.orcai_lstm_recurrent, N.ptr(xz), N.ptr(d[f"lstm{layer}/U"]), n, h, u, N.ptr(hout), st)
+            x, fin = hout, 2 * u
+        d1 = xz.view(-1)[: M * DENSE_UNITS].view(n, h, DENSE_UNITS)  # xz is free again: reuse it for the Dense-128 output
+        self._launch("dense1", "orcai_gemm_bias_act", lib.orcai_gemm_bias_act, N.ptr(h2), N.ptr(d["dense1/W"]), N.ptr(d["dense1/b"]), N.ptr(d["dense1/scale"]),
+                     N.ptr(d["dense1/shift"]), N.ptr(d1), M, DENSE_UNITS, 2 * u, 1, st)
+        self._launch("dense2", "orcai_dense_sigmoid", lib.orcai_dense_sigmoid, N.ptr(d1), N.ptr(d["dense2/W"]), N.ptr(d["dense2/b"]), M, DENSE_UNITS,
+                     self.num_labels, out.data_ptr(), st)
+        if keep is not None:
+            keep.update({"feat": feat.clone(), "h1": h1.clone(), "h2": h2.clone()})
+
+    def forward_device(self, src: torch.Tensor, snippet_stride: int, n: int, out: torch.Tensor, chunk: int = 64, keep: dict | None = None) -> None:
+        """n snippets starting at ``src`` (f32 cuda), snippet i at element offset i*snippet_stride, each [H][W] row-major
+        (unpadded).  Writes probabilities into out[n][steps][labels].  The trunk runs in chunks of `chunk` snippets
+        (bounds activation memory); the recurrent head runs once over all n."""
+        steps, wd, _ = self.stage_shapes()[-1]
+        feat = torch.empty((n, steps, wd * FINAL_FILTERS), dtype=torch.float32, device=src.device)
+        for s in range(0, n, chunk):
+            B = min(chunk, n - s)
+            self.trunk_device(src[s * snippet_stride :], snippet_stride, B, feat[s:], keep=keep if s == 0 else None)
+        self.head_device(feat, out, keep=keep)
 
     def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 64) -> torch.Tensor:
         """All 50 %-overlapping snippets of a device spectrogram [T][W] -> f32 cuda [n][steps][labels].
@@ -329,9 +373,8 @@ class ResNetLSTM:
         shift = H // 2
         n = (spectrogram.shape[0] - H) // shift + 1
         out = torch.empty((max(n, 0), self.out_steps, self.num_labels), dtype=torch.float32, device=spectrogram.device)
-        for s in range(0, n, chunk):
-            B = min(chunk, n - s)
-            self.forward_device(spectrogram[s * shift :], shift * W, B, out[s:])
+        if n > 0:
+            self.forward_device(spectrogram.view(-1), shift * W, n, out, chunk=chunk)
         return out
 
     def predict(self, snippets, batch_size: int = 64, verbose: int = 0, **unused) -> np.ndarray:
@@ -346,7 +389,7 @@ class ResNetLSTM:
             B = min(batch_size, n - s)
             xd = torch.from_numpy(np.ascontiguousarray(x[s : s + B, :, :, 0])).cuda()
             od = torch.empty((B, self.out_steps, self.num_labels), dtype=torch.float32, device=xd.device)
-            self.forward_device(xd, H * W, B, od)
+            self.forward_device(xd.view(-1), H * W, B, od, chunk=B)
             out[s : s + B] = od.cpu().numpy()
         return out
 

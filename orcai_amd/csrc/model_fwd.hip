@@ -1,6 +1,6 @@
 // model_fwd.hip -- inference forward of orcAI's ResNetLSTM (architectures.py:162-241) for gfx950.
 //
-// Activation layout in HBM: planar fp32 [snippet][channel][time H][freq W]  (W innermost).
+// Activation layout in HBM: planar fp32 [snippet][channel][HP][WP], zero-padded planes (see "Padded plane layout").
 // The pointwise (1x1) convolutions, the LSTM projections/recurrence and the dense layers are f32-input
 // MFMA contractions (v_mfma_f32_16x16x4_f32: exact f32, same rounding as an fmaf chain), with the
 // OUTPUT-CHANNEL index on the MFMA row and the PIXEL (or batch) index on the MFMA column/lane, so a
@@ -25,14 +25,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // =========================================================================================
-// conv0: Conv2D(16, k x k, same) on a single-channel input + folded BN + ReLU   (architectures.py:164-168)
+// Activation layout ("padded channel-quad planes"), fp32:
+//     [snippet][CQ = ceil(C/4)][HP = H + 2R][WP = roundup4(W + R)][4]          R = k/2
+//   - 4 consecutive channels are interleaved per pixel, so one pixel of one quad is a 16-byte vector: a wave
+//     reading/writing 64 consecutive pixels moves 1 KiB contiguous per instruction (dwordx4 per lane), and the
+//     4 channels of a quad are exactly one k-step of v_mfma_f32_16x16x4_f32;
+//   - R zero rows above and below and >= R zero columns on the right of every plane (the right pad doubles as the
+//     left pad of the next row): image pixel (y, x) of a quad sits at flat pixel (y + R)*WP + x.  The pads are
+//     zero-filled once by the host and never written, so "same" padding needs no bounds checks and a k x k
+//     window is k loads at flat offsets (dy - R)*WP; channels past C inside the last quad are kept at zero.
 // =========================================================================================
+
+// conv0: Conv2D(16, k x k, same) on a single-channel input + folded BN + ReLU   (architectures.py:164-168)
 template <int KS>
-__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W,
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
                                                      const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][16][H][W]*/) {
-  constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP = HW + 1;
-  __shared__ float halo[HH][HP];
+                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][4][HP][WP][4]*/) {
+  constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
+  __shared__ float halo[HH][HP_];
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const float* src = in + (int64_t)b * snippet_stride;
   for (int i = threadIdx.x; i < HH * HW; i += 256) {
@@ -56,155 +66,235 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in
     }
   const int y = y0 + py, x = x0 + px;
   if (y < H && x < W) {
-    float* o = out + (int64_t)b * 16 * H * W + (int64_t)y * W + x;
+    const int64_t plane = (int64_t)(H + 2 * R) * WP;  // pixels per quad plane
+    float4* o = reinterpret_cast<float4*>(out) + (int64_t)b * 4 * plane + (int64_t)(y + R) * WP + x;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) o[(int64_t)c * H * W] = fmaxf(fmaf(acc[c], scale[c], shift[c]), 0.0f);
+    for (int q = 0; q < 4; ++q) {
+      float4 v;
+      v.x = fmaxf(fmaf(acc[4 * q + 0], scale[4 * q + 0], shift[4 * q + 0]), 0.0f);
+      v.y = fmaxf(fmaf(acc[4 * q + 1], scale[4 * q + 1], shift[4 * q + 1]), 0.0f);
+      v.z = fmaxf(fmaf(acc[4 * q + 2], scale[4 * q + 2], shift[4 * q + 2]), 0.0f);
+      v.w = fmaxf(fmaf(acc[4 * q + 3], scale[4 * q + 3], shift[4 * q + 3]), 0.0f);
+      o[(int64_t)q * plane] = v;
+    }
   }
 }
 
 // =========================================================================================
 // sepconv: [ReLU] -> depthwise k x k (same) -> pointwise 1x1 + bias -> folded BN -> [ReLU]
 //          (architectures.py:174-189, :198-206)
-// One workgroup = one TH x TW pixel tile of one snippet; input channels are processed in chunks of 16:
-//   halo tile of the chunk -> LDS, depthwise by VALU into dwbuf[16][256], then MFMA
-//   D[cout][pixel] += Wpw^T[cout][cin] * dwbuf[cin][pixel].
+//
+// Register-tile formulation, no LDS, no barriers: one WAVE owns 64 consecutive flat pixels of the padded planes
+// (lane = pixel); the inner 64 - 2R are valid outputs, the outer R on each side only feed the horizontal taps
+// through lane shifts.  Per channel quad (= one MFMA k-step) the wave loads the k rows of its window as dwordx4
+// (1 KiB contiguous per instruction), forms the 4 depthwise outputs d[0..3] (lane = pixel, one VGPR per channel)
+// and turns them into the four B fragments of v_mfma_f32_16x16x4_f32 -- B[k = channel][col = pixel], one
+// 16-pixel column tile per 16-lane row -- by a 4 x 4 transpose of 16-lane rows: two v_permlane32_swap + two
+// v_permlane16_swap.  The pointwise weights are the A operand (row = output channel), so the 4 accumulator
+// registers of a lane are 4 consecutive output channels of one pixel = one dwordx4 store of the output layout.
+// The next quad's rows are loaded before the current quad's arithmetic (register double buffer).
 // =========================================================================================
-constexpr int DW_PITCH = 272;  // 256 pixels + 16: rows k and k+1 land 16 banks apart -> conflict-free B-fragment reads
+__device__ __forceinline__ void swap32(float& a, float& b) {  // a's lanes 32..63 <-> b's lanes 0..31
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {  // a's odd 16-lane rows <-> b's even 16-lane rows
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+// value of lane (l + SH) for SH in [-3, 3] (lanes shifted in from outside the wave are don't-care)
+template <int SH>
+__device__ __forceinline__ float lane_shift(float v) {
+  if constexpr (SH == 0) return v;
+  else if constexpr (SH < 0) return __shfl_up(v, -SH, 64);
+  else return __shfl_down(v, SH, 64);
+}
 
-template <int KS, int TW, int MT>
-__global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][Cin][H][W]*/, int Cin, int H, int W, int relu_in,
-                                                       const float* __restrict__ dw /*[Cin][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][CQin][HP][WP][4]*/, int Cin, int H, int W, int WP, int relu_in,
+                                                       const float* __restrict__ dw /*[CQin*4][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                       int out_layout, float* __restrict__ out) {
-  constexpr int TH = 256 / TW, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP = HW + 1, CH = 16;
-  __shared__ float halo[CH][HH][HP];
-  __shared__ float dwbuf[CH][DW_PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  const int64_t plane = (int64_t)H * W;
-  const float* src = in + (int64_t)b * Cin * plane;
-  const int py = tid / TW, px = tid % TW;
+                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP) {
+  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;  // whole wave; the kernel has no barriers
   const int lk = lane >> 4, lj = lane & 15;
+  const int b = blockIdx.y;
+  const int plane = (H + 2 * R) * WP;  // pixels per quad plane
+  const int CQ = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
+  const int qbase = R * WP + task * VAL - R;  // flat padded-plane pixel of lane 0
+  const int q = qbase + lane;
+
+  int ridx[KS];  // row-window load indices (clamped: only lanes whose outputs are discarded can leave the plane)
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy) {
+    const int i = q + (dy - R) * WP;
+    ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+  }
 
   f32x4 acc[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < Cin; c0 += CH) {
-    // ---- stage the chunk's halo tile (zero outside the image and past the last channel)
-    for (int i = tid; i < CH * HH * HW; i += 256) {
-      const int c = i / (HH * HW), rem = i % (HH * HW), r = rem / HW, q = rem % HW;
-      const int y = y0 + r - R, x = x0 + q - R, ch = c0 + c;
-      float v = 0.0f;
-      if (ch < Cin && y >= 0 && y < H && x >= 0 && x < W) {
-        v = src[(int64_t)ch * plane + (int64_t)y * W + x];
-        if (relu_in) v = fmaxf(v, 0.0f);
-      }
-      halo[c][r][q] = v;
+  float4 nxt[KS];
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
+
+  for (int cq = 0; cq < CQ; ++cq) {
+    float4 cur[KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) cur[dy] = nxt[dy];
+    if (cq + 1 < CQ) {
+      const float4* pn = src + (int64_t)(cq + 1) * plane;
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) nxt[dy] = pn[ridx[dy]];
     }
-    // A fragments of this chunk (pointwise weights, transposed): A[i = cout][k = cin]
-    float afrag[MT][4];
+    float afrag[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int ci = c0 + kk * 4 + lk, co = m * 16 + lj;
-        afrag[m][kk] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
-      }
-    __syncthreads();
-    // ---- depthwise: thread = pixel, loop over the chunk's channels (weights are wave-uniform)
-#pragma unroll 4
-    for (int c = 0; c < CH; ++c) {
-      const int ch = c0 + c;
-      float s = 0.0f;
-      if (ch < Cin) {
-        const float* wd = dw + ch * (KS * KS);
-#pragma unroll
-        for (int dy = 0; dy < KS; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < KS; ++dx) s = fmaf(halo[c][py + dy][px + dx], wd[dy * KS + dx], s);
-      }
-      dwbuf[c][tid] = s;
+    for (int m = 0; m < MT; ++m) {
+      const int ci = cq * 4 + lk, co = m * 16 + lj;
+      const bool ok = ci < Cin && co < Cout;
+      const float av = pw[ok ? ci * Cout + co : 0];
+      afrag[m] = ok ? av : 0.0f;
     }
-    __syncthreads();
-    // ---- pointwise: wave owns pixels [64*wave, 64*wave+64) = 4 column tiles
+    const float* wgt = dw + cq * 4 * KK;  // wave-uniform -> scalar loads; [4][KK]
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float bfrag[4];
+    for (int dy = 0; dy < KS; ++dy) {
+      float a[4] = {cur[dy].x, cur[dy].y, cur[dy].z, cur[dy].w};
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bfrag[n] = dwbuf[kk * 4 + lk][wave * 64 + n * 16 + lj];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = mfma16(afrag[m][kk], bfrag[n], acc[m][n]);
-    }
-  }
-  // ---- epilogue: D[row = 4*(lane>>4)+r -> cout][col = lane&15 -> pixel]
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int p = wave * 64 + n * 16 + lj;
-    const int y = y0 + p / TW, x = x0 + p % TW;
-    if (y >= H || x >= W) continue;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = m * 16 + lk * 4 + r;
-        if (co < Cout) {
-          float v = fmaf(acc[m][n][r], scale[co], shift[co]);
-          if (relu_out) v = fmaxf(v, 0.0f);
-          if (out_layout == 0)
-            out[((int64_t)b * Cout + co) * plane + (int64_t)y * W + x] = v;
-          else  // Keras Reshape((-1, W*C)) of NHWC: feature = x*Cout + co   (architectures.py:208)
-            out[((int64_t)b * H + y) * ((int64_t)W * Cout) + (int64_t)x * Cout + co] = v;
+      for (int j = 0; j < 4; ++j) {
+        if (relu_in) a[j] = fmaxf(a[j], 0.0f);
+        const float* wj = wgt + j * KK + dy * KS;
+        if constexpr (KS == 3) {
+          d[j] = fmaf(lane_shift<-1>(a[j]), wj[0], d[j]);
+          d[j] = fmaf(a[j], wj[1], d[j]);
+          d[j] = fmaf(lane_shift<1>(a[j]), wj[2], d[j]);
+        } else if constexpr (KS == 5) {
+          d[j] = fmaf(lane_shift<-2>(a[j]), wj[0], d[j]);
+          d[j] = fmaf(lane_shift<-1>(a[j]), wj[1], d[j]);
+          d[j] = fmaf(a[j], wj[2], d[j]);
+          d[j] = fmaf(lane_shift<1>(a[j]), wj[3], d[j]);
+          d[j] = fmaf(lane_shift<2>(a[j]), wj[4], d[j]);
+        } else {
+          d[j] = fmaf(lane_shift<-3>(a[j]), wj[0], d[j]);
+          d[j] = fmaf(lane_shift<-2>(a[j]), wj[1], d[j]);
+          d[j] = fmaf(lane_shift<-1>(a[j]), wj[2], d[j]);
+          d[j] = fmaf(a[j], wj[3], d[j]);
+          d[j] = fmaf(lane_shift<1>(a[j]), wj[4], d[j]);
+          d[j] = fmaf(lane_shift<2>(a[j]), wj[5], d[j]);
+          d[j] = fmaf(lane_shift<3>(a[j]), wj[6], d[j]);
         }
       }
+    }
+    // d[j] = depthwise output of channel 4cq+j, lane = pixel.  4x4 transpose of 16-lane rows:
+    // afterwards d[t] row g = (channel 4cq+g, pixels 16t..16t+15) = B fragment of column tile t.
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+  }
+
+  // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> pixel 16t + lj of the window]
+  float sc_r[MT][4], sh_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      sc_r[m][r] = co < Cout ? scale[co] : 0.0f;
+      sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
+    }
+  float4* outq = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int wl = 16 * t + lj;  // lane index of this pixel inside the window
+    const int flat = qbase + wl;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WP);  // padded row
+    const int x = flat - row * WP;
+    const bool live = wl >= R && wl < 64 - R && x < W && row < R + H;  // row >= R always
+    if (!live) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]);  // channels past Cout: 0*0+0
+        if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+      }
+      const int oq = m * 4 + lk;  // output quad
+      if (oq >= CQo) continue;
+      if (out_layout == 0) {
+        outq[(int64_t)oq * plane + flat] = make_float4(v[0], v[1], v[2], v[3]);
+      } else {  // Keras Reshape((-1, W*C)) of NHWC: feature = x*Cout + co   (architectures.py:208)
+        float* o = out + ((int64_t)b * H + (row - R)) * ((int64_t)W * Cout) + (int64_t)x * Cout + oq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oq * 4 + r < Cout) o[r] = v[r];
+      }
+    }
   }
 }
 
 // =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
-// thread = output pixel; grid.y = chunk of 16 output channels; grid.z = snippet
+// thread = (output pixel, output channel quad); channel-quad planes in and out.
 // =========================================================================================
-__global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s /*[B][C][H][W]*/, const float* __restrict__ prev /*[B][Cp][H][W]*/,
-                                                            int C, int Cp, int H, int W, int Ho, int Wo, int pad_top, int pad_left,
-                                                            const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
-                                                            float* __restrict__ out /*[B][C][Ho][Wo]*/) {
-  const int b = blockIdx.z, co0 = blockIdx.y * 16;
+__global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s /*[B][CQ][HP][WP][4]*/, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
+                                                            int C, int Cp, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top,
+                                                            int pad_left, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
+                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/) {
+  const int b = blockIdx.z, oq = blockIdx.y;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Ho * Wo) return;
   const int i = idx / Wo, j = idx % Wo;
-  const int64_t plane = (int64_t)H * W;
+  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  const int64_t plane_o = (int64_t)(Ho + 2 * R) * WPo;
   // residual 1x1 stride-2 conv: no padding, samples (2i, 2j)
-  float acc[16];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + (int64_t)(2 * i + R) * WP + 2 * j;
+  for (int cq = 0; cq < CQp; ++cq) {
+    const float4 v = pp[(int64_t)cq * plane];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
-  const float* pp = prev + (int64_t)b * Cp * plane + (int64_t)(2 * i) * W + 2 * j;
-  for (int ci = 0; ci < Cp; ++ci) {
-    const float v = pp[(int64_t)ci * plane];
-    const float* wrow = wr + ci * C + co0;
+    for (int k = 0; k < 4; ++k) {
+      const int ci = cq * 4 + k;
+      if (ci < Cp) {
+        const float* wrow = wr + ci * C + oq * 4;  // uniform
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (co0 + c < C) acc[c] = fmaf(v, wrow[c], acc[c]);
+        for (int c = 0; c < 4; ++c)
+          if (oq * 4 + c < C) acc[c] = fmaf(vv[k], wrow[c], acc[c]);
+      }
+    }
   }
   const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;
+  const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * plane;
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    const int co = co0 + c;
-    if (co >= C) break;
-    const float* sp = s + ((int64_t)b * C + co) * plane;
-    float m = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int y = ys + dy, x = xs + dx;
-        if (y >= 0 && y < H && x >= 0 && x < W) m = fmaxf(m, sp[(int64_t)y * W + x]);
+    for (int dx = 0; dx < 2; ++dx) {
+      const int y = ys + dy, x = xs + dx;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float4 v = sp[(int64_t)(y + R) * WP + x];
+        m[0] = fmaxf(m[0], v.x); m[1] = fmaxf(m[1], v.y); m[2] = fmaxf(m[2], v.z); m[3] = fmaxf(m[3], v.w);
       }
-    out[((int64_t)b * C + co) * ((int64_t)Ho * Wo) + idx] = m + (acc[c] + br[co]);
-  }
+    }
+  float o[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = (oq * 4 + c < C) ? m[c] + (acc[c] + br[oq * 4 + c]) : 0.0f;
+  reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + (int64_t)(i + R) * WPo + j] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // =========================================================================================
@@ -405,44 +495,48 @@ __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __res
   if (l == 0) cnt[s] = (double)c;
 }
 
-template <int KS, int TW>
-int launch_sepconv_mt(int MT, dim3 grid, hipStream_t st, const float* in, int Cin, int H, int W, int relu_in, const float* dw, const float* pw,
-                      const float* scale, const float* shift, int Cout, int relu_out, int out_layout, float* out) {
-  switch (MT) {
-    case 1: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 1>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
-    case 2: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 2>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
-    case 3: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 3>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
-    case 4: hipLaunchKernelGGL((sepconv_kernel<KS, TW, 4>), grid, dim3(256), 0, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out); break;
-    default: return ORCAI_E_UNSUPPORTED;
-  }
+inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }  // __umulhi(n, magic) == n / d while n*d < 2^32
+
+template <int KS, int MT>
+int launch_sepconv_impl(int B, hipStream_t st, const float* in, int Cin, int H, int W, int WP, const float* dw, const float* pw, const float* scale,
+                        const float* shift, int Cout, int relu_in, int relu_out, int out_layout, float* out) {
+  constexpr int VAL = 64 - 2 * (KS / 2);
+  const int tasks = (H * WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
+  if ((int64_t)(H + KS) * WP >= (1ll << 31) / 4) return ORCAI_E_UNSUPPORTED;
+  dim3 grid((tasks + 3) / 4, B);
+  hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, in, Cin, H, W, WP, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out,
+                     tasks, magic_for(WP));
   return (int)hipGetLastError();
 }
 
 template <int KS>
-int launch_sepconv(int B, hipStream_t st, const float* in, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale,
-                   const float* shift, int Cout, int relu_out, int out_layout, float* out) {
-  const int MT = (Cout + 15) / 16;
-  if (W > 48) {
-    dim3 grid((W + 31) / 32, (H + 7) / 8, B);
-    return launch_sepconv_mt<KS, 32>(MT, grid, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+int launch_sepconv(int B, hipStream_t st, const float* in, int Cin, int H, int W, int WP, const float* dw, const float* pw, const float* scale,
+                   const float* shift, int Cout, int relu_in, int relu_out, int out_layout, float* out) {
+  switch ((Cout + 15) / 16) {
+    case 1: return launch_sepconv_impl<KS, 1>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    case 2: return launch_sepconv_impl<KS, 2>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    case 3: return launch_sepconv_impl<KS, 3>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    case 4: return launch_sepconv_impl<KS, 4>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    default: return ORCAI_E_UNSUPPORTED;
   }
-  dim3 grid((W + 15) / 16, (H + 15) / 16, B);
-  return launch_sepconv_mt<KS, 16>(MT, grid, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
 }
 
 }  // namespace
 
 extern "C" {
 
+int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
+
 int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
                         const float* shift, float* out, void* stream) {
   if (!in || !w || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   dim3 grid((W + 31) / 32, (H + 7) / 8, B);
   hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, ksize);
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
-    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
-    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, w, scale, shift, out); break;
+    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
+    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
+    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();
@@ -451,25 +545,27 @@ int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, i
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream) {
   if (!in || !dw || !pw || !scale || !shift || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
-  if (Cout > 64) return ORCAI_E_UNSUPPORTED;
+  if (Cout > 64 || ((uintptr_t)in & 15)) return ORCAI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, ksize);
   switch (ksize) {
-    case 3: return launch_sepconv<3>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
-    case 5: return launch_sepconv<5>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
-    case 7: return launch_sepconv<7>(B, st, in, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out);
+    case 3: return launch_sepconv<3>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    case 5: return launch_sepconv<5>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+    case 7: return launch_sepconv<7>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
     default: return ORCAI_E_UNSUPPORTED;
   }
 }
 
-int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, const float* wr, const float* br, float* out,
+int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
                        void* stream) {
   if (!s || !prev || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
-  dim3 grid((Ho * Wo + 255) / 256, (C + 15) / 16, B);
-  hipLaunchKernelGGL(pool_res_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, s, prev, C, Cp, H, W, Ho, Wo, tot_h / 2, tot_w / 2, wr, br, out);
+  dim3 grid((Ho * Wo + 255) / 256, (C + 3) / 4, B);
+  hipLaunchKernelGGL(pool_res_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, s, prev, C, Cp, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, wr, br, out);
   return (int)hipGetLastError();
 }
 

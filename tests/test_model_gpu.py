@@ -47,7 +47,7 @@ def test_forward_intermediates_orcai_v1():
     xd = torch.from_numpy(x[..., 0].copy()).cuda()
     out = torch.empty((3, 46, 7), dtype=torch.float32, device="cuda")
     keep = {}
-    model.forward_device(xd, 736 * 171, 3, out, keep=keep)
+    model.forward_device(xd.view(-1), 736 * 171, 3, out, keep=keep)
     got = {k: v.cpu().numpy() for k, v in keep.items()}
     close(got["prev0"], inter["conv0"])
     for b in range(1, 5):
@@ -57,6 +57,8 @@ def test_forward_intermediates_orcai_v1():
     close(got["feat"], inter["features"])
     close(got["h1"], inter["lstm1"])
     close(got["h2"], inter["lstm2"])
+    for name in ("prev0", "a1", "b1", "prev1", "a2", "b4", "prev4"):  # pad rows/columns/channels of the layout stay zero
+        assert not got[name + "/pads"].any(), name
     o = out.cpu().numpy()
     assert np.abs(o - ref).max() <= 1e-5, np.abs(o - ref).max()
     ref64 = M.forward_ref(p, x, dtype=torch.float64)

@@ -5,7 +5,7 @@ from bench import synth_pcm_device, SPEC_PARAM
 from orcai_amd.frontend import FrontEnd
 from orcai_amd.architectures import ResNetLSTM
 from orcai_amd.predict import aggregate_predictions_device
-log = open("gpurun_out/debug_predict.log", "a")
+log = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "debug_predict.log"), "a")
 def P(*a):
     print(*a, file=log, flush=True); print(*a, flush=True)
 dev = torch.device("cuda", 0)
