@@ -136,9 +136,10 @@ constexpr int FRAME_BYTES = 16 * ROW_BYTES;  // 2304
 constexpr int WAVE_BYTES = 4 * FRAME_BYTES;  // 9216, also holds the 4 x k_crop output staging (<= 4112 B)
 
 struct __attribute__((aligned(16))) StftLds {
-  unsigned char tile[4][WAVE_BYTES];
+  unsigned char tile[4][WAVE_BYTES];  // per wave: PCM staging (5 hops) -> 16x16 transpose tile -> output staging
   float2 tw256[256];
   float2 tw512[260];
+  float2 win2[256];                   // (w[2n], w[2n+1])
   uint32_t hist[NB1_PAD];
 };
 
@@ -148,7 +149,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 template <bool EVEN_HOP>
-__global__ __launch_bounds__(256) void stft_db_kernel(const float* __restrict__ pcm, int64_t n_samples, int hop, int64_t n_frames,
+__global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict__ pcm, int64_t n_samples, int hop, int64_t n_frames,
                                                        int k_crop, float* __restrict__ out, Workspace* __restrict__ ws) {
   __shared__ StftLds lds;
   const int tid = threadIdx.x;
@@ -161,14 +162,7 @@ __global__ __launch_bounds__(256) void stft_db_kernel(const float* __restrict__ 
   for (int i = tid; i < 257; i += 256) lds.tw512[i] = g_tw512[i];
   for (int i = tid; i < NB1_PAD; i += 256) lds.hist[i] = 0u;
 
-  // window: lane needs w[2n], w[2n+1] for n = n1 + 16 j
-  float wre[16], wim[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    float2 w = *reinterpret_cast<const float2*>(&g_window[2 * (l16 + 16 * j)]);
-    wre[j] = w.x;
-    wim[j] = w.y;
-  }
+  for (int i = tid; i < 256; i += 256) lds.win2[i] = *reinterpret_cast<const float2*>(&g_window[2 * i]);
   __syncthreads();
 
   unsigned char* my_tile = lds.tile[wave];
@@ -183,30 +177,34 @@ __global__ __launch_bounds__(256) void stft_db_kernel(const float* __restrict__ 
     const int64_t s0 = t * (int64_t)hop - (NFFT / 2);
 
     float re[16], im[16];
-    const bool interior = (t0w * (int64_t)hop - (NFFT / 2) >= 0) && ((t0w + 3) * (int64_t)hop + (NFFT / 2) <= n_samples) &&
-                          (t0w + 3 < n_frames);
-    if (interior) {
+    // The wave's 4 frames cover padded samples [hop*t0w, hop*(t0w+3) + 512): for the default hop 256 that is one
+    // contiguous run of 1280 floats, fetched as 5 dwordx4 per lane (1 KiB per instruction) into the wave's tile.
+    const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);  // first sample the wave needs
+    const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
+    if (fast) {
+      float* st = reinterpret_cast<float*>(my_tile);
+      const float4* gp = reinterpret_cast<const float4*>(pcm + w0);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) reinterpret_cast<float4*>(st)[lane + 64 * u] = gp[lane + 64 * u];
+      wave_lds_fence();
+      const float* fr = st + fsub * 256;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int64_t s = s0 + 2 * (l16 + 16 * j);
-        float x0, x1;
-        if (EVEN_HOP) {
-          float2 v = *reinterpret_cast<const float2*>(pcm + s);
-          x0 = v.x; x1 = v.y;
-        } else {
-          x0 = pcm[s]; x1 = pcm[s + 1];
-        }
-        re[j] = x0 * wre[j];
-        im[j] = x1 * wim[j];
+        const float2 v = *reinterpret_cast<const float2*>(fr + 2 * (l16 + 16 * j));
+        const float2 w = lds.win2[l16 + 16 * j];
+        re[j] = v.x * w.x;
+        im[j] = v.y * w.y;
       }
+      wave_lds_fence();  // staging reads done before the tile is reused for the transpose
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int64_t s = s0 + 2 * (l16 + 16 * j);
-        float x0 = (valid && s >= 0 && s < n_samples) ? pcm[s] : 0.0f;
-        float x1 = (valid && s + 1 >= 0 && s + 1 < n_samples) ? pcm[s + 1] : 0.0f;
-        re[j] = x0 * wre[j];
-        im[j] = x1 * wim[j];
+        const int64_t sidx = s0 + 2 * (l16 + 16 * j);
+        const float x0 = (valid && sidx >= 0 && sidx < n_samples) ? pcm[sidx] : 0.0f;
+        const float x1 = (valid && sidx + 1 >= 0 && sidx + 1 < n_samples) ? pcm[sidx + 1] : 0.0f;
+        const float2 w = lds.win2[l16 + 16 * j];
+        re[j] = x0 * w.x;
+        im[j] = x1 * w.y;
       }
     }
 
@@ -573,7 +571,7 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
   if (!pcm || !out_db || !workspace || n_samples <= 0 || hop <= 0 || k_crop < 1 || k_crop > 257) return ORCAI_E_BADARG;
   if (n_fft != NFFT) return ORCAI_E_UNSUPPORTED;
   if (n_frames != 1 + n_samples / hop) return ORCAI_E_BADARG;
-  if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 7)) return ORCAI_E_BADARG;
+  if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 15)) return ORCAI_E_BADARG;
   std::call_once(g_tables_once, init_tables);
   if (g_tables_err) return g_tables_err;
   const int64_t n_groups = (n_frames + 15) / 16;

@@ -140,7 +140,7 @@ def compute_binary_predictions(aggregated_predictions: np.ndarray, overlap_count
     binary_prediction = (aggregated_predictions > adjusted_threshold).astype(int)
     row_starts, row_stops, label_names = [], [], []
     for i, label_name in enumerate(calls):
-        if sum(binary_prediction[:, i]) > 0:
+        if binary_prediction[:, i].sum() > 0:  # == the reference's builtin sum(), vectorised
             row_start, row_stop = find_consecutive_ones(binary_prediction[:, i])
             row_starts += list(row_start)
             row_stops += list(row_stop)
