@@ -46,6 +46,11 @@ size_t orcai_frontend_workspace_bytes(void);
  * recording's orcai_stft_db / orcai_hist_level1. */
 int orcai_frontend_reset(void* workspace, void* stream);
 
+/* Rational polyphase resampler (the resampling half of librosa.load(sr=...), spectrogram.py:23-27; libsoxr itself
+ * is absent, so this stage cannot be bit-compared: parity unpinned).
+ *   out[n] = sum_j x[floor(n*M/L) - ntaps/2 + 1 + j] * table[(n*M) mod L][j]; table f32[L][ntaps], ntaps % 4 == 0. */
+int orcai_resample_polyphase(const float* x, int64_t n_in, float* out, int64_t n_out, int L, int M, const float* table, int ntaps, void* stream);
+
 /* librosa.stft(n_fft=512, hop_length=hop, window="hann", center=True, pad_mode="constant")
  * followed by the first half of amplitude_to_db (spectrogram.py:34-39, :51-53):
  *   out_db[t*k_crop + k] = 10*log10(max(|X[k,t]|^2, 1e-10))          k in [0, k_crop)

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "orcai_lstm_recurrent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dense_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_overlap_average": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_resample_polyphase": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

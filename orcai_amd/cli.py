@@ -1,0 +1,108 @@
+"""``orcai`` command line for the hot path.  Same subcommand names, arguments and option flags as the
+reference's ``src/orcAI/cli.py`` for the four in-scope commands (predict :93-184, create-spectrograms
+:359-416, train :630-677, hpsearch :732-788); the data-preparation subcommands are out of scope.
+Workflow modules are imported lazily, like the reference does.
+"""
+
+from __future__ import annotations
+
+from importlib.resources import files
+from pathlib import Path
+
+import click
+
+from orcai_amd.auxiliary import Messenger
+
+INCLUDED_MODELS = ["orcai-V1"]
+FileR = click.Path(exists=True, dir_okay=False, readable=True, resolve_path=True, path_type=Path)
+DirR = click.Path(exists=True, file_okay=False, readable=True, resolve_path=True, path_type=Path)
+DirW = click.Path(exists=True, file_okay=False, writable=True, resolve_path=True, path_type=Path)
+DirWcreate = click.Path(exists=False, file_okay=False, writable=True, resolve_path=True, path_type=Path)
+DEFAULT_PARAM = files("orcai_amd.defaults").joinpath("default_orcai_parameter.json")
+DEFAULT_HPS = files("orcai_amd.defaults").joinpath("default_hps_parameter.json")
+EPILOG = "MI355X-native implementation of the orcAI hot path (https://github.com/ethz-tb/orcAI)"
+
+
+@click.group(help="orcAI on MI355X: detect acoustic signals in spectrograms generated from audio recordings.", epilog=EPILOG)
+@click.version_option(package_name=None, version=__import__("orcai_amd").__version__)
+def cli():
+    pass
+
+
+@cli.command(name="predict", short_help="Predicts call annotations.", no_args_is_help=True, epilog=EPILOG,
+             help="Predicts call annotations from RECORDING_PATH: a wav file or a recording table (.csv).")
+@click.argument("recording_path", type=FileR)
+@click.option("--channel", "-c", type=int, default=1, show_default=True, help="Channel to use for prediction if running predictions for a single file.")
+@click.option("--model", "-m", type=click.Choice(INCLUDED_MODELS, case_sensitive=False), default="orcai-V1", show_default=True,
+              help="Builtin model to use for prediction. Overridden if model_dir is given.")
+@click.option("--model_dir", "-md", "model_dir", type=DirR, default=None, show_default="use builtin model", help="Path to a model directory.")
+@click.option("--output_path", "-o", default="default", show_default="default",
+              help="Path to the output file/folder or 'default' to save next to the wav file. None to not save predictions to disk.")
+@click.option("--overwrite", "-ow", is_flag=True, help="Overwrite existing predictions.")
+@click.option("--save_probabilities", "-sp", is_flag=True, help="Also save the prediction probabilities.")
+@click.option("--base_dir_recording", "-bdr", type=DirW, default=None, show_default="None", help="Alternative base directory containing the recordings.")
+@click.option("--call_duration_limits", "-cdl", type=FileR, default=None, show_default="None", help="JSON file with call duration limits; None for no filtering.")
+@click.option("--label_suffix", "-ls", default="*", show_default=True, help="Suffix to add to the label names.")
+@click.option("--verbosity", "-v", type=click.IntRange(0, 3), default=2, show_default=True, help="0: Errors only, 1: Warnings, 2: Info, 3: Debug")
+def cli_predict(**kwargs):
+    kwargs["msgr"] = Messenger(verbosity=kwargs["verbosity"], title="Predicting calls")
+    from orcai_amd.predict import predict
+
+    if kwargs["model_dir"] is None:
+        kwargs["model_dir"] = files("orcai_amd.models").joinpath(kwargs["model"])
+    del kwargs["model"]
+    if kwargs["output_path"] == "None":
+        kwargs["output_path"] = None
+    predict(**kwargs)
+
+
+@cli.command(name="create-spectrograms", short_help="Creates spectrograms for all files in a recording table.", no_args_is_help=True, epilog=EPILOG,
+             help="Creates spectrograms for all files in the recording table at RECORDING_TABLE_PATH and saves them to OUTPUT_DIR.")
+@click.argument("recording_table_path", type=FileR)
+@click.argument("output_dir", type=DirWcreate)
+@click.option("--base_dir_recording", "-bdr", type=DirR, default=None, show_default="None", help="Base directory for the wav files.")
+@click.option("--orcai_parameter", "-p", type=FileR, default=DEFAULT_PARAM, show_default="default_orcai_parameter.json", help="Path to the orcAI parameter file.")
+@click.option("--include_not_annotated", "-en", is_flag=True, help="Include recordings without annotations.")
+@click.option("--include_no_possible_annotations", "-enp", is_flag=True, help="Include recordings without possible annotations.")
+@click.option("--overwrite", "-ow", is_flag=True, help="Recreate existing spectrograms.")
+@click.option("--verbosity", "-v", type=click.IntRange(0, 3), default=2, show_default=True, help="0: Errors only, 1: Warnings, 2: Info, 3: Debug")
+def cli_create_spectrograms(**kwargs):
+    kwargs["msgr"] = Messenger(verbosity=kwargs["verbosity"], title="Creating spectrograms")
+    from orcai_amd.spectrogram import create_spectrograms
+
+    create_spectrograms(**kwargs)
+
+
+@cli.command(name="train", short_help="Trains a model on the training dataset.", no_args_is_help=True, epilog=EPILOG,
+             help="Trains a model on the dataset in DATA_DIR and saves it to OUTPUT_DIR.")
+@click.argument("data_dir", type=DirR)
+@click.argument("output_dir", type=DirW)
+@click.option("--orcai_parameter", "-p", type=FileR, default=DEFAULT_PARAM, show_default="default_orcai_parameter.json", help="Path to the orcAI parameter file.")
+@click.option("--data_compression", "-dc", type=click.Choice(["GZIP", "NONE"], case_sensitive=False), default="GZIP", show_default=True, help="Compression of the data files.")
+@click.option("--load_model", "-lm", is_flag=True, help="Load model from previous training.")
+@click.option("--verbosity", "-v", type=click.IntRange(0, 3), default=2, show_default=True, help="0: Errors only, 1: Warnings, 2: Info, 3: Debug")
+def cli_train(**kwargs):
+    kwargs["msgr"] = Messenger(verbosity=kwargs["verbosity"], title="Training model")
+    from orcai_amd.train import train
+
+    train(**kwargs)
+
+
+@cli.command(name="hpsearch", short_help="Performs hyperparameter search.", no_args_is_help=True, epilog=EPILOG,
+             help="Performs hyperparameter search on the dataset in DATA_DIR and saves the results to OUTPUT_DIR.")
+@click.argument("data_dir", type=DirR)
+@click.argument("output_dir", type=DirW)
+@click.option("--orcai_parameter", "-p", type=FileR, default=DEFAULT_PARAM, show_default="default_orcai_parameter.json", help="Path to the orcAI parameter file.")
+@click.option("--hps_parameter", "-hp", type=FileR, default=DEFAULT_HPS, show_default="default_hps_parameter.json", help="Path to the hyperparameter search parameter file.")
+@click.option("--parallel", "-pl", is_flag=True, help="Run the search data-parallel on all GPUs of the node.")
+@click.option("--data_compression", "-dc", type=click.Choice(["GZIP", "NONE"], case_sensitive=False), default="GZIP", show_default=True, help="Compression of the data files.")
+@click.option("--verbosity", "-v", type=click.IntRange(0, 3), default=2, show_default=True, help="0: Errors only, 1: Warnings, 2: Info, 3: Debug")
+def cli_hpsearch(**kwargs):
+    kwargs["msgr"] = Messenger(verbosity=kwargs["verbosity"], title="Hyperparameter search")
+    from orcai_amd.hpsearch import hyperparameter_search
+
+    hyperparameter_search(**kwargs)
+
+
+if __name__ == "__main__":
+    cli()

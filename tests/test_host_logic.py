@@ -125,3 +125,30 @@ def test_predict_rejects_bad_suffix_and_existing_output(tmp_path):
         (wdir / n).write_text((ROOT / "orcai_amd" / "models" / "orcai-V1" / n).read_text())
     with pytest.raises(ValueError):  # no weights in the directory
         P.predict(tmp_path / "x.wav", model_dir=wdir, verbosity=0)
+
+
+def test_cli_surface_matches_reference_options():
+    """Option flags of the four in-scope subcommands (reference cli.py:93-184, 359-416, 630-677, 732-788)."""
+    from orcai_amd.cli import cli
+
+    expect = {
+        "predict": {"-c", "-m", "-md", "-o", "-ow", "-sp", "-bdr", "-cdl", "-ls", "-v"},
+        "create-spectrograms": {"-bdr", "-p", "-en", "-enp", "-ow", "-v"},
+        "train": {"-p", "-dc", "-lm", "-v"},
+        "hpsearch": {"-p", "-hp", "-pl", "-dc", "-v"},
+    }
+    assert set(cli.commands) == set(expect)
+    for name, flags in expect.items():
+        have = {o for p in cli.commands[name].params for o in getattr(p, "opts", []) if o.startswith("-") and not o.startswith("--")}
+        assert have == flags, (name, have ^ flags)
+
+
+def test_resample_table_design():
+    from orcai_amd.resample import design_table, output_length, ratio
+
+    assert ratio(22050, 48000) == (320, 147) and ratio(96000, 48000) == (1, 2)
+    assert output_length(1323000, 22050, 48000) == 2880000
+    t = design_table(320, 147)
+    assert t.shape == (320, 128) and t.dtype == np.float32
+    assert abs(float(t[0].astype(np.float64).sum()) - 1.0) < 1e-3  # unity DC gain
+    assert design_table(1, 2).shape[1] == 256  # down-sampling widens the filter

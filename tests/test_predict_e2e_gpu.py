@@ -1,0 +1,145 @@
+"""End-to-end GPU parity of `orcai predict` (config 1 of BASELINE.json: a mono PCM16 wav, 22.05 kHz -> resampled to
+48 kHz, and the 48 kHz parity twin) against the CPU oracle pipeline, plus the resampler on its own.
+
+Tolerances: resampler |delta| <= 2e-6 (f32 taps, f32 accumulate vs f64 oracle accumulate); aggregated probabilities
+|delta| <= 2e-4 end to end (front end 2e-4 on [0,1] inputs propagates through a calibrated network to ~1e-5);
+label intervals identical unless an averaged probability lies within 1e-3 of the 0.25 threshold.
+"""
+
+import gzip
+import io
+import json
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+CALLS = ["BR", "BUZZ", "HERDING", "PHS", "SS", "TAILSLAP", "WHISTLE"]
+
+
+def test_resampler_vs_oracle():
+    from oracle.resample_ref import resample_ref
+    from orcai_amd.resample import output_length, resample_device
+    from orcai_amd.synthetic import pcm16_to_float, synth_recording
+
+    for sr_in, sr_out, secs in [(22050, 48000, 3.0), (44100, 48000, 1.0), (96000, 48000, 1.0), (48000, 48000, 0.5), (8000, 48000, 0.7)]:
+        x = pcm16_to_float(synth_recording(secs, sr_in, seed=4))
+        y = resample_device(torch.from_numpy(x).cuda(), sr_in, sr_out).cpu().numpy()
+        assert len(y) == output_length(len(x), sr_in, sr_out)
+        if sr_in == sr_out:
+            assert np.array_equal(y, x)
+            continue
+        ref = resample_ref(x, sr_in, sr_out)
+        assert np.abs(y - ref).max() <= 2e-6, (sr_in, np.abs(y - ref).max())
+    # band-limited sine: the resampled signal is the same sine at the new rate
+    t = np.arange(22050) / 22050
+    x = (0.5 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    y = resample_device(torch.from_numpy(x).cuda(), 22050, 48000).cpu().numpy()
+    tt = np.arange(len(y)) / 48000
+    m = slice(1000, len(y) - 1000)
+    assert np.abs(y[m] - 0.5 * np.sin(2 * np.pi * 3000 * tt[m])).max() <= 1e-5
+
+
+def _model_dir(tmp_path, seed=21):
+    from oracle import model_ref as M
+
+    p = M.calibrated_params(seed=seed, calib_batch=1)
+    d = tmp_path / "model"
+    d.mkdir()
+    for n in ("orcai_parameter.json", "model_shape.json"):
+        (d / n).write_text((ROOT / "orcai_amd" / "models" / "orcai-V1" / n).read_text())
+    np.savez(d / "orcai-v1.weights.npz", **p)
+    return d, p
+
+
+def _oracle_pipeline(y48, p):
+    from oracle import frontend_ref as F
+    from oracle import model_ref as M
+    from oracle import postprocess_ref as P
+
+    param = json.loads((ROOT / "orcai_amd" / "models" / "orcai-V1" / "orcai_parameter.json").read_text())
+    spec, _, times = F.make_spectrogram_ref(y48, param)
+    pred = M.forward_ref(p, P.slice_snippets(spec, 736))
+    agg, cnt = P.aggregate_predictions_ref(pred, spec.shape[0], 736, 4, 7)
+    s, e, n = P.compute_binary_predictions_ref(agg, cnt, CALLS)
+    labels = P.compute_labels_ref(s, e, n, 16, "*")
+    return agg, cnt, P.labels_to_tsv_ref(labels, times[1] - times[0])
+
+
+@pytest.mark.parametrize("sr", [48000, 22050])
+def test_predict_wav_end_to_end(tmp_path, sr):
+    from oracle.resample_ref import resample_ref
+    from orcai_amd.predict import predict
+    from orcai_amd.synthetic import pcm16_to_float, synth_recording
+    from orcai_amd.wavio import write_wav_pcm16
+
+    model_dir, p = _model_dir(tmp_path)
+    pcm = synth_recording(14.0, sr, seed=9)
+    wav = tmp_path / "rec.wav"
+    write_wav_pcm16(wav, np.stack([pcm, pcm[::-1]]), sr)  # 2 channels: channel 1 is used
+    out = tmp_path / "rec_pred.txt"
+    predict(wav, channel=1, model_dir=model_dir, output_path=out, save_probabilities=True, verbosity=0)
+    y = pcm16_to_float(pcm)
+    y48 = y if sr == 48000 else resample_ref(y, sr, 48000)
+    agg_ref, cnt_ref, tsv_ref = _oracle_pipeline(y48, p)
+    probs = pd.read_csv(io.BytesIO(gzip.decompress((tmp_path / "rec_pred_probabilities.csv.gz").read_bytes())), index_col="time")
+    assert list(probs.columns) == CALLS and probs.shape == agg_ref.shape
+    assert np.abs(probs.to_numpy() - agg_ref).max() <= 2e-4
+    thr = 0.5 / cnt_ref.max()
+    if np.abs(agg_ref - thr).min() > 1e-3:
+        assert out.read_text() == tsv_ref
+    with pytest.raises(FileExistsError):
+        predict(wav, channel=1, model_dir=model_dir, output_path=out, verbosity=0)
+    predict(wav, channel=1, model_dir=model_dir, output_path=out, overwrite=True, verbosity=0)
+
+
+def test_predict_table_mode_and_cli(tmp_path):
+    from click.testing import CliRunner
+
+    from orcai_amd.cli import cli
+    from orcai_amd.synthetic import synth_recording
+    from orcai_amd.wavio import write_wav_pcm16
+
+    model_dir, _ = _model_dir(tmp_path)
+    rec = tmp_path / "recs"
+    rec.mkdir()
+    for name in ("a", "b"):
+        write_wav_pcm16(rec / f"{name}.wav", synth_recording(9.0, 48000, seed=ord(name)), 48000)
+    table = pd.DataFrame({"recording": ["a", "b", "missing"], "base_dir_recording": [str(rec)] * 3, "rel_recording_path": ["a.wav", "b.wav", "nope.wav"], "channel": [1, 1, 1]})
+    table.to_csv(tmp_path / "table.csv", index=False)
+    outdir = tmp_path / "out"
+    outdir.mkdir()
+    res = CliRunner().invoke(cli, ["predict", str(tmp_path / "table.csv"), "-md", str(model_dir), "-o", str(outdir), "-v", "1"])
+    assert res.exit_code == 0, res.output
+    assert (outdir / "a_model_predicted.txt").exists() and (outdir / "b_model_predicted.txt").exists()
+    assert not (outdir / "missing_model_predicted.txt").exists()  # per-recording errors are logged, not raised
+    first = (outdir / "a_model_predicted.txt").read_text().splitlines()[0]
+    assert first == "start\tstop\tlabel"
+    res = CliRunner().invoke(cli, ["predict", str(tmp_path / "model" / "model_shape.json")])
+    assert res.exit_code != 0  # "Recording file must be a wav or csv file"
+
+
+def test_create_spectrograms(tmp_path):
+    from oracle import frontend_ref as F
+    from orcai_amd.io import read_json
+    from orcai_amd.spectrogram import create_spectrograms
+    from orcai_amd.synthetic import pcm16_to_float, synth_recording
+    from orcai_amd.wavio import write_wav_pcm16
+
+    pcm = synth_recording(6.0, 48000, seed=2)
+    write_wav_pcm16(tmp_path / "r1.wav", pcm, 48000)
+    row = {"recording": "r1", "base_dir_recording": str(tmp_path), "rel_recording_path": "r1.wav", "channel": 1, "base_dir_annotation": "x"}
+    row.update({c: True for c in CALLS})
+    pd.DataFrame([row]).to_csv(tmp_path / "t.csv", index=False)
+    out = tmp_path / "spec"
+    create_spectrograms(tmp_path / "t.csv", out, verbosity=0)
+    spec = np.load(out / "r1" / "spectrogram" / "spectrogram.npy")
+    ref, freqs, times = F.make_spectrogram_ref(pcm16_to_float(pcm), {"spectrogram": read_json(ROOT / "orcai_amd" / "defaults" / "default_orcai_parameter.json")["spectrogram"]})
+    assert spec.shape == ref.shape and np.abs(spec - ref).max() <= 2e-4
+    t = read_json(out / "r1" / "spectrogram" / "times.json")
+    assert t["length"] == len(times) and t["max"] == times[-1]
