@@ -130,16 +130,19 @@ int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, i
  *   in   f32[B][Cin][HP][WP] padded planes
  *   dw   f32[Cin][k*k]   (Keras depthwise kernel (k,k,Cin,1) transposed)
  *   pw   f32[Cin][Cout]  (Keras pointwise kernel (1,1,Cin,Cout))
- *   out_layout 0: f32[B][Cout][HP][WP] padded planes;  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
- *   Reshape((-1, W*C)) of the NHWC tensor (architectures.py:208).  Cout <= 64, k in {3,5,7}. */
+ *   out_layout 0: padded channel-quad planes;  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
+ *   Reshape((-1, W*C)) of the NHWC tensor (architectures.py:208);  2: x-pooled f32[B][CQout][H][roundup4(ceil(W/2))][4]:
+ *   element (y, j) = max over the column pair (2j, 2j+1) -- the first half of the MaxPooling2D((3,2), 2, "same") that
+ *   follows (architectures.py:190), consumed by orcai_pool_res_add(xpooled = 1).  Cout <= 64, k in {3,5,7}. */
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream);
 
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
- *   s f32[B][C][HP][WP], prev f32[B][Cp][HP][WP] (padded for kernel size k), wr f32[Cp][C], br f32[C]
+ *   s: padded channel-quad planes of C channels (xpooled = 0) or the x-pooled tensor written by
+ *   orcai_sepconv_bn(out_layout = 2) (xpooled = 1); prev: padded channel-quad planes of Cp channels; wr f32[Cp][C], br f32[C]
  *   -> out f32[B][C][ceil(H/2) + 2*(k/2)][orcai_padded_width(ceil(W/2), k)] padded planes */
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br,
-                       float* out, void* stream);
+                       float* out, int xpooled, void* stream);
 
 /* C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]; act 0 = identity, 1 = ReLU; bias/scale/shift may be NULL.
  * Used for the LSTM input projections x*W + b (architectures.py:210-229) and Dense(128, relu) + BN (:231-237). */

@@ -265,7 +265,8 @@ class ResNetLSTM:
         for b, f in enumerate(self.filters, start=1):
             h, wd, _ = shapes[b - 1]
             ws[f"a{b}"] = planes(f, h, wd)
-            ws[f"b{b}"] = planes(f, h, wd)
+            wx = (wd + 1) // 2  # x-pooled output of the block's second separable conv: [B][CQ][H][roundup4(ceil(W/2))][4]
+            ws[f"b{b}"] = torch.zeros((B, (f + 3) // 4, h, (wx + 3) & ~3, 4), dtype=torch.float32, device=dev)
             ws[f"prev{b}"] = planes(f, shapes[b][0], shapes[b][1])
         self._ws = {B: ws}  # keep only the latest chunk size resident
         return ws
@@ -302,9 +303,9 @@ class ResNetLSTM:
             self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                          N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
             self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
-                         N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 0, N.ptr(bb), st)
+                         N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
-                         N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
+                         N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 1, st)
             c = f
         h, wd, _ = shapes[-1]
         last = ws[f"prev{len(self.filters)}"]
@@ -318,6 +319,11 @@ class ResNetLSTM:
                 chans.update({f"a{i}": f, f"b{i}": f, f"prev{i}": f})
                 widths.update({f"a{i}": shapes[i - 1][1], f"b{i}": shapes[i - 1][1], f"prev{i}": shapes[i][1]})
             for name, t in ws.items():
+                if name.startswith("b"):  # x-pooled (unpadded rows): [B][CQ][H][WPx][4] -> [B][C][H][ceil(W/2)]
+                    Bq, CQ, hh, WPx, _ = t.shape
+                    full = t.permute(0, 1, 4, 2, 3).reshape(Bq, CQ * 4, hh, WPx)
+                    keep[name] = full[:, : chans[name], :, : (widths[name] + 1) // 2].clone()
+                    continue
                 Bq, CQ, HPp, WPp, _ = t.shape
                 hh = HPp - 2 * R
                 full = t.permute(0, 1, 4, 2, 3).reshape(Bq, CQ * 4, HPp, WPp)

@@ -116,8 +116,9 @@ template <int KS, int MT>
 __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][CQin][HP][WP][4]*/, int Cin, int H, int W, int WP, int relu_in,
                                                        const float* __restrict__ dw /*[CQin*4][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP) {
-  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
+                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo) {
+  constexpr int R = KS / 2, KK = KS * KS;
+  const int VAL = 64 - 2 * lo;  // valid output lanes are [lo, 64 - lo); lo >= R
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (task >= tasks) return;  // whole wave; the kernel has no barriers
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
   const int plane = (H + 2 * R) * WP;  // pixels per quad plane
   const int CQ = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
   const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
-  const int qbase = R * WP + task * VAL - R;  // flat padded-plane pixel of lane 0
+  const int qbase = R * WP + task * VAL - lo;  // flat padded-plane pixel of lane 0
   const int q = qbase + lane;
 
   int ridx[KS];  // row-window load indices (clamped: only lanes whose outputs are discarded can leave the plane)
@@ -216,13 +217,42 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
       sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
     }
   float4* outq = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane;
+  if (out_layout == 2) {
+    // x-pooled output for the MaxPooling2D((3,2)) that follows (architectures.py:190): element (y, j) = max over the
+    // column pair (2j, 2j+1) -- the pair's second column is ignored when it is past the image ("same" pads with -inf).
+    // The window starts at an even flat pixel, so pairs are lanes (2k, 2k+1) of one column tile: one shfl_xor.
+    const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+    float4* outx = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * H * WPx;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int wl = 16 * t + lj;
+      const int flat = qbase + wl;
+      const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+      const int x = flat - row * WP;
+      const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H && (x & 1) == 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]);
+          if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+          const float other = __shfl_xor(v[r], 1, 64);
+          v[r] = (x + 1 < W) ? fmaxf(v[r], other) : v[r];
+        }
+        const int oq = m * 4 + lk;
+        if (live && oq < CQo) outx[((int64_t)oq * H + (row - R)) * WPx + (x >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int wl = 16 * t + lj;  // lane index of this pixel inside the window
     const int flat = qbase + wl;
     const int row = (int)__umulhi((uint32_t)flat, magic_WP);  // padded row
     const int x = flat - row * WP;
-    const bool live = wl >= R && wl < 64 - R && x < W && row < R + H;  // row >= R always
+    const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H;  // row >= R always
     if (!live) continue;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -248,53 +278,111 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
 
 // =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
-// thread = (output pixel, output channel quad); channel-quad planes in and out.
+// Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
+// (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
+// loads the dwordx4 of source pixel (2i, 2j), the 4 VGPRs are transposed into B fragments (permlane swaps) and
+// multiplied by the residual weights (A operand, row = output channel).  In the epilogue a lane holds 4
+// consecutive output channels of its pixel and adds the max over the 3 x 2 pooling window, read as dwordx4.
 // =========================================================================================
-__global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s /*[B][CQ][HP][WP][4]*/, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
+template <int MT>
+__global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
                                                             int C, int Cp, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top,
                                                             int pad_left, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
-                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/) {
-  const int b = blockIdx.z, oq = blockIdx.y;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Ho * Wo) return;
-  const int i = idx / Wo, j = idx % Wo;
+                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int xpooled, int tasks, uint32_t magic_WPo) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int b = blockIdx.y;
   const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const int64_t plane = (int64_t)(H + 2 * R) * WP;
-  const int64_t plane_o = (int64_t)(Ho + 2 * R) * WPo;
-  // residual 1x1 stride-2 conv: no padding, samples (2i, 2j)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + (int64_t)(2 * i + R) * WP + 2 * j;
+  const int plane = (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
+  const int qbase = R * WPo + task * 64;
+  const int q = qbase + lane;
+  const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
+  const int pj = q - prow * WPo, pi = prow - R;
+  const bool pvalid = pj < Wo && pi < Ho;
+  const int srcpix = pvalid ? (2 * pi + R) * WP + 2 * pj : 0;
+  const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + srcpix;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 nxt = pp[0];
   for (int cq = 0; cq < CQp; ++cq) {
-    const float4 v = pp[(int64_t)cq * plane];
-    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const float4 cur = nxt;
+    if (cq + 1 < CQp) nxt = pp[(int64_t)(cq + 1) * plane];
+    float afrag[MT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int ci = cq * 4 + k;
-      if (ci < Cp) {
-        const float* wrow = wr + ci * C + oq * 4;  // uniform
+    for (int m = 0; m < MT; ++m) {
+      const int ci = cq * 4 + lk, co = m * 16 + lj;
+      const bool ok = ci < Cp && co < C;
+      const float av = wr[ok ? ci * C + co : 0];
+      afrag[m] = ok ? av : 0.0f;
+    }
+    float d[4] = {cur.x, cur.y, cur.z, cur.w};
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (oq * 4 + c < C) acc[c] = fmaf(vv[k], wrow[c], acc[c]);
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+  }
+
+  float br_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      br_r[m][r] = co < C ? br[co] : 0.0f;
+    }
+  const int WPx = (Wo + 3) & ~3;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int flat = qbase + 16 * t + lj;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);
+    const int j = flat - row * WPo, i = row - R;
+    if (j >= Wo || i >= Ho) continue;
+    const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      if (oq >= CQ) continue;
+      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (xpooled) {  // s is [B][CQ][H][WPx][4], already reduced over the column pair (pad_left == 0)
+        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * (int64_t)H * WPx;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int y = ys + dy;
+          if (y >= 0 && y < H) {
+            const float4 v = sp[(int64_t)y * WPx + j];
+            mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
+          }
+        }
+      } else {
+        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * plane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int y = ys + dy, x = xs + dx;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+              const float4 v = sp[(int64_t)(y + R) * WP + x];
+              mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
+            }
+          }
       }
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f;
+      reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + flat] = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
-  const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;
-  const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * plane;
-  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int y = ys + dy, x = xs + dx;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const float4 v = sp[(int64_t)(y + R) * WP + x];
-        m[0] = fmaxf(m[0], v.x); m[1] = fmaxf(m[1], v.y); m[2] = fmaxf(m[2], v.z); m[3] = fmaxf(m[3], v.w);
-      }
-    }
-  float o[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) o[c] = (oq * 4 + c < C) ? m[c] + (acc[c] + br[oq * 4 + c]) : 0.0f;
-  reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + (int64_t)(i + R) * WPo + j] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // =========================================================================================
@@ -500,12 +588,13 @@ inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 
 template <int KS, int MT>
 int launch_sepconv_impl(int B, hipStream_t st, const float* in, int Cin, int H, int W, int WP, const float* dw, const float* pw, const float* scale,
                         const float* shift, int Cout, int relu_in, int relu_out, int out_layout, float* out) {
-  constexpr int VAL = 64 - 2 * (KS / 2);
+  const int lo = (out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
+  const int VAL = 64 - 2 * lo;
   const int tasks = (H * WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
   if ((int64_t)(H + KS) * WP >= (1ll << 31) / 4) return ORCAI_E_UNSUPPORTED;
   dim3 grid((tasks + 3) / 4, B);
   hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, in, Cin, H, W, WP, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out,
-                     tasks, magic_for(WP));
+                     tasks, magic_for(WP), lo);
   return (int)hipGetLastError();
 }
 
@@ -557,15 +646,27 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
 }
 
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
-                       void* stream) {
+                       int xpooled, void* stream) {
   if (!s || !prev || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
-  dim3 grid((Ho * Wo + 255) / 256, (C + 3) / 4, B);
-  hipLaunchKernelGGL(pool_res_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, s, prev, C, Cp, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
-                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, wr, br, out);
+  if (xpooled && tot_w / 2 != 0) return ORCAI_E_UNSUPPORTED;
+  const int WP = orcai_padded_width(W, ksize), WPo = orcai_padded_width(Wo, ksize), R = ksize / 2;
+  const int tasks = (Ho * WPo + 63) / 64;
+  dim3 grid((tasks + 3) / 4, B);
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t mg = magic_for(WPo);
+#define ORCAI_POOL_LAUNCH(MT) hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg)
+  switch ((C + 15) / 16) {
+    case 1: ORCAI_POOL_LAUNCH(1); break;
+    case 2: ORCAI_POOL_LAUNCH(2); break;
+    case 3: ORCAI_POOL_LAUNCH(3); break;
+    case 4: ORCAI_POOL_LAUNCH(4); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_POOL_LAUNCH
   return (int)hipGetLastError();
 }
 

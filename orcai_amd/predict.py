@@ -265,7 +265,14 @@ def predict(recording_path: str | Path, channel: int = 1, model_dir: str | Path 
         recording_table["output_path"] = [Path(output_path).joinpath(recording + "_" + model_dir.stem + "_predicted.txt") for recording in recording_table["recording"]]
     else:
         recording_table["output_path"] = output_path
-    msgr.part(f"Predicting annotations for {len(recording_table)} wav files")
+    # one process per GPU (torchrun): each rank takes its own recordings; there is no data-path collective
+    from orcai_amd import parallel
+
+    rank, size, _ = parallel.init()
+    if size > 1:
+        mine = parallel.shard_indices(len(recording_table), rank, size)
+        recording_table = recording_table.iloc[mine]
+    msgr.part(f"Predicting annotations for {len(recording_table)} wav files" + (f" (rank {rank} of {size})" if size > 1 else ""))
     progressbar = tqdm(recording_table.index, desc="Starting ...", unit="file", disable=verbosity < 1)
     for i in progressbar:
         try:
