@@ -162,6 +162,50 @@ int orcai_dense_sigmoid(const float* x, const float* w, const float* bias, int64
  *   agg f64[S][L], cnt f64[S];  float64 accumulation in snippet order (bit-exact with the numpy loop). */
 int orcai_overlap_average(const float* pred, int n, int P, int L, int step, int64_t S, double* agg, double* cnt, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training (train.py:155-219: Adam(lr) + MaskedBinaryCrossentropy + MaskedBinaryAccuracy; architectures.py:210-286)
+ * "Row tensors" are f32[M][cols] row-major, M = snippets * time steps.
+ * ------------------------------------------------------------------------------------------ */
+
+/* C[M][N] (=|+=) alpha * sum_k A(m,k) B(k,n) + beta_w * Wreg[m][n] with A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]:
+ * weight gradients (A^T B), input gradients (A B^T) and the L2 term 2*lambda*W of kernel_regularizer=l2 (architectures.py:215,225,235). */
+int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int M, int N, int K, float alpha,
+                       int accumulate, const float* Wreg, float beta_w, void* stream);
+
+/* out[c] (=|+=) sum_m x[m][c]  (bias gradients) */
+int orcai_colsum(const float* x, int M, int C, float* out, int accumulate, void* stream);
+
+/* BatchNormalization in training mode on a row tensor whose channel is (column % C): batch mean / biased variance,
+ * y = [relu]((x - mean) * gamma * rsqrt(var + eps) + beta), and its backward (dbeta, dgamma, dx) with the optional ReLU folded in. */
+int orcai_bn_rows_stats(const float* x, int M, int cols, int C, float* mean, float* var, void* stream);
+int orcai_bn_rows_apply(const float* x, int M, int cols, int C, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                        int relu, float* y, void* stream);
+int orcai_bn_rows_bwd(const float* dy, const float* x, int M, int cols, int C, const float* mean, const float* var, const float* gamma, const float* beta,
+                      float eps, int relu, float* dbeta, float* dgamma, float* dx, void* stream);
+
+/* Dropout: mask[i] in {0,1} from a counter-based generator (seed, i); y = x * mask * scale (forward and backward). */
+int orcai_dropout_mask(float* mask, int64_t n, uint64_t seed, float keep, void* stream);
+int orcai_mask_scale(const float* x, const float* mask, float scale, int64_t n, float* y, void* stream);
+/* dx = dy * (y > 0) */
+int orcai_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
+
+/* MaskedBinaryCrossentropy / MaskedBinaryAccuracy (architectures.py:262-286): acc3 = {sum of BCE, unmasked count, correct count}
+ * (f64, device); dz (may be NULL) = d(mean BCE)/d(logit of the final sigmoid). */
+int orcai_masked_bce(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, void* stream);
+/* out += lambda * sum w^2   (value of the L2 penalty) */
+int orcai_l2_value(const float* w, int64_t n, float lambda, double* out, void* stream);
+
+/* Keras-3 Adam on flat buffers: g is scaled by gscale first (1/world_size after an all-reduce(sum)); step is 1-based. */
+int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, float gscale, void* stream);
+
+/* Training forward of one Bidirectional(LSTM): as orcai_lstm_recurrent, plus the gate activations (i,f,g,o, permuted columns)
+ * f32[B][T][2][4*units] and cell states f32[B][T][2][units] the backward pass needs. */
+int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream);
+/* Backward through time: dH f32[B][T][2*units] (gradient of the layer output) -> dxz f32[B][T][2][4*units] (permuted columns). */
+int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream);
+/* hprev[b][t][dir][u] = h[b][t-1 (dir 0) | t+1 (dir 1)][dir*units + u], 0 at the sequence start: left operand of dU = hprev^T dxz. */
+int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

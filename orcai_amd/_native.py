@@ -37,6 +37,20 @@ _SIGNATURES = {
     "orcai_lstm_recurrent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dense_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_overlap_average": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_gemm_strided": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "orcai_colsum": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "orcai_bn_rows_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_bn_rows_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_bn_rows_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_dropout_mask": (C.c_int, [C.c_void_p, c_i64, C.c_uint64, C.c_float, C.c_void_p]),
+    "orcai_mask_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_masked_bce": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_l2_value": (C.c_int, [C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p]),
+    "orcai_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "orcai_lstm_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_lstm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_lstm_hprev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_resample_polyphase": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

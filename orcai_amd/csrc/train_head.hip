@@ -1,0 +1,582 @@
+// train_head.hip -- training-mode forward extras and backward of the recurrent head of ResNetLSTM for gfx950:
+// strided f32-MFMA GEMM (weight / input gradients), row-tensor BatchNorm / dropout / ReLU kernels, masked BCE,
+// LSTM backward through time, Adam.   Reference: architectures.py:210-239 (layers), :244-286 (loss, metric),
+// train.py:155-161 (Adam(lr), MaskedBinaryCrossentropy, MaskedBinaryAccuracy).
+//
+// "Row tensors" are [M][C] row-major with M = snippets * time steps.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "orcai_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// =========================================================================================
+// C[M][N] (=|+=) alpha * sum_k A(m,k) B(k,n) + beta_w * Wreg[m][n],  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// (covers A^T B for weight gradients and A B^T for input gradients; Wreg adds the L2 term 2*lambda*W).
+// 64 x 64 block tile, BK = 16, 4 waves as 2 x 2, wave tile 32 x 32.
+// =========================================================================================
+constexpr int SP = 64 + 16;
+
+__global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B, int64_t sbk,
+                                                            int64_t sbn, float* __restrict__ C, int M, int N, int K, float alpha, int accumulate,
+                                                            const float* __restrict__ Wreg, float beta_w) {
+  __shared__ float As[16][SP];
+  __shared__ float Bs[16][SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    {
+      const int row = tid >> 2, kq = (tid & 3) * 4;  // 64 rows x 16 k
+      const int m = m0 + row;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + kq + q;
+        As[kq + q][row] = (m < M && k < K) ? A[(int64_t)m * sam + (int64_t)k * sak] : 0.0f;
+      }
+    }
+    {
+      const int k = tid >> 4, nn = (tid & 15) * 4;  // 16 k x 64 n
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + nn + q;
+        Bs[k][nn + q] = (k0 + k < K && n < N) ? B[(int64_t)(k0 + k) * sbk + (int64_t)n * sbn] : 0.0f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float a[2], bq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk * 4 + lk][wm * 32 + i * 16 + lj];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = Bs[kk * 4 + lk][wn * 32 + j * 16 + lj];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], bq[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 32 + i * 16 + lk * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + lj;
+        if (n >= N) continue;
+        float v = alpha * acc[i][j][r];
+        if (Wreg) v = fmaf(beta_w, Wreg[(int64_t)m * N + n], v);
+        float* c = C + (int64_t)m * N + n;
+        *c = accumulate ? *c + v : v;
+      }
+    }
+}
+
+// column sums of a row tensor: out[c] (=|+=) sum_m x[m][c]      (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out, int accumulate) {
+  __shared__ float part[256];
+  const int c = blockIdx.x;
+  float s = 0.0f;
+  for (int m = threadIdx.x; m < M; m += 256) s += x[(int64_t)m * C + c];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + part[0] : part[0];
+}
+
+// =========================================================================================
+// BatchNormalization (training) on a row tensor whose column index is (position * C + channel), i.e. the channel is
+// column % C: Dense-128 output (C = 128 = columns) and the final separable conv in Keras Reshape layout (C = 36).
+// stats[c] = {mean, biased var}; one workgroup per channel, float64 accumulation.
+// =========================================================================================
+__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int cols, int C, float* __restrict__ mean,
+                                                             float* __restrict__ var) {
+  __shared__ double s1[256], s2[256];
+  const int c = blockIdx.x;
+  const int per_row = cols / C;
+  double a = 0.0, b = 0.0;
+  const int64_t total = (int64_t)M * per_row;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int64_t m = i / per_row;
+    const int p = (int)(i - m * per_row);
+    const double v = (double)x[m * cols + (int64_t)p * C + c];
+    a += v;
+    b += v * v;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mu = s1[0] / (double)total;
+    mean[c] = (float)mu;
+    double vv = s2[0] / (double)total - mu * mu;
+    var[c] = (float)(vv < 0.0 ? 0.0 : vv);
+  }
+}
+
+// y = [relu]( (x - mean) * gamma * rsqrt(var + eps) + beta )
+__global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, int64_t n, int C, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float inv = gamma[c] * rsqrtf(var[c] + eps);
+  float v = fmaf(x[i], inv, beta[c] - mean[c] * inv);
+  if (relu) v = fmaxf(v, 0.0f);
+  y[i] = v;
+}
+
+// BN backward, reduction part: with dy_eff = relu ? dy * (y > 0) : dy  (y = BN output),
+//   sums[c] = {sum dy_eff, sum dy_eff * xhat};  also dgamma = sums[1], dbeta = sums[0].
+__global__ __launch_bounds__(256) void bn_rows_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int cols, int C,
+                                                                 const float* __restrict__ mean, const float* __restrict__ var,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  __shared__ double s1[256], s2[256];
+  const int c = blockIdx.x;
+  const int per_row = cols / C;
+  const float inv = rsqrtf(var[c] + eps), mu = mean[c], g = gamma[c], bt = beta[c];
+  double a = 0.0, b = 0.0;
+  const int64_t total = (int64_t)M * per_row;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int64_t m = i / per_row;
+    const int p = (int)(i - m * per_row);
+    const int64_t idx = m * cols + (int64_t)p * C + c;
+    const float xh = (x[idx] - mu) * inv;
+    float d = dy[idx];
+    if (relu && !(fmaf(xh, g, bt) > 0.0f)) d = 0.0f;
+    a += (double)d;
+    b += (double)d * (double)xh;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { dbeta[c] = (float)s1[0]; dgamma[c] = (float)s2[0]; }
+}
+
+// dx = gamma * inv * (dy_eff - dbeta/N - xhat * dgamma/N)
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t n, int C, float count,
+                                                                 const float* __restrict__ mean, const float* __restrict__ var,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                                 const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                                 float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float inv = rsqrtf(var[c] + eps);
+  const float xh = (x[i] - mean[c]) * inv;
+  float d = dy[i];
+  if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) d = 0.0f;
+  dx[i] = gamma[c] * inv * (d - dbeta[c] / count - xh * dgamma[c] / count);
+}
+
+// y = x * mask * scale (Dropout forward and backward; mask holds 0/1)
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale, int64_t n,
+                                                          float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = x[i] * mask[i] * scale;
+}
+
+// dx = dy * (y > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int64_t n, float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// counter-based Bernoulli(keep) mask: splitmix64 of (seed, element index) -> 0/1
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, int64_t n, uint64_t seed, float keep) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  mask[i] = u < keep ? 1.0f : 0.0f;
+}
+
+// =========================================================================================
+// MaskedBinaryCrossentropy + MaskedBinaryAccuracy (architectures.py:244-286).
+// pass 1: acc[0] += sum of BCE over unmasked elements, acc[1] += count, acc[2] += correct ((p > 0.5) == y)
+// pass 2: dz = dL/d(logit) = mask * (dL/dp) * p (1 - p) / count   (dL/dp = 0 where p is clipped)
+// =========================================================================================
+__global__ __launch_bounds__(256) void bce_reduce_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float mask_value,
+                                                          double* __restrict__ acc) {
+  __shared__ double s0[256], s1[256], s2[256];
+  double l = 0.0, c = 0.0, k = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float t = y[i];
+    if (t != mask_value) {
+      const float q = fminf(fmaxf(p[i], 1e-7f), 1.0f - 1e-7f);
+      l += -((double)t * (double)logf(q) + (1.0 - (double)t) * (double)logf(1.0f - q));
+      c += 1.0;
+      k += ((p[i] > 0.5f ? 1.0f : 0.0f) == t) ? 1.0 : 0.0;
+    }
+  }
+  s0[threadIdx.x] = l; s1[threadIdx.x] = c; s2[threadIdx.x] = k;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(&acc[0], s0[0]); atomicAdd(&acc[1], s1[0]); atomicAdd(&acc[2], s2[0]); }
+}
+
+__global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float mask_value,
+                                                        const double* __restrict__ acc, float* __restrict__ dz) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float t = y[i], q = p[i];
+  float g = 0.0f;
+  if (t != mask_value && q > 1e-7f && q < 1.0f - 1e-7f) {
+    const float dLdp = -t / q + (1.0f - t) / (1.0f - q);
+    g = dLdp * q * (1.0f - q) / (float)acc[1];
+  }
+  dz[i] = g;
+}
+
+// sum of squares (L2 penalty value): out += lambda * sum w^2
+__global__ __launch_bounds__(256) void l2_value_kernel(const float* __restrict__ w, int64_t n, float lambda, double* __restrict__ out) {
+  __shared__ double s[256];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)w[i] * (double)w[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, (double)lambda * s[0]);
+}
+
+// Adam (Keras 3 form): m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); w -= alpha * m / (sqrt(v) + eps),  alpha = lr*sqrt(1-b2^t)/(1-b1^t)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    int64_t n, float alpha, float b1, float b2, float eps, float gscale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+  const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+  m[i] = mi;
+  v[i] = vi;
+  w[i] = w[i] - alpha * mi / (sqrtf(vi) + eps);
+}
+
+// =========================================================================================
+// LSTM, training forward: the inference recurrence (model_fwd.hip lstm_kernel) plus stores of the gate activations
+// (i, f, g, o in the kernel's permuted column order) and of the cell state, needed by the backward pass.
+// =========================================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
+                                                                int B, int T, float* __restrict__ out /*[B][T][2U]*/,
+                                                                float* __restrict__ gates /*[B][T][2][4U] permuted: i f g o activations*/,
+                                                                float* __restrict__ cstate /*[B][T][2][U]*/) {
+  constexpr int KSTEPS = U / 4, HP = U + 2;
+  __shared__ float hbuf[2][16][HP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  float ufrag[2][KSTEPS];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) ufrag[nt][kk] = Ud[(int64_t)(kk * 4 + lk) * (4 * U) + wave * 32 + nt * 16 + lj];
+  for (int i = tid; i < 2 * 16 * HP; i += U * 8) (&hbuf[0][0][0])[i] = 0.0f;
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int unit = wave * 8 + (lj & 7);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + lk * 4 + r;
+        acc[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+      }
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+      const float a = hbuf[cur][lj][kk * 4 + lk];
+      acc[0] = mfma16(a, ufrag[0][kk], acc[0]);
+      acc[1] = mfma16(a, ufrag[1][kk], acc[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mine0 = acc[0][r], mine1 = acc[1][r];
+      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
+      const bool low = lj < 8;
+      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
+      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
+      const float c = gf * cst[r] + gi * gg;
+      const float h = go * tanhf_(c);
+      cst[r] = c;
+      const int row = lk * 4 + r, bb = b0 + row;
+      if (bb < B) {  // this lane's own two gate columns: tile 0 column lj (i or f), tile 1 column lj (g or o)
+        float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
+        gp[0] = low ? gi : gf;
+        gp[16] = low ? gg : go;
+      }
+      if (low) {
+        hbuf[cur ^ 1][row][unit] = h;
+        if (bb < B) {
+          out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+          cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =========================================================================================
+// LSTM backward through time for one direction and 16 snippets.  Per step (walking the forward order backwards):
+//   dh = dH[t] + (dz[t_next] * U^T)     (recurrent part accumulated in LDS by all waves with ds_add_f32)
+//   do = dh tanh(c); dc += dh o (1 - tanh^2 c); di = dc g; dg = dc i; df = dc c_prev; dc_prev = dc f
+//   dz = (di i(1-i), df f(1-f), dg (1-g^2), do o(1-o))  -> dxz[t] (permuted columns), and the next recurrent term.
+// Wave w owns the gate columns [32w, 32w+32) = units [8w, 8w+8); U^T fragments of those columns stay in registers.
+// =========================================================================================
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
+                                                          const float* __restrict__ Uw /*[2][U][4U] permuted*/, int B, int T,
+                                                          float* __restrict__ dxz /*[B][T][2][4U] permuted*/) {
+  constexpr int NT = U / 16, HP = U + 2, ZP = 34;
+  __shared__ float dhbuf[2][16][HP];
+  __shared__ float dzt[U / 8][16][ZP];  // per wave: dz[batch][32 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  // B'[p][k] = U[k][p] for this wave's 32 columns p: k-step s covers p = 4s..4s+3, column tile kt covers k = 16kt..16kt+15
+  float ut[8][NT];
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) ut[s][kt] = Ud[(int64_t)(kt * 16 + lj) * (4 * U) + wave * 32 + 4 * s + lk];
+  for (int i = tid; i < 2 * 16 * HP; i += U * 8) (&dhbuf[0][0][0])[i] = 0.0f;
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int unit = wave * 8 + (lj & 7);
+  const bool worker = lj < 8;  // lanes lj < 8 of each 16-lane row handle (rows 4lk..4lk+3, unit)
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : (T - 1 - step);       // reverse of the forward order
+    const int tprev = dir ? t + 1 : t - 1;           // forward-order predecessor (source of c_prev)
+    const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+    const int cur = step & 1;
+    if (worker) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lk * 4 + r, bb = b0 + row;
+        float dzi = 0.f, dzf = 0.f, dzg = 0.f, dzo = 0.f;
+        const float dhr = dhbuf[cur][row][unit];
+        dhbuf[cur][row][unit] = 0.0f;  // ready to be accumulated into two steps later
+        if (bb < B) {
+          const int64_t gbase = (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + (lj & 7);
+          const float gi = gates[gbase], gf = gates[gbase + 8], gg = gates[gbase + 16], go = gates[gbase + 24];
+          const float c = cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit];
+          const float cp = has_prev ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.0f;
+          const float dh = dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] + dhr;
+          const float tc = tanhf_(c);
+          const float dO = dh * tc;
+          const float dct = dc[r] + dh * go * (1.0f - tc * tc);
+          dzi = dct * gg * gi * (1.0f - gi);
+          dzf = dct * cp * gf * (1.0f - gf);
+          dzg = dct * gi * (1.0f - gg * gg);
+          dzo = dO * go * (1.0f - go);
+          dc[r] = dct * gf;
+          float* dp = dxz + gbase;
+          dp[0] = dzi; dp[8] = dzf; dp[16] = dzg; dp[24] = dzo;
+        }
+        float* zr = &dzt[wave][row][lj & 7];
+        zr[0] = dzi; zr[8] = dzf; zr[16] = dzg; zr[24] = dzo;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // recurrent term: D[batch][k] = sum_p dz[batch][p] * U[k][p] over this wave's 32 columns, added into dhbuf[next]
+    f32x4 acc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = dzt[wave][lj][4 * s + lk];  // A[i = batch lj][k = column 4s + lk]
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) acc[kt] = mfma16(a, ut[s][kt], acc[kt]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&dhbuf[cur ^ 1][lk * 4 + r][kt * 16 + lj], acc[kt][r]);
+    __syncthreads();
+  }
+}
+
+// h_prev[b][t][dir][u] = h[b][t -+ 1][dir*U + u] (0 at the sequence start of each direction): left operand of dU = h_prev^T dxz
+__global__ __launch_bounds__(256) void lstm_hprev_kernel(const float* __restrict__ h /*[B][T][2U]*/, int B, int T, int U, float* __restrict__ hp /*[B][T][2][U]*/) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = (int64_t)B * T * 2 * U;
+  if (i >= n) return;
+  const int u = (int)(i % U);
+  const int dir = (int)((i / U) % 2);
+  const int t = (int)((i / (2 * U)) % T);
+  const int64_t b = i / ((int64_t)2 * U * T);
+  const int tp = dir ? t + 1 : t - 1;
+  hp[i] = (tp >= 0 && tp < T) ? h[(b * T + tp) * (2 * U) + dir * U + u] : 0.0f;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int M, int N, int K, float alpha,
+                       int accumulate, const float* Wreg, float beta_w, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ORCAI_E_BADARG;
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, M, N, K, alpha, accumulate, Wreg, beta_w);
+  return (int)hipGetLastError();
+}
+
+int orcai_colsum(const float* x, int M, int C, float* out, int accumulate, void* stream) {
+  if (!x || !out || M <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, M, C, out, accumulate);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_rows_stats(const float* x, int M, int cols, int C, float* mean, float* var, void* stream) {
+  if (!x || !mean || !var || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, M, cols, C, mean, var);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_rows_apply(const float* x, int M, int cols, int C, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                        int relu, float* y, void* stream) {
+  if (!x || !y || !mean || !var || !gamma || !beta || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
+  const int64_t n = (int64_t)M * cols;
+  hipLaunchKernelGGL(bn_rows_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, C, mean, var, gamma, beta, eps, relu, y);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_rows_bwd(const float* dy, const float* x, int M, int cols, int C, const float* mean, const float* var, const float* gamma, const float* beta,
+                      float eps, int relu, float* dbeta, float* dgamma, float* dx, void* stream) {
+  if (!dy || !x || !dx || !dbeta || !dgamma || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_rows_bwd_stats_kernel, dim3(C), dim3(256), 0, st, dy, x, M, cols, C, mean, var, gamma, beta, eps, relu, dbeta, dgamma);
+  const int64_t n = (int64_t)M * cols;
+  const float count = (float)((int64_t)M * (cols / C));
+  hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, x, n, C, count, mean, var, gamma, beta, eps, relu, dbeta, dgamma, dx);
+  return (int)hipGetLastError();
+}
+
+int orcai_mask_scale(const float* x, const float* mask, float scale, int64_t n, float* y, void* stream) {
+  if (!x || !mask || !y || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(mask_scale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, n, y);
+  return (int)hipGetLastError();
+}
+
+int orcai_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream) {
+  if (!dy || !y || !dx || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, n, dx);
+  return (int)hipGetLastError();
+}
+
+int orcai_dropout_mask(float* mask, int64_t n, uint64_t seed, float keep, void* stream) {
+  if (!mask || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, keep);
+  return (int)hipGetLastError();
+}
+
+int orcai_masked_bce(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, void* stream) {
+  if (!p || !y || !acc3 || n <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc3, 0, 3 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  unsigned g = blocks_for(n);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(bce_reduce_kernel, dim3(g), dim3(256), 0, st, p, y, n, mask_value, acc3);
+  if (dz) hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, st, p, y, n, mask_value, acc3, dz);
+  return (int)hipGetLastError();
+}
+
+int orcai_l2_value(const float* w, int64_t n, float lambda, double* out, void* stream) {
+  if (!w || !out || n <= 0) return ORCAI_E_BADARG;
+  unsigned g = blocks_for(n);
+  if (g > 128) g = 128;
+  hipLaunchKernelGGL(l2_value_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, n, lambda, out);
+  return (int)hipGetLastError();
+}
+
+int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step, float gscale, void* stream) {
+  if (!w || !g || !m || !v || n <= 0 || step < 1) return ORCAI_E_BADARG;
+  const double alpha = (double)lr * sqrt(1.0 - pow((double)b2, step)) / (1.0 - pow((double)b1, step));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, (float)alpha, b1, b2, eps, gscale);
+  return (int)hipGetLastError();
+}
+
+int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream) {
+  if (!xz || !Uw || !out || !gates || !cstate || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  dim3 grid((B + 15) / 16, 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (units) {
+    case 128: hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+    case 64: hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream) {
+  if (!dH || !gates || !cstate || !Uw || !dxz || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  dim3 grid((B + 15) / 16, 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (units) {
+    case 128: hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(1024), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
+    case 64: hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(512), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void* stream) {
+  if (!h || !hprev || B <= 0 || T <= 0 || units <= 0) return ORCAI_E_BADARG;
+  const int64_t n = (int64_t)B * T * 2 * units;
+  hipLaunchKernelGGL(lstm_hprev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, h, B, T, units, hprev);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
