@@ -206,6 +206,39 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
 /* hprev[b][t][dir][u] = h[b][t-1 (dir 0) | t+1 (dir 1)][dir*units + u], 0 at the sequence start: left operand of dU = hprev^T dxz. */
 int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void* stream);
 
+/* conv0 with a selectable ReLU (training forward stores the pre-BatchNorm output: scale = 1, shift = bias, relu = 0). */
+int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                       int relu, float* out, void* stream);
+
+/* orcai_sepconv_bn with the tap size (ktap in {1,3,5,7}) decoupled from the padding of the planes (ksize_planes >= ktap), used by the
+ * backward pass: ktap = 1 is a pure pointwise conv (input gradient through the pointwise weights), out_layout 3 scatter-ADDS the
+ * result to pixel (2y, 2x) of planes of an H2 x W2 image (input gradient of the stride-2 1x1 residual conv). */
+int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
+                         const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream);
+
+/* BatchNormalization (training) on padded channel-quad planes: batch mean / biased variance (scratch: f64[8*ceil(C/4)]),
+ * y = [relu](v*s + t) at interior pixels, backward (dbeta, dgamma, dv) with the optional ReLU folded in. */
+int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize, double* scratch, float* mean, float* var, void* stream);
+int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
+                          float eps, int relu, float* y, void* stream);
+int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                        const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, float* dv, void* stream);
+/* out[c] (=|+=) sum over snippets and pixels of x[c] (bias gradients); scratch: f64[4*ceil(C/4)] */
+int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratch, float* out, int accumulate, void* stream);
+/* gradient of MaxPooling2D((3,2), 2, "same"): dy[y][x] = sum of dout over the windows whose maximum is ybn[y][x] */
+int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream);
+/* D[ca][cb] += sum over snippets and pixels of A[ca][p] * Bq[cb][p] (pointwise / residual weight gradients); with a_stride2 the A planes
+ * are an Ha x Wa image sampled at (2i, 2j) for pixel (i, j) of the H x W image of Bq. */
+int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, void* stream);
+/* dW[c][tap] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient) */
+int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
+/* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
+int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);
+/* Keras-Reshape layout f32[B][H][W*C] -> padded channel-quad planes (gradient entering the final separable conv) */
+int orcai_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, float* out, void* stream);
+/* dx = (y > 0) ? dy : 0 on whole plane buffers (n_floats % 4 == 0) */
+int orcai_planes_relu_bwd(const float* dy, const float* y, int64_t n_floats, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,7 +135,7 @@ def loss_and_grads(params_np: dict, x: np.ndarray, y: np.ndarray, masks_np: dict
     loss = bce + l2_penalty(p)
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in p.items() if v.requires_grad}
-    return {"loss": float(loss), "bce": float(bce), "grads": grads, "probs": probs.detach().numpy(), "new_stats": {k: v.numpy() for k, v in new_stats.items()}}
+    return {"loss": float(loss.detach()), "bce": float(bce.detach()), "grads": grads, "probs": probs.detach().numpy(), "new_stats": {k: v.numpy() for k, v in new_stats.items()}}
 
 
 def adam_step_ref(w: np.ndarray, g: np.ndarray, m: np.ndarray, v: np.ndarray, t: int, lr: float, b1=0.9, b2=0.999, eps=1e-7):

@@ -40,7 +40,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 template <int KS>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
                                                      const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][4][HP][WP][4]*/) {
+                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][4][HP][WP][4]*/, int relu) {
   constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
   __shared__ float halo[HH][HP_];
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
@@ -71,10 +71,11 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v;
-      v.x = fmaxf(fmaf(acc[4 * q + 0], scale[4 * q + 0], shift[4 * q + 0]), 0.0f);
-      v.y = fmaxf(fmaf(acc[4 * q + 1], scale[4 * q + 1], shift[4 * q + 1]), 0.0f);
-      v.z = fmaxf(fmaf(acc[4 * q + 2], scale[4 * q + 2], shift[4 * q + 2]), 0.0f);
-      v.w = fmaxf(fmaf(acc[4 * q + 3], scale[4 * q + 3], shift[4 * q + 3]), 0.0f);
+      v.x = fmaf(acc[4 * q + 0], scale[4 * q + 0], shift[4 * q + 0]);
+      v.y = fmaf(acc[4 * q + 1], scale[4 * q + 1], shift[4 * q + 1]);
+      v.z = fmaf(acc[4 * q + 2], scale[4 * q + 2], shift[4 * q + 2]);
+      v.w = fmaf(acc[4 * q + 3], scale[4 * q + 3], shift[4 * q + 3]);
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       o[(int64_t)q * plane] = v;
     }
   }
@@ -116,8 +117,9 @@ template <int KS, int MT>
 __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][CQin][HP][WP][4]*/, int Cin, int H, int W, int WP, int relu_in,
                                                        const float* __restrict__ dw /*[CQin*4][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo) {
-  constexpr int R = KS / 2, KK = KS * KS;
+                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo, int RP, int H2, int WP2) {
+  constexpr int KK = KS * KS;
+  const int R = RP;  // rows of zero padding of the planes (>= KS/2, the tap radius)
   const int VAL = 64 - 2 * lo;  // valid output lanes are [lo, 64 - lo); lo >= R
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
   int ridx[KS];  // row-window load indices (clamped: only lanes whose outputs are discarded can leave the plane)
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) {
-    const int i = q + (dy - R) * WP;
+    const int i = q + (dy - KS / 2) * WP;
     ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
   }
 
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
       for (int j = 0; j < 4; ++j) {
         if (relu_in) a[j] = fmaxf(a[j], 0.0f);
         const float* wj = wgt + j * KK + dy * KS;
-        if constexpr (KS == 3) {
+        if constexpr (KS == 1) {
+          d[j] = a[j] * wj[0];
+        } else if constexpr (KS == 3) {
           d[j] = fmaf(lane_shift<-1>(a[j]), wj[0], d[j]);
           d[j] = fmaf(a[j], wj[1], d[j]);
           d[j] = fmaf(lane_shift<1>(a[j]), wj[2], d[j]);
@@ -266,6 +270,12 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
       if (oq >= CQo) continue;
       if (out_layout == 0) {
         outq[(int64_t)oq * plane + flat] = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (out_layout == 3) {  // scatter-add to pixel (2y, 2x) of planes [B][CQo][H2 + 2R][WP2][4]: backward of a stride-2 1x1 conv
+        const int64_t plane2 = (int64_t)(H2 + 2 * R) * WP2;
+        float4* o2 = reinterpret_cast<float4*>(out) + ((int64_t)b * CQo + oq) * plane2 + (int64_t)(2 * (row - R) + R) * WP2 + 2 * x;
+        float4 t4 = *o2;
+        t4.x += v[0]; t4.y += v[1]; t4.z += v[2]; t4.w += v[3];
+        *o2 = t4;
       } else {  // Keras Reshape((-1, W*C)) of NHWC: feature = x*Cout + co   (architectures.py:208)
         float* o = out + ((int64_t)b * H + (row - R)) * ((int64_t)W * Cout) + (int64_t)x * Cout + oq * 4;
 #pragma unroll
@@ -585,27 +595,31 @@ __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __res
 
 inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }  // __umulhi(n, magic) == n / d while n*d < 2^32
 
+struct SepArgs {
+  const float *in, *dw, *pw, *scale, *shift;
+  float* out;
+  int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
+};
+
 template <int KS, int MT>
-int launch_sepconv_impl(int B, hipStream_t st, const float* in, int Cin, int H, int W, int WP, const float* dw, const float* pw, const float* scale,
-                        const float* shift, int Cout, int relu_in, int relu_out, int out_layout, float* out) {
-  const int lo = (out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
+int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
+  const int lo = (a.out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
   const int VAL = 64 - 2 * lo;
-  const int tasks = (H * WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
-  if ((int64_t)(H + KS) * WP >= (1ll << 31) / 4) return ORCAI_E_UNSUPPORTED;
-  dim3 grid((tasks + 3) / 4, B);
-  hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, in, Cin, H, W, WP, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, out,
-                     tasks, magic_for(WP), lo);
+  const int tasks = (a.H * a.WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
+  if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  dim3 grid((tasks + 3) / 4, a.B);
+  hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pw, a.scale, a.shift, a.Cout, a.relu_out,
+                     a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2);
   return (int)hipGetLastError();
 }
 
 template <int KS>
-int launch_sepconv(int B, hipStream_t st, const float* in, int Cin, int H, int W, int WP, const float* dw, const float* pw, const float* scale,
-                   const float* shift, int Cout, int relu_in, int relu_out, int out_layout, float* out) {
-  switch ((Cout + 15) / 16) {
-    case 1: return launch_sepconv_impl<KS, 1>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
-    case 2: return launch_sepconv_impl<KS, 2>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
-    case 3: return launch_sepconv_impl<KS, 3>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
-    case 4: return launch_sepconv_impl<KS, 4>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+int launch_sepconv(hipStream_t st, const SepArgs& a) {
+  switch ((a.Cout + 15) / 16) {
+    case 1: return launch_sepconv_impl<KS, 1>(st, a);
+    case 2: return launch_sepconv_impl<KS, 2>(st, a);
+    case 3: return launch_sepconv_impl<KS, 3>(st, a);
+    case 4: return launch_sepconv_impl<KS, 4>(st, a);
     default: return ORCAI_E_UNSUPPORTED;
   }
 }
@@ -618,14 +632,19 @@ int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 
 int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
                         const float* shift, float* out, void* stream) {
+  return orcai_conv0_affine(in, snippet_stride, B, H, W, ksize, w, scale, shift, 1, out, stream);
+}
+
+int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                       int relu, float* out, void* stream) {
   if (!in || !w || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   dim3 grid((W + 31) / 32, (H + 7) / 8, B);
   hipStream_t st = (hipStream_t)stream;
   const int WP = orcai_padded_width(W, ksize);
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
-    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
-    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out); break;
+    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
+    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
+    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();
@@ -633,14 +652,22 @@ int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, i
 
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream) {
+  return orcai_sepconv_planes(in, B, Cin, H, W, ksize, ksize, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, 0, 0, out, stream);
+}
+
+int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
+                         const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream) {
   if (!in || !dw || !pw || !scale || !shift || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
-  if (Cout > 64 || ((uintptr_t)in & 15)) return ORCAI_E_UNSUPPORTED;
+  if (Cout > 64 || ((uintptr_t)in & 15) || ktap > ksize_planes) return ORCAI_E_UNSUPPORTED;
+  if (out_layout == 3 && (H2 < 2 * H - 1 || W2 < 2 * W - 1)) return ORCAI_E_BADARG;
+  SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, orcai_padded_width(W, ksize_planes), ksize_planes / 2, Cout, relu_in, relu_out, out_layout,
+            H2, out_layout == 3 ? orcai_padded_width(W2, ksize_planes) : 0};
   hipStream_t st = (hipStream_t)stream;
-  const int WP = orcai_padded_width(W, ksize);
-  switch (ksize) {
-    case 3: return launch_sepconv<3>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
-    case 5: return launch_sepconv<5>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
-    case 7: return launch_sepconv<7>(B, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_in, relu_out, out_layout, out);
+  switch (ktap) {
+    case 1: return launch_sepconv<1>(st, a);
+    case 3: return launch_sepconv<3>(st, a);
+    case 5: return launch_sepconv<5>(st, a);
+    case 7: return launch_sepconv<7>(st, a);
     default: return ORCAI_E_UNSUPPORTED;
   }
 }

@@ -1,0 +1,562 @@
+// train_trunk.hip -- training-mode BatchNorm and the backward kernels of the convolutional trunk of ResNetLSTM for
+// gfx950, on the padded channel-quad planes of model_fwd.hip ([snippet][CQ][HP][WP][4], zero pads never written).
+// Reference: architectures.py:162-206 (layers), train.py:201-219 (model.fit computes these gradients inside Keras).
+//
+// Because the pads of every activation / gradient tensor are zero, reductions run over whole planes with no masks.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "orcai_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// ---------------------------------------------------------------- per-channel sums over planes
+// sums[c] += sum x, sumsq[c] += sum x^2 (sumsq may be NULL) over all snippets and pixels; float64 accumulation.
+__global__ __launch_bounds__(256) void planes_sums_kernel(const float* __restrict__ x, int CQ, int64_t plane, int B, double* __restrict__ sums,
+                                                           double* __restrict__ sumsq) {
+  __shared__ double red[256][4];
+  const int cq = blockIdx.y;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  const int64_t total = (int64_t)B * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / plane, p = i - b * plane;
+    const float4 v = reinterpret_cast<const float4*>(x)[(b * CQ + cq) * plane + p];
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+  }
+  for (int pass = 0; pass < (sumsq ? 2 : 1); ++pass) {
+    const double* src = pass ? q : s;
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = src[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o)
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) atomicAdd(&(pass ? sumsq : sums)[cq * 4 + threadIdx.x], red[0][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+__global__ void bn_finish_stats_kernel(const double* __restrict__ sums, const double* __restrict__ sumsq, int C, double count, float* __restrict__ mean,
+                                       float* __restrict__ var) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / count;
+  double v = sumsq[c] / count - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(v < 0.0 ? 0.0 : v);
+}
+
+// y = [relu](v * s + t) at interior pixels (s = gamma*rsqrt(var+eps), t = beta - mean*s); pads of y are left untouched (zero).
+__global__ __launch_bounds__(256) void bn_planes_apply_kernel(const float* __restrict__ v, int C, int H, int W, int WP, int R, const float* __restrict__ mean,
+                                                               const float* __restrict__ var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int B) {
+  const int CQ = (C + 3) >> 2;
+  const int64_t interior = (int64_t)H * W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * CQ * interior) return;
+  const int64_t bq = idx / interior, pix = idx - bq * interior;
+  const int cq = (int)(bq % CQ);
+  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  const int64_t off = bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx;
+  const float4 a = reinterpret_cast<const float4*>(v)[off];
+  float in[4] = {a.x, a.y, a.z, a.w}, o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;
+    if (c < C) {
+      const float s = gamma[c] * rsqrtf(var[c] + eps);
+      float r = fmaf(in[k], s, beta[c] - mean[c] * s);
+      o[k] = relu ? fmaxf(r, 0.0f) : r;
+    } else {
+      o[k] = 0.0f;
+    }
+  }
+  reinterpret_cast<float4*>(y)[off] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// BN backward, reduction part over planes: dy_eff = relu ? dy*(y>0) : dy;  dbeta[c] += sum dy_eff, dgamma[c] += sum dy_eff*xhat
+__global__ __launch_bounds__(256) void bn_planes_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ v, int C, int64_t plane, int B,
+                                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                                  double* __restrict__ dbeta, double* __restrict__ dgamma) {
+  __shared__ double red[256][4];
+  const int cq = blockIdx.y, CQ = (C + 3) >> 2;
+  float mu[4], inv[4], g[4], bt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k, cc = c < C ? c : 0;
+    mu[k] = mean[cc]; inv[k] = rsqrtf(var[cc] + eps); g[k] = gamma[cc]; bt[k] = beta[cc];
+  }
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  const int64_t total = (int64_t)B * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / plane, p = i - b * plane;
+    const int64_t off = (b * CQ + cq) * plane + p;
+    const float4 d4 = reinterpret_cast<const float4*>(dy)[off];
+    const float4 v4 = reinterpret_cast<const float4*>(v)[off];
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (vv[k] - mu[k]) * inv[k];
+      float de = d[k];
+      if (relu && !(fmaf(xh, g[k], bt[k]) > 0.0f)) de = 0.0f;
+      s[k] += (double)de;
+      q[k] += (double)de * (double)xh;
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* src = pass ? q : s;
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][k] = src[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o)
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 4 && cq * 4 + threadIdx.x < C) atomicAdd(&(pass ? dgamma : dbeta)[cq * 4 + threadIdx.x], red[0][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+// dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) at interior pixels (pads of dv stay zero)
+__global__ __launch_bounds__(256) void bn_planes_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ v, int C, int H, int W, int WP, int R,
+                                                                   const float* __restrict__ mean, const float* __restrict__ var,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                                   const double* __restrict__ dbeta, const double* __restrict__ dgamma, double count,
+                                                                   float* __restrict__ dv, int B) {
+  const int CQ = (C + 3) >> 2;
+  const int64_t interior = (int64_t)H * W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * CQ * interior) return;
+  const int64_t bq = idx / interior, pix = idx - bq * interior;
+  const int cq = (int)(bq % CQ);
+  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  const int64_t off = bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx;
+  const float4 d4 = reinterpret_cast<const float4*>(dy)[off];
+  const float4 v4 = reinterpret_cast<const float4*>(v)[off];
+  const float d[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;
+    if (c < C) {
+      const float inv = rsqrtf(var[c] + eps);
+      const float xh = (vv[k] - mean[c]) * inv;
+      float de = d[k];
+      if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+      o[k] = gamma[c] * inv * (de - (float)(dbeta[c] / count) - xh * (float)(dgamma[c] / count));
+    } else {
+      o[k] = 0.0f;
+    }
+  }
+  reinterpret_cast<float4*>(dv)[off] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ a, float* __restrict__ b, int n, int accumulate) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
+}
+
+// ---------------------------------------------------------------- max-pool backward (gather form)
+// dy[y][x] = sum over the pooling windows (i, j) containing (y, x) of dout[i][j] * [ybn[y][x] == max of that window]
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout /*[B][CQ][Ho+2R][WPo][4]*/, const float* __restrict__ ybn /*[B][CQ][HP][WP][4]*/,
+                                                        int C, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, int pad_left,
+                                                        float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B) {
+  const int CQ = (C + 3) >> 2;
+  const int64_t interior = (int64_t)H * W;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * CQ * interior) return;
+  const int64_t bq = idx / interior, pix = idx - bq * interior;
+  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  const float4* yp = reinterpret_cast<const float4*>(ybn) + bq * ((int64_t)(H + 2 * R) * WP);
+  const float4* dp = reinterpret_cast<const float4*>(dout) + bq * ((int64_t)(Ho + 2 * R) * WPo);
+  const float4 me = yp[(int64_t)(yy + R) * WP + xx];
+  const float mv[4] = {me.x, me.y, me.z, me.w};
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const int j = (xx + pad_left) >> 1;
+  const int i_hi = (yy + pad_top) >> 1;
+  int i_lo = (yy + pad_top - 2 + 1) >> 1;  // ceil((yy + pad_top - 2) / 2)
+  if (yy + pad_top - 2 < 0) i_lo = 0;
+  for (int i = i_lo; i <= i_hi; ++i) {
+    if (i >= Ho || j >= Wo) continue;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int dyy = 0; dyy < 3; ++dyy)
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        const int y2 = 2 * i - pad_top + dyy, x2 = 2 * j - pad_left + dxx;
+        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
+          const float4 t = yp[(int64_t)(y2 + R) * WP + x2];
+          mx[0] = fmaxf(mx[0], t.x); mx[1] = fmaxf(mx[1], t.y); mx[2] = fmaxf(mx[2], t.z); mx[3] = fmaxf(mx[3], t.w);
+        }
+      }
+    const float4 d = dp[(int64_t)(i + R) * WPo + j];
+    if (mv[0] == mx[0]) g[0] += d.x;
+    if (mv[1] == mx[1]) g[1] += d.y;
+    if (mv[2] == mx[2]) g[2] += d.z;
+    if (mv[3] == mx[3]) g[3] += d.w;
+  }
+  reinterpret_cast<float4*>(dy)[bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx] = make_float4(g[0], g[1], g[2], g[3]);
+}
+
+// ---------------------------------------------------------------- D[ca][cb] += sum_pixels A[ca][p] * Bq[cb][p]
+// (pointwise / residual weight gradients).  256 pixels per pass go through LDS as [channel][pixel] (pitch 258: the
+// 16 channel rows x 2 pixels of a half-wave hit 32 distinct banks), then MFMA with k = pixel.
+// a_mode 1: A is sampled at pixel (2i, 2j) of planes (Ha, Wa) for each pixel (i, j) of the Bq planes (stride-2 1x1 conv).
+constexpr int OR_P = 258;
+
+__global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ A, int Ca, const float* __restrict__ Bq, int Cb, int H, int W, int WP, int R,
+                                                            int B, int a_mode, int Ha, int WPa, float* __restrict__ D /*[Ca][Cb]*/, uint32_t magic_WP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int CQa = (Ca + 3) >> 2, CQb = (Cb + 3) >> 2;
+  const int MT = (Ca + 15) >> 4, NT = (Cb + 15) >> 4, ntile = MT * NT;
+  float* As = smem;                    // [MT*16][OR_P]  (rows past CQa*4 stay zero)
+  float* Bs = smem + MT * 16 * OR_P;   // [NT*16][OR_P]
+  for (int i = threadIdx.x; i < (MT + NT) * 16 * OR_P; i += 256) smem[i] = 0.0f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int64_t plane_a = a_mode ? (int64_t)(Ha + 2 * R) * WPa : plane;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int chunks_per_plane = (plane + 255) >> 8;
+  const int64_t nchunks = (int64_t)B * chunks_per_plane;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t b = ch / chunks_per_plane;
+    const int p = (int)(ch - b * chunks_per_plane) * 256 + tid;  // this thread's pixel
+    const bool pin = p < plane;
+    int pa = p;
+    bool ain = pin;
+    if (a_mode) {
+      const int row = (int)__umulhi((uint32_t)(pin ? p : 0), magic_WP);
+      const int x = p - row * WP, i = row - R;
+      ain = pin && i >= 0 && i < H && x < W;
+      pa = ain ? (2 * i + R) * WPa + 2 * x : 0;
+    }
+    __syncthreads();
+    for (int q = 0; q < CQa; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ain) v = reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa];
+      As[(4 * q + 0) * OR_P + tid] = v.x; As[(4 * q + 1) * OR_P + tid] = v.y; As[(4 * q + 2) * OR_P + tid] = v.z; As[(4 * q + 3) * OR_P + tid] = v.w;
+    }
+    for (int q = 0; q < CQb; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pin) v = reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p];
+      Bs[(4 * q + 0) * OR_P + tid] = v.x; Bs[(4 * q + 1) * OR_P + tid] = v.y; Bs[(4 * q + 2) * OR_P + tid] = v.z; Bs[(4 * q + 3) * OR_P + tid] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int tile = wave + 4 * ti;
+      if (tile < ntile) {  // wave-uniform
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const float* ar = As + (mt * 16 + lj) * OR_P + lk;
+        const float* br = Bs + (nt * 16 + lj) * OR_P + lk;
+        f32x4 c = acc[ti];
+        for (int s = 0; s < 64; ++s) c = mfma16(ar[4 * s], br[4 * s], c);  // A[i = ca][k = pixel], B[k = pixel][j = cb]
+        acc[ti] = c;
+      }
+    }
+  }
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int tile = wave + 4 * ti;
+    if (tile < ntile) {
+      const int mt = tile / NT, nt = tile - mt * NT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
+        if (ca < Ca && cb < Cb) atomicAdd(&D[ca * Cb + cb], acc[ti][r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- depthwise weight gradient
+// dW[c][tap] += sum_p r[c][p + off(tap)] * du[c][p]   with r = relu_in ? relu(x) : x.  One wave = 64-pixel windows of one
+// (snippet, quad); lanes R..63-R contribute; 4 x k x k accumulators per lane, wave-reduced once at the end.
+template <int KS, int SH>
+__device__ __forceinline__ float lsh(float v) {
+  if constexpr (SH == 0) return v;
+  else if constexpr (SH < 0) return __shfl_up(v, -SH, 64);
+  else return __shfl_down(v, SH, 64);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int RP, int relu_in,
+                                                        float* __restrict__ dW /*[CQ*4][KS*KS]*/, int tasks, int tasks_per_wave) {
+  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int cq = blockIdx.y, b = blockIdx.z;
+  const int CQ = (C + 3) >> 2;
+  const int plane = (H + 2 * RP) * WP;
+  const float4* xp = reinterpret_cast<const float4*>(x) + ((int64_t)b * CQ + cq) * plane;
+  const float4* dp = reinterpret_cast<const float4*>(du) + ((int64_t)b * CQ + cq) * plane;
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const bool contributes = lane >= R && lane < 64 - R;
+  for (int task = wv * tasks_per_wave; task < (wv + 1) * tasks_per_wave && task < tasks; ++task) {
+    const int q = RP * WP + task * VAL - R + lane;
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (contributes && q < plane) g4 = dp[q];
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      int i = q + (dy - R) * WP;
+      i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+      const float4 a4 = xp[i];
+      float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (relu_in) a[j] = fmaxf(a[j], 0.0f);
+        if constexpr (KS == 3) {
+          acc[j][dy * 3 + 0] = fmaf(lsh<KS, -1>(a[j]), g[j], acc[j][dy * 3 + 0]);
+          acc[j][dy * 3 + 1] = fmaf(a[j], g[j], acc[j][dy * 3 + 1]);
+          acc[j][dy * 3 + 2] = fmaf(lsh<KS, 1>(a[j]), g[j], acc[j][dy * 3 + 2]);
+        } else if constexpr (KS == 5) {
+          acc[j][dy * 5 + 0] = fmaf(lsh<KS, -2>(a[j]), g[j], acc[j][dy * 5 + 0]);
+          acc[j][dy * 5 + 1] = fmaf(lsh<KS, -1>(a[j]), g[j], acc[j][dy * 5 + 1]);
+          acc[j][dy * 5 + 2] = fmaf(a[j], g[j], acc[j][dy * 5 + 2]);
+          acc[j][dy * 5 + 3] = fmaf(lsh<KS, 1>(a[j]), g[j], acc[j][dy * 5 + 3]);
+          acc[j][dy * 5 + 4] = fmaf(lsh<KS, 2>(a[j]), g[j], acc[j][dy * 5 + 4]);
+        } else {
+          acc[j][dy * 7 + 0] = fmaf(lsh<KS, -3>(a[j]), g[j], acc[j][dy * 7 + 0]);
+          acc[j][dy * 7 + 1] = fmaf(lsh<KS, -2>(a[j]), g[j], acc[j][dy * 7 + 1]);
+          acc[j][dy * 7 + 2] = fmaf(lsh<KS, -1>(a[j]), g[j], acc[j][dy * 7 + 2]);
+          acc[j][dy * 7 + 3] = fmaf(a[j], g[j], acc[j][dy * 7 + 3]);
+          acc[j][dy * 7 + 4] = fmaf(lsh<KS, 1>(a[j]), g[j], acc[j][dy * 7 + 4]);
+          acc[j][dy * 7 + 5] = fmaf(lsh<KS, 2>(a[j]), g[j], acc[j][dy * 7 + 5]);
+          acc[j][dy * 7 + 6] = fmaf(lsh<KS, 3>(a[j]), g[j], acc[j][dy * 7 + 6]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0 && cq * 4 + j < C) atomicAdd(&dW[(cq * 4 + j) * KK + t], v);
+    }
+}
+
+// ---------------------------------------------------------------- conv0 weight gradient
+// dW0[tap][c] += sum_p in[p + off(tap)] * dv0[c][p]; the single-channel input is the UNPADDED snippet image.
+template <int KS>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ in, int64_t snippet_stride, const float* __restrict__ dv /*[B][4][HP][WP][4]*/,
+                                                           int H, int W, int WP, float* __restrict__ dW /*[KS*KS][16]*/) {
+  constexpr int R = KS / 2, KK = KS * KS;
+  const int lane = threadIdx.x & 63;
+  const int cq = blockIdx.y, b = blockIdx.z;
+  const int plane = (H + 2 * R) * WP;
+  const float* src = in + (int64_t)b * snippet_stride;
+  const float4* dp = reinterpret_cast<const float4*>(dv) + ((int64_t)b * 4 + cq) * plane;
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const int64_t total = (int64_t)H * W;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+    const float4 g4 = dp[(int64_t)(y + R) * WP + x];
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const int yy = y + dy - R, xx = x + dx - R;
+        const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(int64_t)yy * W + xx] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][dy * KS + dx] = fmaf(a, g[j], acc[j][dy * KS + dx]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) atomicAdd(&dW[t * 16 + cq * 4 + j], v);
+    }
+}
+
+// ---------------------------------------------------------------- Keras Reshape layout [B][H][W*C] -> planes (gradient of the final conv)
+__global__ __launch_bounds__(256) void feat_to_planes_kernel(const float* __restrict__ f, int C, int H, int W, int WP, int R, float* __restrict__ out, int B) {
+  const int CQ = (C + 3) >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t interior = (int64_t)H * W;
+  if (idx >= (int64_t)B * CQ * interior) return;
+  const int64_t bq = idx / interior, pix = idx - bq * interior;
+  const int cq = (int)(bq % CQ);
+  const int64_t b = bq / CQ;
+  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  const float* src = f + ((b * H + yy) * (int64_t)W + xx) * C + cq * 4;
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (cq * 4 + k < C) ? src[k] : 0.0f;
+  reinterpret_cast<float4*>(out)[bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// elementwise on whole plane buffers: dx = (y > 0) ? dy : 0   /  x += y
+__global__ __launch_bounds__(256) void relu_bwd4_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, int64_t n4, float4* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 d = dy[i], v = y[i];
+  dx[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize, double* scratch2C, float* mean, float* var, void* stream) {
+  if (!v || !scratch2C || !mean || !var || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(planes_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, v, CQ, plane, B, scratch2C, scratch2C + 4 * CQ);
+  hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, scratch2C + 4 * CQ, C, (double)B * H * W, mean, var);
+  return (int)hipGetLastError();
+}
+
+int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratchC, float* out, int accumulate, void* stream) {
+  if (!x || !scratchC || !out || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 4 * CQ, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(planes_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, x, CQ, plane, B, scratchC, (double*)nullptr);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratchC, out, C, accumulate);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
+                          float eps, int relu, float* y, void* stream) {
+  if (!v || !y || !mean || !var || !gamma || !beta || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  const int64_t n = (int64_t)B * ((C + 3) / 4) * H * W;
+  hipLaunchKernelGGL(bn_planes_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, v, C, H, W, orcai_padded_width(W, ksize), ksize / 2, mean, var,
+                     gamma, beta, eps, relu, y, B);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                        const float* beta, float eps, int relu, double* scratch2C, float* dbeta, float* dgamma, float* dv, void* stream) {
+  if (!dy || !v || !dv || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 512) gx = 512;
+  double* db = scratch2C;
+  double* dg = scratch2C + 4 * CQ;
+  hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  const int64_t n = (int64_t)B * CQ * H * W;
+  hipLaunchKernelGGL(bn_planes_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, v, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg,
+                     (double)B * H * W, dv, B);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  return (int)hipGetLastError();
+}
+
+int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream) {
+  if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
+  if (tot_h < 0) tot_h = 0;
+  if (tot_w < 0) tot_w = 0;
+  const int64_t n = (int64_t)B * ((C + 3) / 4) * H * W;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B);
+  return (int)hipGetLastError();
+}
+
+int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, void* stream) {
+  if (!A || !Bq || !D || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
+  const int CQa = (Ca + 3) / 4, CQb = (Cb + 3) / 4;
+  (void)CQa; (void)CQb;
+  const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * OR_P * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)outer_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
+  const int plane = (H + 2 * R) * WP;
+  int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
+  int grid = (int)(nchunks < 512 ? nchunks : 512);
+  hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
+                     a_stride2 ? orcai_padded_width(Wa, ksize) : 0, D, magic_for(WP));
+  return (int)hipGetLastError();
+}
+
+int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {
+  if (!x || !du || !dW || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
+  const int VAL = 64 - 2 * (ktap / 2);
+  const int tasks = (H * WP + VAL - 1) / VAL;
+  const int tpw = 8;
+  dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, (C + 3) / 4, B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (ktap) {
+    case 3: hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 5: hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 7: hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream) {
+  if (!in || !dv || !dW || B <= 0) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, ksize);
+  dim3 grid(32, 4, B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_wgrad_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
+    case 5: hipLaunchKernelGGL(conv0_wgrad_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
+    case 7: hipLaunchKernelGGL(conv0_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, float* out, void* stream) {
+  if (!f || !out || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  const int64_t n = (int64_t)B * ((C + 3) / 4) * H * W;
+  hipLaunchKernelGGL(feat_to_planes_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, f, C, H, W, orcai_padded_width(W, ksize), ksize / 2, out, B);
+  return (int)hipGetLastError();
+}
+
+int orcai_planes_relu_bwd(const float* dy, const float* y, int64_t n_floats, float* dx, void* stream) {
+  if (!dy || !y || !dx || n_floats <= 0 || (n_floats & 3)) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(relu_bwd4_kernel, dim3(blocks_for(n_floats / 4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)y, n_floats / 4,
+                     (float4*)dx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -219,3 +219,243 @@ class HeadTrainer:
 def adam_step(params: FlatParams, lr: float, step: int, gscale: float = 1.0, b1=0.9, b2=0.999, eps=1e-7) -> None:
     N.check(N.lib().orcai_adam_step(params.w.data_ptr(), params.g.data_ptr(), params.m.data_ptr(), params.v.data_ptr(), params.n_trainable, lr, b1, b2, eps, step,
                                     gscale, N.stream_ptr()), "orcai_adam_step")
+
+
+class TrunkTrainer:
+    """Training forward / backward of the convolutional trunk on padded channel-quad planes.  The forward stores, per
+    BatchNorm, the pre-normalisation tensor v and the batch statistics, and materialises y = [relu](BN(v)); the backward
+    walks the layers in reverse with the kernels of csrc/train_trunk.hip (correctness first: u = dw(relu(x)) is
+    re-materialised for the pointwise weight gradient, and depthwise-only / pointwise-only passes reuse the
+    separable-conv kernel with identity factors)."""
+
+    def __init__(self, model: ResNetLSTM, params: FlatParams):
+        self.model, self.P = model, params
+        self.lib = N.lib()
+        self.k = model.kernel_size
+        self.R = self.k // 2
+        self.dev = params.w.device
+        self.buf = {}
+        self.B = None
+        self.consts = {}
+        self.scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad, <= 64 channels
+
+    # ------------------------------------------------------------- helpers
+    def _planes(self, B, c, h, w):
+        return torch.zeros((B, (c + 3) // 4, h + 2 * self.R, self.model.padded_width(w), 4), dtype=torch.float32, device=self.dev)
+
+    def _const(self, key, make):
+        if key not in self.consts:
+            self.consts[key] = make()
+        return self.consts[key]
+
+    def _ones(self, n):
+        return self._const(("ones", n), lambda: torch.ones(n, dtype=torch.float32, device=self.dev))
+
+    def _zeros(self, n):
+        return self._const(("zeros", n), lambda: torch.zeros(n, dtype=torch.float32, device=self.dev))
+
+    def _eye(self, c):
+        return self._const(("eye", c), lambda: torch.eye(c, dtype=torch.float32, device=self.dev).contiguous())
+
+    def _dw_kernel_layout(self, name):
+        """Keras depthwise (k,k,c,1) -> [4*ceil(c/4)][k*k] (zero rows for the padding channels)."""
+        w = self.P.W(name)
+        c = w.shape[2]
+        out = torch.zeros((4 * ((c + 3) // 4), self.k * self.k), dtype=torch.float32, device=self.dev)
+        out[:c] = w[:, :, :, 0].permute(2, 0, 1).reshape(c, self.k * self.k)
+        return out
+
+    def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0):
+        N.check(self.lib.orcai_sepconv_planes(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
+                                              shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), N.stream_ptr()), "orcai_sepconv_planes")
+
+    def _bn_fwd(self, v, bn, C, H, W, relu, y):
+        lib, P, st = self.lib, self.P, N.stream_ptr()
+        mean = torch.empty(C, dtype=torch.float32, device=self.dev)
+        var = torch.empty(C, dtype=torch.float32, device=self.dev)
+        N.check(lib.orcai_bn_planes_stats(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
+        N.check(lib.orcai_bn_planes_apply(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                          P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), st), "bn_planes_apply")
+        self.stats[bn] = (mean, var)
+
+    def _bn_bwd(self, dy, v, bn, C, H, W, relu, dv):
+        lib, P, st = self.lib, self.P, N.stream_ptr()
+        mean, var = self.stats[bn]
+        N.check(lib.orcai_bn_planes_bwd(dy.data_ptr(), v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                        P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), P.G(bn + "/beta").data_ptr(),
+                                        P.G(bn + "/gamma").data_ptr(), dv.data_ptr(), st), "bn_planes_bwd")
+
+    def _alloc(self, B):
+        if self.B == B:
+            return
+        self.B = B
+        m = self.model
+        shapes = m.stage_shapes()
+        b = {}
+        h, w, _ = shapes[0]
+        b["v0"], b["y0"] = self._planes(B, 16, h, w), self._planes(B, 16, h, w)
+        for i, f in enumerate(m.filters, start=1):
+            h, w, cprev = shapes[i - 1]
+            for n in ("va", "ya", "vb", "yb"):
+                b[f"{n}{i}"] = self._planes(B, f, h, w)
+            b[f"u_a{i}"], b[f"du_a{i}"] = self._planes(B, cprev, h, w), self._planes(B, cprev, h, w)  # depthwise output / its gradient (sep_a)
+            b[f"u_b{i}"], b[f"du_b{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w)
+            b[f"prev{i}"] = self._planes(B, f, shapes[i][0], shapes[i][1])
+        h, w, c = shapes[-1]
+        b["u_f"], b["du_f"] = self._planes(B, c, h, w), self._planes(B, c, h, w)
+        b["dvf"] = self._planes(B, FINAL_FILTERS, h, w)
+        self.buf = b
+
+    # ------------------------------------------------------------- forward
+    def forward(self, src: torch.Tensor, snippet_stride: int, B: int) -> torch.Tensor:
+        """src: flat f32 cuda tensor, snippet i = [H][W] at element offset i*snippet_stride.  Returns featv [B][T][W_last*36]
+        (pre-BN output of the final separable conv)."""
+        self._alloc(B)
+        lib, P, m, b, st = self.lib, self.P, self.model, self.buf, N.stream_ptr()
+        self.stats = {}
+        self.src, self.snippet_stride = src, snippet_stride
+        H, W = m.input_hw
+        k = self.k
+        shapes = m.stage_shapes()
+        N.check(lib.orcai_conv0_affine(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                       0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
+        self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+        prev, c = b["y0"], 16
+        self.dwl = {}
+        for i, f in enumerate(m.filters, start=1):
+            h, w, _ = shapes[i - 1]
+            for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], b[f"yb{i}"], 0)):
+                name = f"b{i}/sep_{tag}"
+                self.dwl[name] = self._dw_kernel_layout(name + "/depthwise")
+                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v)
+                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y)
+            N.check(lib.orcai_pool_res_add(b[f"yb{i}"].data_ptr(), prev.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(), P.W(f"b{i}/res/bias").data_ptr(),
+                                           b[f"prev{i}"].data_ptr(), 0, st), "orcai_pool_res_add")
+            prev, c = b[f"prev{i}"], f
+        h, w, _ = shapes[-1]
+        self.dwl["sep_f"] = self._dw_kernel_layout("sep_f/depthwise")
+        featv = torch.empty((B, h, w * FINAL_FILTERS), dtype=torch.float32, device=self.dev)
+        self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1)
+        return featv
+
+    def update_moving_stats(self) -> None:
+        S = self.P.stats
+        for bn, (mean, var) in self.stats.items():
+            S[bn + "/mean"].mul_(BN_MOMENTUM).add_(mean, alpha=1 - BN_MOMENTUM)
+            S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
+
+    # ------------------------------------------------------------- backward
+    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr):
+        """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
+        (ReLU'd) input into `dr` (planes of Cin channels)."""
+        lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
+        dwl = self.dwl[name]
+        N.check(lib.orcai_planes_sum(dv.data_ptr(), self.B, Cout, H, W, k, self.scratch.data_ptr(), P.G(name + "/bias").data_ptr(), 0, st), "planes_sum")
+        # u = dw(relu?(x))   (identity pointwise)
+        self._sep(x, Cin, H, W, k, relu_in, dwl, self._eye(Cin), self._zeros(64), Cin, u)
+        N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), st), "outer_reduce")
+        # du = Wpw dv   (pointwise conv with the transposed weights)
+        wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
+        self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
+        dwg = torch.zeros_like(dwl)
+        N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, dwg.data_ptr(), st), "dw_wgrad")
+        P.G(name + "/depthwise").copy_(dwg[:Cin].reshape(Cin, k, k).permute(1, 2, 0).unsqueeze(3))
+        # dr = depthwise conv of du with the flipped taps (identity pointwise)
+        flipped = dwl.reshape(-1, k, k).flip(1, 2).reshape(-1, k * k).contiguous()
+        self._sep(du, Cin, H, W, k, 0, flipped, self._eye(Cin), self._zeros(64), Cin, dr)
+
+    def backward(self, dfeatv: torch.Tensor) -> None:
+        """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
+        lib, P, m, b, st, k, B = self.lib, self.P, self.model, self.buf, N.stream_ptr(), self.k, self.B
+        shapes = m.stage_shapes()
+        L = len(m.filters)
+        h, w, c = shapes[-1]
+        N.check(lib.orcai_feat_to_planes(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
+        dprev = self._planes(B, c, h, w)
+        self._sep_backward("sep_f", b[f"prev{L}"], 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
+        for i in range(L, 0, -1):
+            f = m.filters[i - 1]
+            h, w, cprev = shapes[i - 1]
+            ho, wo, _ = shapes[i]
+            prev = b[f"prev{i - 1}"] if i > 1 else b["y0"]
+            dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
+            # residual 1x1 stride-2 conv: weight / bias gradients
+            N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(), st), "outer_reduce")
+            N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
+            # max-pool branch
+            dyb = self._planes(B, f, h, w)
+            N.check(lib.orcai_pool_bwd(dout.data_ptr(), b[f"yb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), st), "pool_bwd")
+            dvb = dyb  # in place
+            self._bn_bwd(dyb, b[f"vb{i}"], f"b{i}/bn_b", f, h, w, 0, dvb)
+            dya = self._planes(B, f, h, w)
+            self._sep_backward(f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, dvb, b[f"u_b{i}"], b[f"du_b{i}"], dya)
+            dva = dya
+            self._bn_bwd(dya, b[f"va{i}"], f"b{i}/bn_a", f, h, w, 1, dva)
+            dr = self._planes(B, cprev, h, w)
+            self._sep_backward(f"b{i}/sep_a", prev, 1, cprev, f, h, w, dva, b[f"u_a{i}"], b[f"du_a{i}"], dr)
+            # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
+            N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), prev.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
+            wrt = P.W(f"b{i}/res/kernel")[0, 0].t().contiguous()  # [f][cprev]
+            self._sep(dout, f, ho, wo, 1, 0, self._ones(4 * ((f + 3) // 4)), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
+            dprev = dr
+        H, W = m.input_hw
+        dv0 = dprev
+        self._bn_bwd(dprev, b["v0"], "bn0", 16, H, W, 1, dv0)
+        N.check(lib.orcai_conv0_wgrad(self.src.data_ptr(), self.snippet_stride, dv0.data_ptr(), B, H, W, k, P.G("conv0/kernel").data_ptr(), st), "conv0_wgrad")
+        N.check(lib.orcai_planes_sum(dv0.data_ptr(), B, 16, H, W, k, self.scratch.data_ptr(), P.G("conv0/bias").data_ptr(), 0, st), "planes_sum")
+
+
+class Trainer:
+    """One optimisation step = forward (training mode) + masked BCE + L2 + backward + (all-reduce) + Adam."""
+
+    def __init__(self, model: ResNetLSTM, learning_rate: float = 1e-4, seed: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("orcai_amd training needs a ROCm GPU: there is no CPU / autograd fallback")
+        self.model = model
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.P = FlatParams(model, self.dev)
+        self.trunk = TrunkTrainer(model, self.P)
+        self.head = HeadTrainer(model, self.P)
+        self.lr = float(learning_rate)
+        self.step_count = 0
+        self.seed = int(seed)
+
+    def _masks(self, n, T):
+        rate = self.model.dropout_rate
+        if rate <= 0.0:
+            return None
+        lib, st = N.lib(), N.stream_ptr()
+        out = {}
+        for j, d in (("drop1", 2 * self.model.lstm_units), ("drop2", 2 * self.model.lstm_units), ("drop3", DENSE_UNITS)):
+            mk = torch.empty((n, T, d), dtype=torch.float32, device=self.dev)
+            seed = (self.seed * 1000003 + self.step_count * 3 + int(j[-1])) & 0xFFFFFFFFFFFFFFFF
+            N.check(lib.orcai_dropout_mask(mk.data_ptr(), mk.numel(), seed, 1.0 - rate, st), "dropout_mask")
+            out[j] = mk
+        return out
+
+    def forward_backward(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor, masks: dict | None = "auto") -> dict:
+        """Gradients of (masked BCE + L2) into the flat gradient buffer.  Returns device accumulators {bce sum, count, correct, l2}."""
+        self.P.g.zero_()
+        featv = self.trunk.forward(src, snippet_stride, B)
+        if isinstance(masks, str):
+            masks = self._masks(B, featv.shape[1])
+        probs = self.head.forward(featv, masks, self.model.dropout_rate)
+        out = self.head.loss_and_backward(labels)
+        self.trunk.backward(out["dfeatv"])
+        return {"acc": out["acc"], "probs": probs}
+
+    def apply(self, world_size: int = 1) -> None:
+        """(all-reduce) + Adam + BN moving statistics."""
+        if world_size > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.P.g, op=dist.ReduceOp.SUM)  # one flat bucket over RCCL
+        self.step_count += 1
+        adam_step(self.P, self.lr, self.step_count, gscale=1.0 / world_size)
+        self.trunk.update_moving_stats()
+        self.head.update_moving_stats()
+
+    def train_step(self, src, snippet_stride, B, labels, world_size: int = 1) -> dict:
+        out = self.forward_backward(src, snippet_stride, B, labels)
+        self.apply(world_size)
+        return out

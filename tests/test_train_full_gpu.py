@@ -1,0 +1,90 @@
+"""GPU parity of one full training step (forward in training mode, masked BCE + L2, backward through the whole ResNetLSTM)
+against torch autograd on the CPU oracle in float64, for small hyper-parameter variants, and of an Adam step.
+
+Tolerance: every gradient tensor max|delta| <= 5e-4 * max(1e-3, max|ref|): fp32 kernels (float atomics in the weight-gradient
+reductions) vs fp64 autograd; the bias gradients of convs that feed a BatchNorm are mathematically zero (BN removes the mean)
+and are compared on an absolute scale instead."""
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import model_ref as M  # noqa: E402
+from oracle import train_ref as T  # noqa: E402
+
+
+def _run(cfg, B, seed, rate=0.5):
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    p = M.calibrated_params(seed=seed, **cfg)
+    rng = np.random.default_rng(seed)
+    for k in p:
+        if k.endswith(("gamma", "beta")):
+            p[k] = (p[k] + 0.2 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    H, W, _ = cfg["input_shape"]
+    steps = H // 2 ** len(cfg["filters"])
+    L, u = cfg["num_labels"], cfg["lstm_units"]
+    x = rng.random((B, H, W, 1), dtype=np.float32)
+    y = (rng.random((B, steps, L)) > 0.5).astype(np.float32)
+    y[0, :, 0] = -1.0
+    masks = {k: (rng.random((B, steps, d)) > rate).astype(np.float32) for k, d in (("drop1", 2 * u), ("drop2", 2 * u), ("drop3", 128))}
+    ref = T.loss_and_grads(p, x, y, masks, rate)
+    model = ResNetLSTM(cfg["input_shape"], L, list(cfg["filters"]), cfg["kernel_size"], rate, u)
+    model.set_weights_dict(p)
+    tr = Trainer(model, learning_rate=1e-3)
+    xd = torch.from_numpy(np.ascontiguousarray(x[..., 0])).cuda().view(-1)
+    out = tr.forward_backward(xd, H * W, B, torch.from_numpy(y).cuda(), masks={k: torch.from_numpy(v).cuda() for k, v in masks.items()})
+    return ref, tr, out, p
+
+
+@pytest.mark.parametrize(
+    "cfg,B",
+    [
+        (dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=64, num_labels=3), 3),
+        (dict(input_shape=(48, 21, 1), filters=(12, 30, 40), kernel_size=3, lstm_units=64, num_labels=7), 2),
+        (dict(input_shape=(32, 16, 1), filters=(10, 20), kernel_size=5, lstm_units=64, num_labels=2), 2),
+    ],
+)
+def test_full_step_gradients_vs_autograd(cfg, B):
+    ref, tr, out, p = _run(cfg, B, seed=5)
+    acc = out["acc"].cpu().numpy()
+    assert np.abs(out["probs"].cpu().numpy() - ref["probs"]).max() <= 5e-6
+    assert abs(acc[0] / acc[1] - ref["bce"]) <= 2e-6 * max(1.0, abs(ref["bce"]))
+    assert abs(acc[0] / acc[1] + acc[3] - ref["loss"]) <= 2e-6 * max(1.0, abs(ref["loss"]))
+    bad = {}
+    for name, g in ref["grads"].items():
+        got = tr.P.G(name).cpu().numpy()
+        zero_mean_bias = name.endswith("/bias") and not name.startswith(("dense2", "lstm", "dense1")) and "res" not in name
+        scale = max(1e-3, float(np.abs(g).max())) if not zero_mean_bias else 1.0
+        err = float(np.abs(got - g).max()) / scale
+        if err > (5e-4 if not zero_mean_bias else 1e-4):
+            bad[name] = (err, float(np.abs(g).max()))
+    assert not bad, bad
+    tr.trunk.update_moving_stats()
+    tr.head.update_moving_stats()
+    for k, v in ref["new_stats"].items():
+        assert np.abs(tr.P.stats[k].cpu().numpy() - v).max() <= 2e-5 * max(1.0, float(np.abs(v).max())), k
+
+
+def test_training_reduces_loss_and_roundtrips_weights():
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    cfg = dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=64, num_labels=3)
+    rng = np.random.default_rng(0)
+    model = ResNetLSTM(cfg["input_shape"], 3, [10, 20], 3, 0.0, 64, seed=1)
+    tr = Trainer(model, learning_rate=3e-3)
+    x = rng.random((8, 32, 12), dtype=np.float32)
+    y = (x.reshape(8, 8, 4, 12).mean(axis=(2, 3), keepdims=False)[:, :, None] > 0.5).astype(np.float32).repeat(3, axis=2)
+    xd, yd = torch.from_numpy(x).cuda().view(-1), torch.from_numpy(y).cuda()
+    losses = []
+    for _ in range(30):
+        out = tr.train_step(xd, 32 * 12, 8, yd)
+        a = out["acc"].cpu().numpy()
+        losses.append(a[0] / a[1])
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::5]
+    tr.P.to_model(model)
+    assert np.isfinite(model.predict(x[..., None])).all()
