@@ -383,6 +383,28 @@ class ResNetLSTM:
             self.forward_device(spectrogram.view(-1), shift * W, n, out, chunk=chunk)
         return out
 
+    # ------------------------------------------------------------------ keras-shaped training API (train.py:155-219)
+    def compile(self, optimizer=None, loss=None, metrics=None, learning_rate: float | None = None, seed: int = 0) -> None:
+        """``optimizer`` may be a number (learning rate) or an object with ``learning_rate``; the loss / metric are always
+        MaskedBinaryCrossentropy / MaskedBinaryAccuracy (the only ones the reference compiles with)."""
+        from orcai_amd.fit import FitLoop
+        from orcai_amd.training import Trainer
+
+        lr = learning_rate if learning_rate is not None else (optimizer if isinstance(optimizer, (int, float)) else getattr(optimizer, "learning_rate", 1e-4))
+        self._loop = FitLoop(self, Trainer(self, learning_rate=float(lr), seed=seed))
+
+    def _need_loop(self):
+        if getattr(self, "_loop", None) is None:
+            self.compile()
+        return self._loop
+
+    def fit(self, train_dataset, validation_data=None, epochs: int = 1, callbacks=(), class_weight=None, verbose: int = 0):
+        return self._need_loop().fit(train_dataset, validation_data, epochs, callbacks, class_weight, verbose)
+
+    def evaluate(self, dataset, return_dict: bool = True, verbose: int = 0):
+        logs = self._need_loop().evaluate(dataset)
+        return logs if return_dict else [logs["loss"], logs["MBA"]]
+
     def predict(self, snippets, batch_size: int = 64, verbose: int = 0, **unused) -> np.ndarray:
         """keras.Model.predict for materialised snippets: ndarray [n, H, W, 1] -> ndarray [n, steps, labels] (float32)."""
         x = np.asarray(snippets, dtype=np.float32)

@@ -1,0 +1,159 @@
+"""Keras-shaped training loop for ResNetLSTM: compile / fit / evaluate, History, and the three callbacks the reference
+uses (train.py:155-219): EarlyStopping, ModelCheckpoint, ReduceLROnPlateau.  Host logic only -- every number comes
+from the HIP kernels driven by orcai_amd.training.Trainer."""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from orcai_amd import _native as N
+from orcai_amd import parallel
+from orcai_amd.training import L2_LAMBDA, MASK_VALUE, Trainer
+
+
+class History:
+    def __init__(self):
+        self.history: dict[str, list] = {}
+
+    def add(self, logs: dict) -> None:
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(float(v))
+
+
+class Callback:
+    def on_train_begin(self, loop): ...
+    def on_epoch_end(self, loop, epoch: int, logs: dict): ...
+    def on_train_end(self, loop): ...
+
+
+def _better(a, b, mode):
+    return a > b if mode == "max" else a < b
+
+
+class EarlyStopping(Callback):
+    """keras.callbacks.EarlyStopping(monitor, patience, mode, restore_best_weights) (train.py:165-171)."""
+
+    def __init__(self, monitor="val_MBA", patience=10, mode="max", restore_best_weights=True, verbose=0):
+        self.monitor, self.patience, self.mode, self.restore = monitor, patience, mode, restore_best_weights
+        self.best, self.wait, self.best_state, self.stopped_epoch = None, 0, None, None
+
+    def on_epoch_end(self, loop, epoch, logs):
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return
+        if self.best is None or _better(cur, self.best, self.mode):
+            self.best, self.wait = cur, 0
+            if self.restore:
+                self.best_state = loop.trainer.state_dict()
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                loop.stop_training = True
+                self.stopped_epoch = epoch
+
+    def on_train_end(self, loop):
+        if self.restore and self.best_state is not None and self.stopped_epoch is not None:
+            loop.trainer.load_state_dict(self.best_state)
+
+
+class ModelCheckpoint(Callback):
+    """keras.callbacks.ModelCheckpoint(path, monitor, save_best_only=True) (train.py:172-177).  The reference leaves mode="auto",
+    which Keras resolves to "min" for a monitor named val_MBA; the monitor is an accuracy, so "max" is used."""
+
+    def __init__(self, filepath, monitor="val_MBA", save_best_only=True, mode="max", verbose=0):
+        self.filepath, self.monitor, self.best_only, self.mode, self.best = Path(filepath), monitor, save_best_only, mode, None
+
+    def on_epoch_end(self, loop, epoch, logs):
+        cur = logs.get(self.monitor)
+        if not self.best_only or cur is None or self.best is None or _better(cur, self.best, self.mode):
+            self.best = cur if cur is not None else self.best
+            if parallel.world()[0] == 0:
+                loop.trainer.sync_model()
+                self.filepath.parent.mkdir(parents=True, exist_ok=True)
+                loop.model.save(self.filepath)
+
+
+class ReduceLROnPlateau(Callback):
+    """keras.callbacks.ReduceLROnPlateau(monitor, factor, patience, min_lr) (train.py:178-184), mode "max" (see ModelCheckpoint)."""
+
+    def __init__(self, monitor="val_MBA", factor=0.5, patience=3, min_lr=1e-7, mode="max", verbose=0):
+        self.monitor, self.factor, self.patience, self.min_lr, self.mode = monitor, factor, patience, min_lr, mode
+        self.best, self.wait = None, 0
+
+    def on_epoch_end(self, loop, epoch, logs):
+        cur = logs.get(self.monitor)
+        logs["learning_rate"] = loop.trainer.lr
+        if cur is None:
+            return
+        if self.best is None or _better(cur, self.best, self.mode):
+            self.best, self.wait = cur, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                loop.trainer.lr = max(loop.trainer.lr * self.factor, self.min_lr)
+                self.wait = 0
+
+
+def _epoch_logs(acc: np.ndarray, prefix: str = "") -> dict:
+    """acc = {sum of BCE, unmasked count, correct count, l2}: Keras reports loss = mean BCE + regularisation, MBA = accuracy."""
+    n = max(acc[1], 1.0)
+    return {prefix + "loss": acc[0] / n + acc[3], prefix + "MBA": acc[2] / n}
+
+
+class FitLoop:
+    def __init__(self, model, trainer: Trainer):
+        self.model, self.trainer, self.stop_training = model, trainer, False
+
+    def evaluate(self, dataset) -> dict:
+        """Inference-mode pass (moving BN statistics, no dropout): mean masked BCE + L2 and masked binary accuracy."""
+        self.trainer.sync_model()
+        m, lib = self.model, N.lib()
+        H, W = m.input_hw
+        tot = torch.zeros(4, dtype=torch.float64, device=self.trainer.dev)
+        acc = torch.zeros(3, dtype=torch.float64, device=self.trainer.dev)
+        for xb, yb in dataset:
+            B = xb.shape[0]
+            probs = torch.empty((B, m.out_steps, m.num_labels), dtype=torch.float32, device=xb.device)
+            m.forward_device(xb.contiguous().view(-1), H * W, B, probs, chunk=B)
+            N.check(lib.orcai_masked_bce(probs.data_ptr(), yb.contiguous().data_ptr(), probs.numel(), MASK_VALUE, acc.data_ptr(), None, N.stream_ptr()), "masked_bce")
+            tot[:3] += acc
+        l2 = sum(float((m.weights[k].astype(np.float64) ** 2).sum()) for k in m.weights if k.endswith("/kernel") and (k.startswith("lstm") or k.startswith("dense1")))
+        a = tot.cpu().numpy()
+        a[3] = L2_LAMBDA * l2
+        if parallel.world()[1] > 1:
+            parts = parallel.gather_objects(a[:3].tolist())
+            a[:3] = np.sum(np.array(parts), axis=0)
+        return _epoch_logs(a)
+
+    def fit(self, train_dataset, validation_data=None, epochs=1, callbacks=(), class_weight=None, verbose=0) -> History:
+        if class_weight is not None:
+            raise NotImplementedError("class_weight (call_weights) is not implemented on the HIP training path")
+        hist = History()
+        m = self.model
+        H, W = m.input_hw
+        world = parallel.world()[1]
+        for cb in callbacks:
+            cb.on_train_begin(self)
+        for epoch in range(epochs):
+            tot = torch.zeros(4, dtype=torch.float64, device=self.trainer.dev)
+            for xb, yb in train_dataset:
+                out = self.trainer.train_step(xb.contiguous().view(-1), H * W, xb.shape[0], yb, world_size=world)
+                tot[:3] += out["acc"][:3]
+                tot[3] = out["acc"][3]
+            logs = _epoch_logs(tot.cpu().numpy())
+            if validation_data is not None:
+                logs.update({"val_" + k: v for k, v in self.evaluate(validation_data).items()})
+            for cb in callbacks:
+                cb.on_epoch_end(self, epoch, logs)
+            hist.add(logs)
+            if verbose:
+                print(f"epoch {epoch + 1}/{epochs}: " + "  ".join(f"{k} {v:.4f}" for k, v in logs.items()), flush=True)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end(self)
+        self.trainer.sync_model()
+        return hist

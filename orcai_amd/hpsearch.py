@@ -1,14 +1,120 @@
-"""Hyperparameter search entry point.  Mirrors reference ``src/orcAI/hpsearch.py:110-257``.
-
-NOT BUILT YET: depends on the training path."""
+"""Hyperparameter search.  Same entry point and outputs as the reference's ``src/orcAI/hpsearch.py:110-257``
+(``<output_dir>/hps_logs/{best_hyperparameters.json, all_trials.csv}``).  keras_tuner is absent, so the Hyperband
+schedule (max_epochs 10, factor 3, objective = monitor, direction max; hpsearch.py:189-234) is restated as host logic:
+successive-halving brackets over seeded random draws from the choice lists of the hps parameter file
+(``_hp_model_builder``, hpsearch.py:21-85).  Each trial trains with the HIP training path; with ``parallel`` every
+trial is data parallel over all ranks (what MirroredStrategy does in the reference).
+"""
 
 from __future__ import annotations
 
+import copy
+import math
+from importlib.resources import files
 from pathlib import Path
 
-from orcai_amd.auxiliary import Messenger
+import numpy as np
+import pandas as pd
+
+from orcai_amd.architectures import build_model
+from orcai_amd.auxiliary import SEED_ID_LOAD_TEST_DATA, SEED_ID_LOAD_VAL_DATA, Messenger
+from orcai_amd.datasets import load_dataset
+from orcai_amd.fit import EarlyStopping
+from orcai_amd.io import read_json, write_json
+
+DEFAULT_ORCAI_PARAMETER = files("orcai_amd.defaults").joinpath("default_orcai_parameter.json")
+DEFAULT_HPS_PARAMETER = files("orcai_amd.defaults").joinpath("default_hps_parameter.json")
+MAX_EPOCHS, FACTOR = 10, 3
 
 
-def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_parameter=None, hps_parameter=None, parallel: bool = False,
-                          data_compression: str | None = "GZIP", verbosity: int = 2, msgr: Messenger | None = None) -> None:
-    raise NotImplementedError("orcai_amd.hpsearch: needs the HIP training path, which is not built yet")
+def _draw(rng, hps_parameter: dict, orcai_parameter: dict) -> dict:
+    """One configuration: a Choice per hyper-parameter (hpsearch.py:54-83)."""
+    hp = {"filters": str(rng.choice(list(hps_parameter["filters"].keys()))), "kernel_size": int(rng.choice(hps_parameter["kernel_size"])),
+          "dropout_rate": float(rng.choice(hps_parameter["dropout_rate"])), "batch_size": int(rng.choice(hps_parameter["batch_size"]))}
+    if "lstm_units" in orcai_parameter["model"]:
+        if "lstm_units" not in hps_parameter:
+            raise ValueError("LSTM units not in hyperparameter search parameter. Is the right model specified?")
+        hp["lstm_units"] = int(rng.choice(hps_parameter["lstm_units"]))
+    elif "lstm_units" in hps_parameter:
+        raise ValueError("LSTM units not in model parameter. Is the right model specified?")
+    return hp
+
+
+def _apply(hp: dict, orcai_parameter: dict, hps_parameter: dict) -> dict:
+    p = copy.deepcopy(orcai_parameter)
+    p["model"]["filters"] = hps_parameter["filters"][hp["filters"]]
+    for k in ("kernel_size", "dropout_rate", "batch_size", "lstm_units"):
+        if k in hp:
+            p["model"][k] = hp[k]
+    return p
+
+
+def hyperband_brackets(max_epochs: int = MAX_EPOCHS, factor: int = FACTOR):
+    """[(n_configs, [epochs per rung])] of Hyperband (Li et al.) for R = max_epochs, eta = factor."""
+    s_max = int(math.floor(math.log(max_epochs, factor) + 1e-9))
+    out = []
+    for s in range(s_max, -1, -1):
+        n = int(math.ceil((s_max + 1) / (s + 1) * factor**s))
+        rungs = [max(1, int(round(max_epochs * factor ** (i - s)))) for i in range(s + 1)]
+        out.append((n, rungs))
+    return out
+
+
+def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_parameter: (Path | str) | dict = DEFAULT_ORCAI_PARAMETER,
+                          hps_parameter: (Path | str) | dict = DEFAULT_HPS_PARAMETER, parallel_: bool = False, data_compression: str | None = "GZIP",
+                          verbosity: int = 2, msgr: Messenger | None = None, parallel: bool | None = None, max_epochs: int = MAX_EPOCHS) -> None:
+    use_parallel = bool(parallel_ if parallel is None else parallel)
+    if msgr is None:
+        msgr = Messenger(verbosity=verbosity, title="Hyperparameter search")
+    import orcai_amd.parallel as par
+
+    rank, world, _ = par.init() if use_parallel else (0, 1, 0)
+    if rank != 0:
+        msgr.verbosity = 0
+    data_dir, output_dir = Path(data_dir), Path(output_dir)
+    if not isinstance(orcai_parameter, dict):
+        orcai_parameter = read_json(orcai_parameter)
+    if not isinstance(hps_parameter, dict):
+        hps_parameter = read_json(hps_parameter)
+    dataset_shape = read_json(data_dir.joinpath("dataset_shapes.json"))
+    monitor = orcai_parameter["model"]["monitor"]
+    hps_logs_dir = output_dir.joinpath("hps_logs")
+    msgr.part("Searching hyperparameters")
+    msgr.info(f"{'Parallel - running on ' + str(world) + ' GPU' if use_parallel else 'Sequential - running on 1 GPU'}")
+    rng = np.random.default_rng(orcai_parameter.get("seed") or 0)
+    trials = []
+
+    def run(hp: dict, epochs: int) -> float:
+        p = _apply(hp, orcai_parameter, hps_parameter)
+        bs = p["model"]["batch_size"]
+        train_ds = load_dataset(data_dir.joinpath("train_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_TEST_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
+        val_ds = load_dataset(data_dir.joinpath("val_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
+        model = build_model(tuple(dataset_shape["spectrogram"]), p, msgr=Messenger(verbosity=0))
+        model.compile(learning_rate=p["model"]["learning_rate"])
+        hist = model.fit(train_ds, validation_data=val_ds, epochs=epochs, callbacks=[EarlyStopping(monitor=monitor, patience=5, mode="max", restore_best_weights=True)])
+        return float(max(hist.history[monitor]))
+
+    for n, rungs in hyperband_brackets(max_epochs, FACTOR):
+        configs = [_draw(rng, hps_parameter, orcai_parameter) for _ in range(n)]
+        for i, epochs in enumerate(rungs):
+            scores = []
+            for hp in configs:
+                score = run(hp, epochs)
+                scores.append(score)
+                trials.append({**hp, "epochs": epochs, "score": score, "status": "COMPLETED", monitor: score})
+                msgr.info(f"trial {len(trials)}: {hp} epochs {epochs} -> {monitor} {score:.4f}")
+            keep = max(1, len(configs) // FACTOR)
+            order = np.argsort(-np.array(scores), kind="stable")[:keep]
+            configs = [configs[j] for j in order]
+            if i == len(rungs) - 1:
+                break
+    best = max(trials, key=lambda t: t["score"])
+    best_hp = {k: best[k] for k in ("filters", "kernel_size", "dropout_rate", "batch_size", "lstm_units") if k in best}
+    if rank == 0:
+        hps_logs_dir.mkdir(parents=True, exist_ok=True)
+        msgr.part("Best Hyperparameters")
+        msgr.info(best_hp)
+        write_json(best_hp, hps_logs_dir.joinpath("best_hyperparameters.json"))
+        pd.DataFrame(trials).to_csv(hps_logs_dir.joinpath("all_trials.csv"), index=False)
+        msgr.info(f"Saved trial data to {hps_logs_dir.joinpath('all_trials.csv')}")
+    msgr.success("Hyperparameter search completed")

@@ -449,11 +449,30 @@ class Trainer:
         if world_size > 1:
             import torch.distributed as dist
 
-            dist.all_reduce(self.P.g, op=dist.ReduceOp.SUM)  # one flat bucket over RCCL
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.P.g, op=dist.ReduceOp.SUM)  # one flat 4 MB bucket over RCCL / xGMI
+            else:  # gloo (tests): stage through the host
+                g = self.P.g.cpu()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                self.P.g.copy_(g)
         self.step_count += 1
         adam_step(self.P, self.lr, self.step_count, gscale=1.0 / world_size)
         self.trunk.update_moving_stats()
         self.head.update_moving_stats()
+
+    def sync_model(self) -> None:
+        """Copy the flat device parameters (and BN moving statistics) back into the model object (for predict / save)."""
+        self.P.to_model(self.model)
+
+    def state_dict(self) -> dict:
+        return {"w": self.P.w.clone(), "m": self.P.m.clone(), "v": self.P.v.clone(), "stats": {k: t.clone() for k, t in self.P.stats.items()},
+                "step": self.step_count, "lr": self.lr}
+
+    def load_state_dict(self, s: dict) -> None:
+        self.P.w.copy_(s["w"]); self.P.m.copy_(s["m"]); self.P.v.copy_(s["v"])
+        for k, t in s["stats"].items():
+            self.P.stats[k].copy_(t)
+        self.step_count, self.lr = s["step"], s["lr"]
 
     def train_step(self, src, snippet_stride, B, labels, world_size: int = 1) -> dict:
         out = self.forward_backward(src, snippet_stride, B, labels)

@@ -1,0 +1,170 @@
+"""The training workflow end to end on the GPU: dataset shards, `train()` API (callbacks, history, outputs, reload + resume),
+model.evaluate, 2-rank data parallel consistency (gloo staging on one GPU), and a tiny hyper-parameter search."""
+
+import json
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+SMALL = {"input_shape": (32, 12, 1), "steps": 8, "labels": 3}
+
+
+def _param(tmp=None, **model_over):
+    from orcai_amd.io import read_json
+
+    p = read_json(ROOT / "orcai_amd" / "defaults" / "default_orcai_parameter.json")
+    p["calls"] = ["A", "B", "C"]
+    p["seed"] = 1234
+    p["model"].update({"filters": [10, 20], "lstm_units": 64, "batch_size": 8, "epochs": 3, "learning_rate": 3e-3, "dropout_rate": 0.2})
+    p["model"].update(model_over)
+    return p
+
+
+def _data(tmp_path, n_train=64, n_val=24):
+    from orcai_amd.datasets import make_synthetic_dataset
+
+    d = tmp_path / "data"
+    d.mkdir()
+    make_synthetic_dataset(d / "train_dataset", n_train, seed=4, input_shape=(32, 12), out_steps=8, n_labels=3)
+    make_synthetic_dataset(d / "val_dataset", n_val, seed=5, input_shape=(32, 12), out_steps=8, n_labels=3)
+    (d / "dataset_shapes.json").write_text(json.dumps({"spectrogram": [32, 12, 1], "labels": [8, 3]}))
+    return d
+
+
+def test_train_api_outputs_and_resume(tmp_path):
+    from orcai_amd.io import load_orcai_model
+    from orcai_amd.train import train
+
+    d = _data(tmp_path)
+    out = tmp_path / "out"
+    out.mkdir()
+    p = _param()
+    train(d, out, p, verbosity=0)
+    mdir = out / "orcai-v1"
+    for f in ("orcai-v1.weights.npz", "training_history.json", "orcai_parameter.json", "model_shape.json"):
+        assert (mdir / f).exists(), f
+    hist = json.loads((mdir / "training_history.json").read_text())
+    assert set(hist) >= {"loss", "MBA", "val_loss", "val_MBA", "learning_rate"} and len(hist["loss"]) == 3
+    assert np.isfinite(hist["loss"]).all() and hist["loss"][-1] < hist["loss"][0]
+    assert json.loads((mdir / "model_shape.json").read_text()) == {"input_shape": [32, 12, 1], "num_labels": 3}
+    model, p2, shape = load_orcai_model(mdir)
+    x = np.random.default_rng(0).random((4, 32, 12, 1), dtype=np.float32)
+    assert model.predict(x).shape == (4, 8, 3)
+    train(d, out, p, load_model=True, verbosity=0)  # resume from the saved weights
+
+
+def test_evaluate_matches_oracle_metric(tmp_path):
+    from oracle import model_ref as M
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.datasets import SnippetDataset
+
+    d = _data(tmp_path, n_train=16, n_val=16)
+    cfg = dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=64, num_labels=3)
+    p = M.calibrated_params(seed=8, **cfg)
+    model = ResNetLSTM(cfg["input_shape"], 3, [10, 20], 3, 0.0, 64)
+    model.set_weights_dict(p)
+    ds = SnippetDataset(d / "val_dataset", 8, shuffle=False)
+    logs = model.evaluate(ds, return_dict=True)
+    x, y = np.load(d / "val_dataset" / "spectrogram.npy"), np.load(d / "val_dataset" / "labels.npy")
+    probs = M.forward_ref(p, x[..., None])
+    l2 = 1e-3 * sum(float((p[k].astype(np.float64) ** 2).sum()) for k in p if k.endswith("/kernel") and k.startswith(("lstm", "dense1")))
+    assert abs(logs["loss"] - (M.masked_bce_ref(y, probs) + l2)) <= 1e-5
+    assert abs(logs["MBA"] - M.masked_binary_accuracy_ref(y, probs)) <= 1e-6
+
+
+def test_label_downsampling_and_loader_semantics(tmp_path):
+    from oracle.train_ref import reshape_labels_ref
+    from orcai_amd.datasets import SnippetDataset, reshape_labels
+
+    rng = np.random.default_rng(3)
+    lab = (rng.random((736, 7)) > 0.5).astype(np.float32)
+    lab[:, 2] = -1.0
+    assert np.array_equal(reshape_labels(lab, 4), reshape_labels_ref(lab, 4))
+    half = np.zeros((32, 1), dtype=np.float32)
+    half[:8] = 1.0  # mean exactly 0.5 -> rounds half to even = 0
+    assert reshape_labels(half, 4)[0, 0] == 0.0
+    with pytest.raises(ValueError):
+        reshape_labels(lab[:730], 4)
+    d = _data(tmp_path, n_train=50, n_val=8)
+    ds = SnippetDataset(d / "train_dataset", 8, seed=[7, 1234])
+    assert len(ds) == 6  # drop_remainder
+    seen = [tuple(np.round(x.cpu().numpy().sum(axis=(1, 2)), 3)) for x, _ in ds]
+    assert len(seen) == 6
+    again = [tuple(np.round(x.cpu().numpy().sum(axis=(1, 2)), 3)) for x, _ in ds]
+    assert again != seen  # reshuffled each epoch
+    ds2 = SnippetDataset(d / "train_dataset", 8, seed=[7, 1234])
+    assert [tuple(np.round(x.cpu().numpy().sum(axis=(1, 2)), 3)) for x, _ in ds2] == seen  # seeded
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port, data_dir, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch
+    import torch.distributed as dist
+
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.datasets import SnippetDataset
+    from orcai_amd.training import Trainer
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=3)  # same seed -> same initial weights on every rank
+    tr = Trainer(model, learning_rate=1e-3)
+    ds = SnippetDataset(Path(data_dir) / "train_dataset", 8, seed=[7, 1], rank=rank, world_size=world)
+    grads = []
+    for xb, yb in ds:
+        tr.forward_backward(xb.contiguous().view(-1), 32 * 12, 8, yb)
+        grads.append(tr.P.g.cpu().numpy().copy())
+        tr.apply(world_size=world)
+    q.put((rank, tr.P.w.cpu().numpy(), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_weights_identical(tmp_path):
+    import torch.multiprocessing as mp
+
+    d = _data(tmp_path, n_train=32, n_val=8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, str(d), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (w, g)) for r, w, g in [q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0])  # identical weights on both ranks after every all-reduced step
+    assert len(res[0][1]) == 2 and not np.array_equal(res[0][1][0], res[1][1][0])  # the ranks really saw different batches
+
+
+def test_hyperband_and_tiny_search(tmp_path):
+    from orcai_amd.hpsearch import hyperband_brackets, hyperparameter_search
+
+    br = hyperband_brackets(10, 3)
+    assert br[0][1][-1] == 10 and all(r[-1] == 10 for _, r in br) and br[-1] == (3, [10])
+    d = _data(tmp_path, n_train=32, n_val=16)
+    hps = {"filters": {"set1": [10, 20], "set2": [12, 24]}, "lstm_units": [64], "dropout_rate": [0.0, 0.3], "kernel_size": [3], "batch_size": [8]}
+    out = tmp_path / "hps_out"
+    out.mkdir()
+    hyperparameter_search(d, out, _param(), hps, verbosity=0, max_epochs=3)
+    best = json.loads((out / "hps_logs" / "best_hyperparameters.json").read_text())
+    assert best["filters"] in ("set1", "set2") and best["lstm_units"] == 64
+    import pandas as pd
+
+    trials = pd.read_csv(out / "hps_logs" / "all_trials.csv")
+    assert len(trials) >= 4 and {"filters", "score", "status", "val_MBA"} <= set(trials.columns)
