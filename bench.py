@@ -117,9 +117,10 @@ class FrontendWorkload:
 
 WORKLOADS = {"frontend": FrontendWorkload}
 try:
-    from bench_predict import PredictWorkload  # added once the model forward exists
+    from bench_predict import PredictWorkload, TrainWorkload
 
     WORKLOADS["predict"] = PredictWorkload
+    WORKLOADS["train"] = TrainWorkload
 except ImportError:
     pass
 
@@ -180,6 +181,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
+        if args.workload == "train":
+            line["scaling"] = "weak"
+            line["config"]["parallelism"] = f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

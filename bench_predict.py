@@ -128,3 +128,62 @@ class PredictWorkload:
         t_total_per_audio_s = t_fe / seconds + (t_model / n_snip) / audio_per_snippet
         return {"value": round(1.0 / t_total_per_audio_s, 1), "unit": self.unit, "cores": cores, "kind": "port",
                 "sample": f"oracle (numpy/scipy front end on {seconds:.0f} s: {t_fe:.1f} s; torch-CPU fp32 model on {n_snip} snippets, {cores} threads: {t_model:.1f} s)"}
+
+
+class TrainWorkload:
+    """BASELINE configs[3]: orcai train, orcai-V1 architecture, synthetic snippets resident in HBM, batch 64 per GPU,
+    data parallel over RCCL (one flat 3.98 MB gradient all-reduce per step).  One step = forward (training mode) +
+    masked BCE + backward + all-reduce + Adam; metric snippets/s."""
+
+    name = "orcai-V1 train step, batch 64 per GPU, synthetic snippets"
+    metric = "snippets_per_s"
+    unit = "snippets/s"
+    dtype = "f32"
+
+    def __init__(self, device, rank):
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.training import Trainer
+
+        self.B = int(os.environ.get("ORCAI_BENCH_BATCH", "64"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.model = ResNetLSTM((736, 171, 1), 7, FILTERS, 3, 0.5, 128, seed=1)
+        self.trainer = Trainer(self.model, 1e-4, seed=rank)
+        g = torch.Generator(device=device)
+        g.manual_seed(4 + rank)
+        self.x = torch.rand((self.B, 736, 171), device=device, generator=g).view(-1)
+        self.y = (torch.rand((self.B, 46, 7), device=device, generator=g) > 0.7).float()
+        self.units_per_step = float(self.B)
+        self.ev = []
+
+    def step(self, timed: bool):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.trainer.train_step(self.x, 736 * 171, self.B, self.y, world_size=self.world)
+        if timed:
+            e1.record()
+            self.ev.append((e0, e1))
+
+    def roofline(self):
+        ms = float(np.mean([a.elapsed_time(b) for a, b in self.ev]))
+        flops = 3.0 * FWD_FLOP_PER_SNIPPET * self.B  # fwd + bwd ~ 3x forward (SURVEY 8a row C5)
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "train_step (all kernels)", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(ms, 3)}
+
+    def cpu_baseline(self):
+        from oracle import model_ref as M
+        from oracle import train_ref as T
+
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("ORCAI_BENCH_CPU_THREADS", "16")))
+        torch.set_num_threads(cores)
+        p = M.random_params(seed=1)
+        rng = np.random.default_rng(0)
+        n = 4
+        x = rng.random((n, 736, 171, 1), dtype=np.float32)
+        y = (rng.random((n, 46, 7)) > 0.7).astype(np.float32)
+        t0 = time.perf_counter()
+        T.loss_and_grads(p, x, y, None, 0.0, dtype=torch.float32)
+        dt = time.perf_counter() - t0
+        return {"value": round(n / dt, 2), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"oracle.train_ref.loss_and_grads (torch-CPU autograd, fp32, {cores} threads) on {n} snippets: {dt:.1f} s"}
