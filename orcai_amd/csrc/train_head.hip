@@ -392,11 +392,36 @@ __global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict
   __syncthreads();
   const int unit = wave * 8 + (lj & 7);
   const bool worker = lj < 8;  // lanes lj < 8 of each 16-lane row handle (rows 4lk..4lk+3, unit)
+  // register-prefetched operands of the current step: gates (i,f,g,o), c, c_prev, dH for the lane's 4 batch rows
+  float pg[4][4], pc[4], pcp[4], pdh[4];
+  auto load_step = [&](int step) {
+    const int t = dir ? step : (T - 1 - step);
+    const int tprev = dir ? t + 1 : t - 1;
+    const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bb = b0 + lk * 4 + r;
+      const bool ok = worker && bb < B && step < T;
+      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + (lj & 7) : 0;
+      pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
+      pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
+      pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
+      pcp[r] = (ok && has_prev) ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.f;
+      pdh[r] = ok ? dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] : 0.f;
+    }
+  };
+  load_step(0);
   for (int step = 0; step < T; ++step) {
     const int t = dir ? step : (T - 1 - step);       // reverse of the forward order
-    const int tprev = dir ? t + 1 : t - 1;           // forward-order predecessor (source of c_prev)
-    const bool has_prev = dir ? (t + 1 < T) : (t > 0);
     const int cur = step & 1;
+    float cg[4][4], cc[4], ccp[4], cdh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cc[r] = pc[r]; ccp[r] = pcp[r]; cdh[r] = pdh[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cg[r][q] = pg[r][q];
+    }
+    load_step(step + 1);  // next step's operands are in flight during this step's arithmetic
     if (worker) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -406,10 +431,9 @@ __global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict
         dhbuf[cur][row][unit] = 0.0f;  // ready to be accumulated into two steps later
         if (bb < B) {
           const int64_t gbase = (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + (lj & 7);
-          const float gi = gates[gbase], gf = gates[gbase + 8], gg = gates[gbase + 16], go = gates[gbase + 24];
-          const float c = cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit];
-          const float cp = has_prev ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.0f;
-          const float dh = dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] + dhr;
+          const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
+          const float c = cc[r], cp = ccp[r];
+          const float dh = cdh[r] + dhr;
           const float tc = tanhf_(c);
           const float dO = dh * tc;
           const float dct = dc[r] + dh * go * (1.0f - tc * tc);

@@ -519,7 +519,8 @@ int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, 
   const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
   const int VAL = 64 - 2 * (ktap / 2);
   const int tasks = (H * WP + VAL - 1) / VAL;
-  const int tpw = 8;
+  int tpw = (tasks + 15) / 16;  // ~16 waves per (snippet, quad): the 4*k*k wave reductions + atomics are paid once per wave
+  if (tpw < 8) tpw = 8;
   dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, (C + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   switch (ktap) {
