@@ -137,6 +137,13 @@ int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, i
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream);
 
+/* Both separable convolutions of a residual block fused, k = 3 (architectures.py:173-189):
+ *   in (Cp channels) -> ReLU -> SepConv(F)+BN+ReLU -> SepConv(F)+BN -> x-pooled output (as out_layout 2 of orcai_sepconv_bn).
+ * The intermediate activation stays in LDS.  Weight layouts as for orcai_sepconv_bn (dwa [4*ceil(Cp/4)][9], pwa [Cp][F], dwb
+ * [4*ceil(F/4)][9], pwb [F][F], folded BN scale/shift per conv). */
+int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
+                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
+
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
  *   s: padded channel-quad planes of C channels (xpooled = 0) or the x-pooled tensor written by
  *   orcai_sepconv_bn(out_layout = 2) (xpooled = 1); prev: padded channel-quad planes of Cp channels; wr f32[Cp][C], br f32[C]

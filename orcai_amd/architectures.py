@@ -38,6 +38,16 @@ def lstm_column_permutation(units: int) -> np.ndarray:
     return (2 * nt + (j >> 3)) * units + 8 * w + (j & 7)
 
 
+def depthwise_kernel_layout(dwk: np.ndarray) -> np.ndarray:
+    """Keras depthwise kernel (k,k,c,1) -> [ceil(c/4)][k*k][4] (channel innermost inside a quad; zero taps for the channels that
+    pad the last quad): the layout the kernels read with scalar loads."""
+    k, c = dwk.shape[0], dwk.shape[2]
+    cq = (c + 3) // 4
+    out = np.zeros((cq * 4, k * k), dtype=np.float32)
+    out[:c] = dwk[:, :, :, 0].transpose(2, 0, 1).reshape(c, k * k)
+    return np.ascontiguousarray(out.reshape(cq, 4, k * k).transpose(0, 2, 1))
+
+
 class ResNetLSTM:
     """CNN with residual connections + 2 bidirectional LSTM layers (architectures.py:120-241)."""
 
@@ -65,6 +75,10 @@ class ResNetLSTM:
         self._init_weights(np.random.default_rng(seed))
         self._dev = None  # folded device copies
         self._ws = {}
+        import os
+
+        # residual blocks at least this wide run both separable convs as one fused kernel (k = 3); 0 disables the fusion
+        self.fuse_min_width = int(os.environ.get("ORCAI_FUSE_MIN_WIDTH", "60")) or 10**9
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
 
     # ------------------------------------------------------------------ structure
@@ -218,9 +232,7 @@ class ResNetLSTM:
         def sep(name, bn):
             dwk = w[name + "/depthwise"]  # (k,k,c,1)
             c = dwk.shape[2]
-            dwt = np.zeros((4 * ((c + 3) // 4), k * k), dtype=np.float32)  # channels past c inside the last quad: zero taps
-            dwt[:c] = dwk[:, :, :, 0].transpose(2, 0, 1).reshape(c, k * k)
-            d[name + "/dw"] = self._upload(dwt)
+            d[name + "/dw"] = self._upload(depthwise_kernel_layout(dwk))
             d[name + "/pw"] = self._upload(w[name + "/pointwise"][0, 0])
             d[name + "/scale"], d[name + "/shift"] = self._fold_bn(bn, w[name + "/bias"])
 
@@ -300,10 +312,16 @@ class ResNetLSTM:
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
-            self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
-                         N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
-            self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
-                         N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
+            if k == 3 and wd >= self.fuse_min_width and keep is None:
+                # both separable convs in one kernel: the intermediate activation never leaves the CU
+                self._launch(f"b{b}/sep_ab", "orcai_block_sep2", lib.orcai_block_sep2, N.ptr(prev), B, c, f, h, wd, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
+                             N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
+                             N.ptr(d[pb + "/shift"]), N.ptr(bb), st)
+            else:
+                self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
+                             N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
+                self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
+                             N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
                          N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 1, st)
             c = f

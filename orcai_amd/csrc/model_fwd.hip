@@ -113,9 +113,54 @@ __device__ __forceinline__ float lane_shift(float v) {
   else return __shfl_down(v, SH, 64);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Depthwise stage for one channel quad, lane = pixel.  rows[dy] = the quad's dwordx4 of window row dy; wq = the quad's taps
+// [k*k][4] (channel innermost, wave-uniform -> scalar loads); relu_lo = 0 (ReLU on load) or -inf.
+// By linearity the horizontal taps are applied to per-column partial sums: p_dx = sum_dy w[dy][dx] * a_dy (lane-local,
+// packed two channels per v_pk_fma_f32), d = sum_dx shift(p_dx, dx - R): k - 1 lane shifts per channel instead of k*(k-1).
+template <int KS>
+__device__ __forceinline__ void dw_quad(const float4 (&rows)[KS], const float* __restrict__ wq, float relu_lo, float (&d)[4]) {
+  constexpr int R = KS / 2;
+  f32x2 p01[KS], p23[KS];
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx) { p01[dx] = (f32x2){0.f, 0.f}; p23[dx] = (f32x2){0.f, 0.f}; }
+#pragma unroll
+  for (int dy = 0; dy < KS; ++dy) {
+    const f32x2 a01 = {fmaxf(rows[dy].x, relu_lo), fmaxf(rows[dy].y, relu_lo)};
+    const f32x2 a23 = {fmaxf(rows[dy].z, relu_lo), fmaxf(rows[dy].w, relu_lo)};
+#pragma unroll
+    for (int dx = 0; dx < KS; ++dx) {
+      const float* w = wq + (dy * KS + dx) * 4;
+      const f32x2 w01 = {w[0], w[1]}, w23 = {w[2], w[3]};
+      p01[dx] = a01 * w01 + p01[dx];
+      p23[dx] = a23 * w23 + p23[dx];
+    }
+  }
+  float acc[4] = {p01[R].x, p01[R].y, p23[R].x, p23[R].y};
+#pragma unroll
+  for (int dx = 0; dx < KS; ++dx) {
+    if (dx == R) continue;
+    const float v[4] = {p01[dx].x, p01[dx].y, p23[dx].x, p23[dx].y};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sv;
+      if (dx - R == -3) sv = lane_shift<-3>(v[j]);
+      else if (dx - R == -2) sv = lane_shift<-2>(v[j]);
+      else if (dx - R == -1) sv = lane_shift<-1>(v[j]);
+      else if (dx - R == 1) sv = lane_shift<1>(v[j]);
+      else if (dx - R == 2) sv = lane_shift<2>(v[j]);
+      else sv = lane_shift<3>(v[j]);
+      acc[j] += sv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d[j] = acc[j];
+}
+
 template <int KS, int MT>
 __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][CQin][HP][WP][4]*/, int Cin, int H, int W, int WP, int relu_in,
-                                                       const float* __restrict__ dw /*[CQin*4][KS*KS]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                       const float* __restrict__ dw /*[CQin][KS*KS][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                        int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo, int RP, int H2, int WP2) {
   constexpr int KK = KS * KS;
@@ -148,6 +193,7 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
   float4 nxt[KS];
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
+  const float relu_lo = relu_in ? 0.0f : -INFINITY;
 
   for (int cq = 0; cq < CQ; ++cq) {
     float4 cur[KS];
@@ -166,38 +212,8 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
       const float av = pw[ok ? ci * Cout + co : 0];
       afrag[m] = ok ? av : 0.0f;
     }
-    const float* wgt = dw + cq * 4 * KK;  // wave-uniform -> scalar loads; [4][KK]
-    float d[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dy = 0; dy < KS; ++dy) {
-      float a[4] = {cur[dy].x, cur[dy].y, cur[dy].z, cur[dy].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (relu_in) a[j] = fmaxf(a[j], 0.0f);
-        const float* wj = wgt + j * KK + dy * KS;
-        if constexpr (KS == 1) {
-          d[j] = a[j] * wj[0];
-        } else if constexpr (KS == 3) {
-          d[j] = fmaf(lane_shift<-1>(a[j]), wj[0], d[j]);
-          d[j] = fmaf(a[j], wj[1], d[j]);
-          d[j] = fmaf(lane_shift<1>(a[j]), wj[2], d[j]);
-        } else if constexpr (KS == 5) {
-          d[j] = fmaf(lane_shift<-2>(a[j]), wj[0], d[j]);
-          d[j] = fmaf(lane_shift<-1>(a[j]), wj[1], d[j]);
-          d[j] = fmaf(a[j], wj[2], d[j]);
-          d[j] = fmaf(lane_shift<1>(a[j]), wj[3], d[j]);
-          d[j] = fmaf(lane_shift<2>(a[j]), wj[4], d[j]);
-        } else {
-          d[j] = fmaf(lane_shift<-3>(a[j]), wj[0], d[j]);
-          d[j] = fmaf(lane_shift<-2>(a[j]), wj[1], d[j]);
-          d[j] = fmaf(lane_shift<-1>(a[j]), wj[2], d[j]);
-          d[j] = fmaf(a[j], wj[3], d[j]);
-          d[j] = fmaf(lane_shift<1>(a[j]), wj[4], d[j]);
-          d[j] = fmaf(lane_shift<2>(a[j]), wj[5], d[j]);
-          d[j] = fmaf(lane_shift<3>(a[j]), wj[6], d[j]);
-        }
-      }
-    }
+    float d[4];
+    dw_quad<KS>(cur, dw + cq * 4 * KK, relu_lo, d);  // taps of the quad: [KK][4], wave-uniform -> scalar loads
     // d[j] = depthwise output of channel 4cq+j, lane = pixel.  4x4 transpose of 16-lane rows:
     // afterwards d[t] row g = (channel 4cq+g, pixels 16t..16t+15) = B fragment of column tile t.
     swap32(d[0], d[2]);
@@ -284,6 +300,173 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
       }
     }
   }
+}
+
+// =========================================================================================
+// block_sep2: the two separable convolutions of a residual block fused (architectures.py:173-189), k = 3:
+//   x -> ReLU -> SepConv(F) -> BN -> ReLU  (= a, never written to HBM)  -> SepConv(F) -> BN -> column-pair max (x-pooled)
+// One workgroup (4 waves) owns a 64-column window x TH output rows of one snippet.  Phase 1: the waves compute the
+// TH + 2 rows of `a` the second convolution needs (register-tile sepconv as above; rows / columns outside the image are
+// written as ZEROS: they are the "same" padding of the second convolution) into LDS as [row][quad][lane] dwordx4.
+// Phase 2: the waves compute the TH output rows reading `a` from LDS (ds_read_b128, lane = pixel), same depthwise /
+// transpose / MFMA pipeline, and store the column-pair max.  HBM traffic per block drops from (Cp + 2F + F/2) to
+// (Cp + F/2) channel planes; the price is (TH + 2)/TH recomputation of the first convolution.
+// Window k covers image columns 60k - 2 + lane: lanes 1..62 hold valid `a`, lanes 2..61 valid outputs (60 per window).
+// =========================================================================================
+template <int MT>
+__global__ __launch_bounds__(256) void block_sep2_kernel(const float* __restrict__ in /*[B][CQp][HP][WP][4]*/, int Cp, int F, int H, int W, int WP,
+                                                          const float* __restrict__ dwa, const float* __restrict__ pwa, const float* __restrict__ sca,
+                                                          const float* __restrict__ sha, const float* __restrict__ dwb, const float* __restrict__ pwb,
+                                                          const float* __restrict__ scb, const float* __restrict__ shb, float* __restrict__ outx, int TH,
+                                                          int nwin) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float4* alds = reinterpret_cast<float4*>(smem);  // [(TH + 2)][CQ][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int b = blockIdx.y;
+  const int win = blockIdx.x % nwin, y0 = (blockIdx.x / nwin) * TH;
+  const int x = win * 60 - 2 + lane;  // image column of this lane
+  const int plane = (H + 2) * WP;
+  const int CQp = (Cp + 3) >> 2, CQ = (F + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQp * plane;
+  const bool colok = x >= 0 && x < W;
+
+  // ---------------- phase 1: rows ya = y0 - 1 + ra of a = relu(BN_a(sepconv_a(relu(x))))
+  for (int ra = wave; ra < TH + 2; ra += 4) {
+    const int ya = y0 - 1 + ra;
+    float4* arow = alds + (int64_t)ra * CQ * 64;
+    if (ya < 0 || ya >= H) {  // wave-uniform: "same" padding rows of the second convolution
+      for (int q = 0; q < CQ; ++q) arow[q * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    int ridx[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int i = (ya + dy) * WP + x;  // padded row ya + dy == image row ya - 1 + dy
+      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 nxt[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) nxt[dy] = src[ridx[dy]];
+    for (int cq = 0; cq < CQp; ++cq) {
+      float4 cur[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) cur[dy] = nxt[dy];
+      if (cq + 1 < CQp) {
+        const float4* pn = src + (int64_t)(cq + 1) * plane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) nxt[dy] = pn[ridx[dy]];
+      }
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < Cp && co < F;
+        const float av = pwa[ok ? ci * F + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      float d[4];
+      dw_quad<3>(cur, dwa + cq * 36, 0.0f, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+    // BN_a + ReLU, zero outside the image columns; D register (m, t, r) = channel 16m + 4lk + r of window pixel 16t + lj
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      float s4[4], h4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = oq * 4 + r;
+        s4[r] = co < F ? sca[co] : 0.0f;
+        h4[r] = co < F ? sha[co] : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int wl = 16 * t + lj;
+        const int xx = win * 60 - 2 + wl;
+        const bool ok = xx >= 0 && xx < W && wl >= 1 && wl <= 62;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ok ? fmaxf(fmaf(acc[m][t][r], s4[r], h4[r]), 0.0f) : 0.0f;
+        if (oq < CQ) arow[oq * 64 + wl] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: output rows yb = y0 + rb from the `a` rows rb, rb+1, rb+2 in LDS
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float4* outq = reinterpret_cast<float4*>(outx) + (int64_t)b * CQ * H * WPx;
+  for (int rb = wave; rb < TH; rb += 4) {
+    const int yb = y0 + rb;
+    if (yb >= H) break;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cq = 0; cq < CQ; ++cq) {
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < F && co < F;
+        const float av = pwb[ok ? ci * F + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      float4 rows3[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) rows3[dy] = alds[((int64_t)(rb + dy) * CQ + cq) * 64 + lane];
+      float d[4];
+      dw_quad<3>(rows3, dwb + cq * 36, -INFINITY, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      float s4[4], h4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = oq * 4 + r;
+        s4[r] = co < F ? scb[co] : 0.0f;
+        h4[r] = co < F ? shb[co] : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int wl = 16 * t + lj;
+        const int xx = win * 60 - 2 + wl;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc[m][t][r], s4[r], h4[r]);
+          const float other = __shfl_xor(v[r], 1, 64);
+          v[r] = (xx + 1 < W) ? fmaxf(v[r], other) : v[r];
+        }
+        const bool live = wl >= 2 && wl <= 61 && xx >= 0 && xx < W && (xx & 1) == 0 && oq < CQ;
+        if (live) outq[((int64_t)oq * H + yb) * WPx + (xx >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  (void)colok;
 }
 
 // =========================================================================================
@@ -670,6 +853,41 @@ int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksiz
     case 7: return launch_sepconv<7>(st, a);
     default: return ORCAI_E_UNSUPPORTED;
   }
+}
+
+int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
+                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream) {
+  if (!in || !dwa || !pwa || !sca || !sha || !dwb || !pwb || !scb || !shb || !outx || B <= 0 || Cp <= 0 || F <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (F > 64) return ORCAI_E_UNSUPPORTED;
+  const int CQ = (F + 3) / 4;
+  int rows_a = (80 * 1024) / (CQ * 64 * 16);  // LDS budget 80 KiB -> two workgroups per CU
+  if (rows_a < 3) return ORCAI_E_UNSUPPORTED;
+  int TH = rows_a - 2;
+  if (TH > H) TH = H;
+  const size_t lds = (size_t)(TH + 2) * CQ * 64 * 16;
+  const int nwin = (W + 59) / 60;
+  dim3 grid(nwin * ((H + TH - 1) / TH), B);
+  hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, 3);
+#define ORCAI_SEP2_LAUNCH(MT)                                                                                                          \
+  {                                                                                                                                    \
+    static size_t lds_set = 0;                                                                                                         \
+    if (lds > lds_set) {                                                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)block_sep2_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+      if (e != hipSuccess) return (int)e;                                                                                              \
+      lds_set = lds;                                                                                                                   \
+    }                                                                                                                                  \
+    hipLaunchKernelGGL(block_sep2_kernel<MT>, grid, dim3(256), lds, st, in, Cp, F, H, W, WP, dwa, pwa, sca, sha, dwb, pwb, scb, shb, outx, TH, nwin); \
+  }
+  switch ((F + 15) / 16) {
+    case 1: ORCAI_SEP2_LAUNCH(1); break;
+    case 2: ORCAI_SEP2_LAUNCH(2); break;
+    case 3: ORCAI_SEP2_LAUNCH(3); break;
+    case 4: ORCAI_SEP2_LAUNCH(4); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_SEP2_LAUNCH
+  return (int)hipGetLastError();
 }
 
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,

@@ -257,13 +257,16 @@ class TrunkTrainer:
     def _eye(self, c):
         return self._const(("eye", c), lambda: torch.eye(c, dtype=torch.float32, device=self.dev).contiguous())
 
-    def _dw_kernel_layout(self, name):
-        """Keras depthwise (k,k,c,1) -> [4*ceil(c/4)][k*k] (zero rows for the padding channels)."""
+    def _dw_kernel_layout(self, name, flip: bool = False):
+        """Keras depthwise (k,k,c,1) -> [ceil(c/4)][k*k][4] (zero taps for the padding channels); flip = taps of the input gradient."""
         w = self.P.W(name)
-        c = w.shape[2]
-        out = torch.zeros((4 * ((c + 3) // 4), self.k * self.k), dtype=torch.float32, device=self.dev)
-        out[:c] = w[:, :, :, 0].permute(2, 0, 1).reshape(c, self.k * self.k)
-        return out
+        if flip:
+            w = w.flip(0, 1)
+        c, kk = w.shape[2], self.k * self.k
+        cq = (c + 3) // 4
+        out = torch.zeros((cq * 4, kk), dtype=torch.float32, device=self.dev)
+        out[:c] = w[:, :, :, 0].permute(2, 0, 1).reshape(c, kk)
+        return out.reshape(cq, 4, kk).permute(0, 2, 1).contiguous()
 
     def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0):
         N.check(self.lib.orcai_sepconv_planes(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
@@ -357,12 +360,11 @@ class TrunkTrainer:
         # du = Wpw dv   (pointwise conv with the transposed weights)
         wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
         self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
-        dwg = torch.zeros_like(dwl)
+        dwg = torch.zeros((4 * ((Cin + 3) // 4), k * k), dtype=torch.float32, device=self.dev)
         N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, dwg.data_ptr(), st), "dw_wgrad")
         P.G(name + "/depthwise").copy_(dwg[:Cin].reshape(Cin, k, k).permute(1, 2, 0).unsqueeze(3))
         # dr = depthwise conv of du with the flipped taps (identity pointwise)
-        flipped = dwl.reshape(-1, k, k).flip(1, 2).reshape(-1, k * k).contiguous()
-        self._sep(du, Cin, H, W, k, 0, flipped, self._eye(Cin), self._zeros(64), Cin, dr)
+        self._sep(du, Cin, H, W, k, 0, self._dw_kernel_layout(name + "/depthwise", flip=True), self._eye(Cin), self._zeros(64), Cin, dr)
 
     def backward(self, dfeatv: torch.Tensor) -> None:
         """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
