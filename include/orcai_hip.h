@@ -144,6 +144,11 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
 int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
                      const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
 
+/* Same contract as orcai_block_sep2, fused in REGISTERS: each wave walks down a 64-column window keeping the last three rows of the
+ * intermediate activation as channel quads (3*ceil(F/4) dwordx4 registers per lane; F <= 40), no LDS, no barriers. */
+int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
+                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
+
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
  *   s: padded channel-quad planes of C channels (xpooled = 0) or the x-pooled tensor written by
  *   orcai_sepconv_bn(out_layout = 2) (xpooled = 1); prev: padded channel-quad planes of Cp channels; wr f32[Cp][C], br f32[C]

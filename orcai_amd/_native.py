@@ -32,6 +32,7 @@ _SIGNATURES = {
     "orcai_conv0_bn_relu": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_bn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_block_sep2": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10),
+    "orcai_block_rows": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10),
     "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_padded_width": (C.c_int, [C.c_int, C.c_int]),
     "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -77,8 +77,11 @@ class ResNetLSTM:
         self._ws = {}
         import os
 
-        # residual blocks at least this wide run both separable convs as one fused kernel (k = 3); 0 disables the fusion
-        self.fuse_min_width = int(os.environ.get("ORCAI_FUSE_MIN_WIDTH", "60")) or 10**9
+        # Experimental: residual blocks at least this wide run both separable convs as one fused kernel (k = 3, F <= 40).
+        # Off by default (0): on MI355X both fused variants measured SLOWER than the two HBM-bound unfused kernels
+        # (DESIGN.md 4.2): "lds" = orcai_block_sep2, "rows" = orcai_block_rows.
+        self.fuse_min_width = int(os.environ.get("ORCAI_FUSE_MIN_WIDTH", "0")) or 10**9
+        self.fuse_variant = os.environ.get("ORCAI_FUSE_VARIANT", "rows")
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
 
     # ------------------------------------------------------------------ structure
@@ -312,9 +315,10 @@ class ResNetLSTM:
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
-            if k == 3 and wd >= self.fuse_min_width and keep is None:
-                # both separable convs in one kernel: the intermediate activation never leaves the CU
-                self._launch(f"b{b}/sep_ab", "orcai_block_sep2", lib.orcai_block_sep2, N.ptr(prev), B, c, f, h, wd, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
+            if k == 3 and wd >= self.fuse_min_width and f <= 40 and keep is None:
+                # both separable convs in one kernel: the intermediate activation never leaves the registers
+                fused = lib.orcai_block_sep2 if self.fuse_variant == "lds" else lib.orcai_block_rows
+                self._launch(f"b{b}/sep_ab", "orcai_block_rows", fused, N.ptr(prev), B, c, f, h, wd, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                              N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
                              N.ptr(d[pb + "/shift"]), N.ptr(bb), st)
             else:

@@ -470,6 +470,186 @@ __global__ __launch_bounds__(256) void block_sep2_kernel(const float* __restrict
 }
 
 // =========================================================================================
+// block_rows: both separable convolutions of a residual block fused IN REGISTERS, k = 3 (architectures.py:173-189).
+// One wave owns a 64-column window (as block_sep2: image columns 60*win - 2 + lane) and walks DOWN a run of output rows.
+// It keeps the last three rows of a = relu(BN_a(sepconv_a(relu(x)))) as channel quads with lane = pixel (3 x CQ dwordx4
+// registers, ring indexed at compile time by unrolling the row loop 3x).  Per output row it computes ONE new row of `a`
+// (3 input rows per input quad from HBM/L1 -> depthwise -> MFMA -> BN+ReLU -> 4x4 row transposes back to lane = pixel)
+// and one output row from the three `a` rows in registers, then stores the column-pair max.  No LDS, no barriers, and the
+// first convolution is recomputed only for the 2 warm-up rows of each run.
+// =========================================================================================
+template <int MT, int CQ /* output quads = ceil(F/4) <= 4*MT */>
+__global__ __launch_bounds__(256) void block_rows_kernel(const float* __restrict__ in /*[B][CQp][HP][WP][4]*/, int Cp, int F, int H, int W, int WP,
+                                                          const float* __restrict__ dwa, const float* __restrict__ pwa, const float* __restrict__ sca,
+                                                          const float* __restrict__ sha, const float* __restrict__ dwb, const float* __restrict__ pwb,
+                                                          const float* __restrict__ scb, const float* __restrict__ shb, float* __restrict__ outx,
+                                                          int rows_per_task, int nwin, int ntasks) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= ntasks) return;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int b = blockIdx.y;
+  const int win = task % nwin, y_begin = (task / nwin) * rows_per_task;
+  const int y_end = (y_begin + rows_per_task < H) ? y_begin + rows_per_task : H;
+  const int x = win * 60 - 2 + lane;
+  const int plane = (H + 2) * WP;
+  const int CQp = (Cp + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQp * plane;
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float4* outq = reinterpret_cast<float4*>(outx) + (int64_t)b * CQ * H * WPx;
+  const bool a_ok = x >= 0 && x < W && lane >= 1 && lane <= 62;  // `a` is zero outside the image columns ("same" padding)
+
+  // per-lane BN constants in the D layout: register (m, r) <-> channel 16m + 4lk + r
+  float sa[MT][4], ha[MT][4], sb[MT][4], hb[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      sa[m][r] = co < F ? sca[co] : 0.f; ha[m][r] = co < F ? sha[co] : 0.f;
+      sb[m][r] = co < F ? scb[co] : 0.f; hb[m][r] = co < F ? shb[co] : 0.f;
+    }
+
+  float4 A[3][CQ];  // ring of `a` rows (lane = pixel)
+
+  // ---- one row of a: image row ya -> slot
+  auto a_row = [&](int ya, float4 (&dst)[CQ]) {
+    if (ya < 0 || ya >= H) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    int ridx[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int i = (ya + dy) * WP + x;
+      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 nxt[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) nxt[dy] = src[ridx[dy]];
+    for (int cq = 0; cq < CQp; ++cq) {
+      float4 cur[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) cur[dy] = nxt[dy];
+      if (cq + 1 < CQp) {
+        const float4* pn = src + (int64_t)(cq + 1) * plane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) nxt[dy] = pn[ridx[dy]];
+      }
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < Cp && co < F;
+        const float av = pwa[ok ? ci * F + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      float d[4];
+      dw_quad<3>(cur, dwa + cq * 36, 0.0f, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+    // BN_a + ReLU in the D layout, then back to lane = pixel: for fixed (m, r) the 4 registers over t hold rows lk = quad;
+    // the same 4 x 4 row transpose turns register t / row g into register g / row t, i.e. quad 4m+g with lane = pixel.
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float y[4][4];  // [t][r]
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[t][r] = fmaxf(fmaf(acc[m][t][r], sa[m][r], ha[m][r]), 0.0f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        swap32(y[0][r], y[2][r]);
+        swap32(y[1][r], y[3][r]);
+        swap16(y[0][r], y[1][r]);
+        swap16(y[2][r], y[3][r]);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q = m * 4 + g;
+        if (q < CQ) dst[q] = a_ok ? make_float4(y[g][0], y[g][1], y[g][2], y[g][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  // ---- one output row yb from three `a` rows
+  auto out_row = [&](int yb, const float4 (&r0)[CQ], const float4 (&r1)[CQ], const float4 (&r2)[CQ]) {
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq) {
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < F && co < F;
+        const float av = pwb[ok ? ci * F + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      const float4 rows3[3] = {r0[cq], r1[cq], r2[cq]};
+      float d[4];
+      dw_quad<3>(rows3, dwb + cq * 36, -INFINITY, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int wl = 16 * t + lj;
+        const int xx = win * 60 - 2 + wl;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc[m][t][r], sb[m][r], hb[m][r]);
+          const float other = __shfl_xor(v[r], 1, 64);
+          v[r] = (xx + 1 < W) ? fmaxf(v[r], other) : v[r];
+        }
+        const bool live = wl >= 2 && wl <= 61 && xx >= 0 && xx < W && (xx & 1) == 0 && oq < CQ;
+        if (live) outq[((int64_t)oq * H + yb) * WPx + (xx >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+
+  // prologue: a rows y_begin - 1 -> slot 0, y_begin -> slot 1; then per output row y: a row y+1 -> next slot, output from the ring
+  a_row(y_begin - 1, A[0]);
+  a_row(y_begin, A[1]);
+  for (int y = y_begin; y < y_end; y += 3) {
+    a_row(y + 1, A[2]);
+    out_row(y, A[0], A[1], A[2]);
+    if (y + 1 >= y_end) break;
+    a_row(y + 2, A[0]);
+    out_row(y + 1, A[1], A[2], A[0]);
+    if (y + 2 >= y_end) break;
+    a_row(y + 3, A[1]);
+    out_row(y + 2, A[2], A[0], A[1]);
+  }
+}
+
+// =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
 // Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
 // (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
@@ -887,6 +1067,36 @@ int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const 
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_SEP2_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
+                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream) {
+  if (!in || !dwa || !pwa || !sca || !sha || !dwb || !pwb || !scb || !shb || !outx || B <= 0 || Cp <= 0 || F <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  const int CQ = (F + 3) / 4;
+  if (CQ > 10) return ORCAI_E_UNSUPPORTED;  // 3*CQ dwordx4 registers of `a` per lane
+  const int nwin = (W + 59) / 60;
+  int rows = 32;
+  if (rows > H) rows = H;
+  const int ntasks = nwin * ((H + rows - 1) / rows);
+  dim3 grid((ntasks + 3) / 4, B);
+  hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, 3);
+#define ORCAI_ROWS_LAUNCH(MT, CQ_) hipLaunchKernelGGL((block_rows_kernel<MT, CQ_>), grid, dim3(256), 0, st, in, Cp, F, H, W, WP, dwa, pwa, sca, sha, dwb, pwb, scb, shb, outx, rows, nwin, ntasks)
+  switch (CQ) {
+    case 1: ORCAI_ROWS_LAUNCH(1, 1); break;
+    case 2: ORCAI_ROWS_LAUNCH(1, 2); break;
+    case 3: ORCAI_ROWS_LAUNCH(1, 3); break;
+    case 4: ORCAI_ROWS_LAUNCH(1, 4); break;
+    case 5: ORCAI_ROWS_LAUNCH(2, 5); break;
+    case 6: ORCAI_ROWS_LAUNCH(2, 6); break;
+    case 7: ORCAI_ROWS_LAUNCH(2, 7); break;
+    case 8: ORCAI_ROWS_LAUNCH(2, 8); break;
+    case 9: ORCAI_ROWS_LAUNCH(3, 9); break;
+    case 10: ORCAI_ROWS_LAUNCH(3, 10); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_ROWS_LAUNCH
   return (int)hipGetLastError();
 }
 

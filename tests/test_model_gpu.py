@@ -123,3 +123,15 @@ def test_overlap_average_bit_exact(golden_dir):
         pred = torch.from_numpy(g["predictions"]).cuda()
         agg, cnt = aggregate_predictions_device(pred, T, 736, 4)
         assert np.array_equal(agg, g["aggregated"]) and np.array_equal(cnt, g["overlap_count"])
+
+
+@pytest.mark.parametrize("variant", ["lds", "rows"])
+def test_fused_block_variants_match_unfused(variant):
+    """The experimental fused residual-block kernels (both separable convs in one launch) give the unfused result."""
+    model, p = make_model(9)
+    x = np.random.default_rng(4).random((3, 736, 171, 1), dtype=np.float32)
+    ref = model.predict(x, batch_size=3)
+    model.fuse_min_width, model.fuse_variant = 60, variant
+    out = model.predict(x, batch_size=3)
+    assert np.abs(out - ref).max() <= 2e-6
+    assert np.abs(out - M.forward_ref(p, x)).max() <= 1e-5
