@@ -36,6 +36,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 //     window is k loads at flat offsets (dy - R)*WP; channels past C inside the last quad are kept at zero.
 // =========================================================================================
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with a private L2), so linear block L runs on
+// XCD L % 8.  Remapping L -> start(L % 8) + L / 8 gives every XCD one contiguous band of the (snippet, window) space: windows
+// of vertically adjacent rows -- which re-read the same input rows -- then share an L2 instead of each pulling the rows over
+// the fabric again.  Bijective for any grid size; placement affects speed only.
+__device__ __forceinline__ void xcd_remap(int& bx, int& by) {
+  const unsigned nbx = gridDim.x, total = nbx * gridDim.y;
+  const unsigned L = blockIdx.y * nbx + blockIdx.x;
+  const unsigned k = L & 7u, q = total >> 3, r = total & 7u;
+  const unsigned Lp = k * q + (k < r ? k : r) + (L >> 3);
+  by = (int)(Lp / nbx);
+  bx = (int)(Lp - (unsigned)by * nbx);
+}
+
 // conv0: Conv2D(16, k x k, same) on a single-channel input + folded BN + ReLU   (architectures.py:164-168)
 template <int KS>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
@@ -167,10 +180,11 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
   const int R = RP;  // rows of zero padding of the planes (>= KS/2, the tap radius)
   const int VAL = 64 - 2 * lo;  // valid output lanes are [lo, 64 - lo); lo >= R
   const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int task = bx * 4 + (threadIdx.x >> 6);
   if (task >= tasks) return;  // whole wave; the kernel has no barriers
   const int lk = lane >> 4, lj = lane & 15;
-  const int b = blockIdx.y;
   const int plane = (H + 2 * R) * WP;  // pixels per quad plane
   const int CQ = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
   const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
@@ -190,19 +204,24 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 nxt[KS];
+  // register pipeline two quads deep: the rows of quads cq+1 and cq+2 are in flight while quad cq is being processed
+  float4 nxt[KS], nx2[KS];
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
+  if (CQ > 1) {
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) nx2[dy] = src[plane + ridx[dy]];
+  }
   const float relu_lo = relu_in ? 0.0f : -INFINITY;
 
   for (int cq = 0; cq < CQ; ++cq) {
     float4 cur[KS];
 #pragma unroll
-    for (int dy = 0; dy < KS; ++dy) cur[dy] = nxt[dy];
-    if (cq + 1 < CQ) {
-      const float4* pn = src + (int64_t)(cq + 1) * plane;
+    for (int dy = 0; dy < KS; ++dy) { cur[dy] = nxt[dy]; nxt[dy] = nx2[dy]; }
+    if (cq + 2 < CQ) {
+      const float4* pn = src + (int64_t)(cq + 2) * plane;
 #pragma unroll
-      for (int dy = 0; dy < KS; ++dy) nxt[dy] = pn[ridx[dy]];
+      for (int dy = 0; dy < KS; ++dy) nx2[dy] = pn[ridx[dy]];
     }
     float afrag[MT];
 #pragma unroll
@@ -663,10 +682,11 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
                                                             int pad_left, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
                                                             float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int xpooled, int tasks, uint32_t magic_WPo) {
   const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int task = bx * 4 + (threadIdx.x >> 6);
   if (task >= tasks) return;
   const int lk = lane >> 4, lj = lane & 15;
-  const int b = blockIdx.y;
   const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
   const int plane = (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
   const int qbase = R * WPo + task * 64;
