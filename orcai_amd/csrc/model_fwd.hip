@@ -119,11 +119,14 @@ __device__ __forceinline__ void swap16(float& a, float& b) {  // a's odd 16-lane
   b = __uint_as_float(r[1]);
 }
 // value of lane (l + SH) for SH in [-3, 3] (lanes shifted in from outside the wave are don't-care)
+// One DPP wave shift (wave_shr:1 / wave_shl:1, a VALU move) per lane of distance, instead of an LDS-pipe ds_bpermute.
 template <int SH>
 __device__ __forceinline__ float lane_shift(float v) {
   if constexpr (SH == 0) return v;
-  else if constexpr (SH < 0) return __shfl_up(v, -SH, 64);
-  else return __shfl_down(v, SH, 64);
+  else if constexpr (SH < 0)
+    return lane_shift<SH + 1>(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)));
+  else
+    return lane_shift<SH - 1>(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true)));
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

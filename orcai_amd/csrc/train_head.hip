@@ -87,6 +87,125 @@ __global__ __launch_bounds__(256) void gemm_strided_kernel(const float* __restri
     }
 }
 
+// =========================================================================================
+// The same product for the two stride patterns training uses, with 16-byte global loads, a register-prefetched
+// 64 x 64 x 32 tile pipeline and split-K (partial products added with global_atomic_add_f32):
+//   XM = 0: X(r, k) = X[k*ld + r]  (r contiguous; weight gradients A^T B)      tile row k, one float4 along r per thread
+//   XM = 1: X(r, k) = X[r*ld + k]  (k contiguous; input gradients  A B^T)      one float4 along k per thread, r fastest over lanes
+// =========================================================================================
+constexpr int GBK = 32;
+
+template <int XM>
+__device__ __forceinline__ void gemm_tile_load(const float* __restrict__ X, int64_t ld, int r0, int rmax, int k0, int kend, bool vec, int tid, float4 (&reg)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int f = tid + 256 * g;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XM == 0) {
+      const int k = k0 + (f >> 4), r = r0 + (f & 15) * 4;
+      const float* base = X + (int64_t)k * ld + r;
+      if (k < kend) {
+        if (vec && r + 3 < rmax) {
+          const float4 t = *reinterpret_cast<const float4*>(base);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (r + e < rmax) ? base[e] : 0.0f;
+        }
+      }
+    } else {
+      const int r = r0 + (f & 63), k = k0 + (f >> 6) * 4;
+      const float* base = X + (int64_t)r * ld + k;
+      if (r < rmax) {
+        if (vec && k + 3 < kend) {
+          const float4 t = *reinterpret_cast<const float4*>(base);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (k + e < kend) ? base[e] : 0.0f;
+        }
+      }
+    }
+    reg[g] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int XM>
+__device__ __forceinline__ void gemm_tile_store(float (*S)[SP], int tid, const float4 (&reg)[2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int f = tid + 256 * g;
+    if constexpr (XM == 0) {
+      *reinterpret_cast<float4*>(&S[f >> 4][(f & 15) * 4]) = reg[g];
+    } else {
+      const int r = f & 63, k = (f >> 6) * 4;
+      S[k][r] = reg[g].x; S[k + 1][r] = reg[g].y; S[k + 2][r] = reg[g].z; S[k + 3][r] = reg[g].w;
+    }
+  }
+}
+
+template <int AM, int BM>
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                          int M, int N, int K, float alpha, int accumulate, const float* __restrict__ Wreg, float beta_w,
+                                                          int k_per_split, int vec_a, int vec_b) {
+  __shared__ __attribute__((aligned(16))) float As[GBK][SP];
+  __shared__ __attribute__((aligned(16))) float Bs[GBK][SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ra[2], rb[2];
+  gemm_tile_load<AM>(A, lda, m0, M, kbeg, kend, vec_a != 0, tid, ra);
+  gemm_tile_load<BM>(B, ldb, n0, N, kbeg, kend, vec_b != 0, tid, rb);
+  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    __syncthreads();  // previous tile fully consumed
+    gemm_tile_store<AM>(As, tid, ra);
+    gemm_tile_store<BM>(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + GBK < kend) {  // next tile in flight during this tile's MFMAs
+      gemm_tile_load<AM>(A, lda, m0, M, k0 + GBK, kend, vec_a != 0, tid, ra);
+      gemm_tile_load<BM>(B, ldb, n0, N, k0 + GBK, kend, vec_b != 0, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GBK / 4; ++kk) {
+      float a[2], bq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk * 4 + lk][wm * 32 + i * 16 + lj];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = Bs[kk * 4 + lk][wn * 32 + j * 16 + lj];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], bq[j], acc[i][j]);
+    }
+  }
+  const bool split = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 32 + i * 16 + lk * 4 + r;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + lj;
+        if (n >= N) continue;
+        float v = alpha * acc[i][j][r];
+        if (Wreg && blockIdx.z == 0) v = fmaf(beta_w, Wreg[(int64_t)m * N + n], v);
+        float* c = C + (int64_t)m * N + n;
+        if (split) atomicAdd(c, v);  // C was zeroed by the launcher unless accumulating
+        else *c = accumulate ? *c + v : v;
+      }
+    }
+}
+
 // column sums of a row tensor: out[c] (=|+=) sum_m x[m][c]      (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out, int accumulate) {
   __shared__ float part[256];
@@ -367,31 +486,33 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __re
 //   dh = dH[t] + (dz[t_next] * U^T)     (recurrent part accumulated in LDS by all waves with ds_add_f32)
 //   do = dh tanh(c); dc += dh o (1 - tanh^2 c); di = dc g; dg = dc i; df = dc c_prev; dc_prev = dc f
 //   dz = (di i(1-i), df f(1-f), dg (1-g^2), do o(1-o))  -> dxz[t] (permuted columns), and the next recurrent term.
-// Wave w owns the gate columns [32w, 32w+32) = units [8w, 8w+8); U^T fragments of those columns stay in registers.
+// U/16 waves; wave w owns units [16w, 16w+16) = the 64 contiguous permuted gate columns [64w, 64w+64) (two column
+// groups of the forward kernel); the U^T fragments of those columns stay in registers (2 waves per SIMD, so the 128
+// fragment registers fit without spilling).  Lane (lk, lj) does the gate arithmetic of unit 16w+lj for rows 4lk..4lk+3.
 // =========================================================================================
 template <int U>
-__global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
+__global__ __launch_bounds__(U * 4) void lstm_bwd_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
                                                           const float* __restrict__ Uw /*[2][U][4U] permuted*/, int B, int T,
                                                           float* __restrict__ dxz /*[B][T][2][4U] permuted*/) {
-  constexpr int NT = U / 16, HP = U + 2, ZP = 34;
+  constexpr int NT = U / 16, NW = U / 16, HP = U + 2, ZP = 68;
   __shared__ float dhbuf[2][16][HP];
-  __shared__ float dzt[U / 8][16][ZP];  // per wave: dz[batch][32 columns]
+  __shared__ __attribute__((aligned(16))) float dzt[NW][16][ZP];  // per wave: dz[batch][64 columns]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int dir = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const float* Ud = Uw + (int64_t)dir * U * 4 * U;
-  // B'[p][k] = U[k][p] for this wave's 32 columns p: k-step s covers p = 4s..4s+3, column tile kt covers k = 16kt..16kt+15
-  float ut[8][NT];
+  // B'[p][k] = U[k][p] for this wave's 64 columns p: k-step s covers p = 4s..4s+3, column tile kt covers k = 16kt..16kt+15
+  float ut[16][NT];
 #pragma unroll
-  for (int s = 0; s < 8; ++s)
+  for (int s = 0; s < 16; ++s)
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) ut[s][kt] = Ud[(int64_t)(kt * 16 + lj) * (4 * U) + wave * 32 + 4 * s + lk];
-  for (int i = tid; i < 2 * 16 * HP; i += U * 8) (&dhbuf[0][0][0])[i] = 0.0f;
+    for (int kt = 0; kt < NT; ++kt) ut[s][kt] = Ud[(int64_t)(kt * 16 + lj) * (4 * U) + wave * 64 + 4 * s + lk];
+  for (int i = tid; i < 2 * 16 * HP; i += U * 4) (&dhbuf[0][0][0])[i] = 0.0f;
   float dc[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  const int unit = wave * 8 + (lj & 7);
-  const bool worker = lj < 8;  // lanes lj < 8 of each 16-lane row handle (rows 4lk..4lk+3, unit)
+  const int unit = wave * 16 + lj;
+  const int pl = (lj >> 3) * 32 + (lj & 7);  // wave-local column of gate i of this unit; f, g, o follow at +8, +16, +24
   // register-prefetched operands of the current step: gates (i,f,g,o), c, c_prev, dH for the lane's 4 batch rows
   float pg[4][4], pc[4], pcp[4], pdh[4];
   auto load_step = [&](int step) {
@@ -401,8 +522,8 @@ __global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int bb = b0 + lk * 4 + r;
-      const bool ok = worker && bb < B && step < T;
-      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + (lj & 7) : 0;
+      const bool ok = bb < B && step < T;
+      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + pl : 0;
       pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
       pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
       pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
@@ -422,41 +543,39 @@ __global__ __launch_bounds__(U * 8) void lstm_bwd_kernel(const float* __restrict
       for (int q = 0; q < 4; ++q) cg[r][q] = pg[r][q];
     }
     load_step(step + 1);  // next step's operands are in flight during this step's arithmetic
-    if (worker) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = lk * 4 + r, bb = b0 + row;
-        float dzi = 0.f, dzf = 0.f, dzg = 0.f, dzo = 0.f;
-        const float dhr = dhbuf[cur][row][unit];
-        dhbuf[cur][row][unit] = 0.0f;  // ready to be accumulated into two steps later
-        if (bb < B) {
-          const int64_t gbase = (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + (lj & 7);
-          const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
-          const float c = cc[r], cp = ccp[r];
-          const float dh = cdh[r] + dhr;
-          const float tc = tanhf_(c);
-          const float dO = dh * tc;
-          const float dct = dc[r] + dh * go * (1.0f - tc * tc);
-          dzi = dct * gg * gi * (1.0f - gi);
-          dzf = dct * cp * gf * (1.0f - gf);
-          dzg = dct * gi * (1.0f - gg * gg);
-          dzo = dO * go * (1.0f - go);
-          dc[r] = dct * gf;
-          float* dp = dxz + gbase;
-          dp[0] = dzi; dp[8] = dzf; dp[16] = dzg; dp[24] = dzo;
-        }
-        float* zr = &dzt[wave][row][lj & 7];
-        zr[0] = dzi; zr[8] = dzf; zr[16] = dzg; zr[24] = dzo;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = lk * 4 + r;
+      const float dhr = dhbuf[cur][row][unit];
+      dhbuf[cur][row][unit] = 0.0f;  // ready to be accumulated into two steps later
+      const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
+      const float c = cc[r], cp = ccp[r];
+      const float dh = cdh[r] + dhr;
+      const float tc = tanhf_(c);
+      const float dO = dh * tc;
+      const float dct = dc[r] + dh * go * (1.0f - tc * tc);
+      dc[r] = dct * gf;
+      float* zr = &dzt[wave][row][pl];  // rows past B carry zero gates, hence zero dz
+      zr[0] = dct * gg * gi * (1.0f - gi);
+      zr[8] = dct * cp * gf * (1.0f - gf);
+      zr[16] = dct * gi * (1.0f - gg * gg);
+      zr[24] = dO * go * (1.0f - go);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // recurrent term: D[batch][k] = sum_p dz[batch][p] * U[k][p] over this wave's 32 columns, added into dhbuf[next]
+    // dxz[t] rows of this wave's 64 columns: 16 rows x 16 float4, four per lane, 256 B contiguous per row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 4 + lk, bb = b0 + row;
+      const float4 v = *reinterpret_cast<const float4*>(&dzt[wave][row][lj * 4]);
+      if (bb < B) *reinterpret_cast<float4*>(dxz + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + lj * 4) = v;
+    }
+    // recurrent term: D[batch][k] = sum_p dz[batch][p] * U[k][p] over this wave's 64 columns, added into dhbuf[next]
     f32x4 acc[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 16; ++s) {
       const float a = dzt[wave][lj][4 * s + lk];  // A[i = batch lj][k = column 4s + lk]
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) acc[kt] = mfma16(a, ut[s][kt], acc[kt]);
@@ -491,8 +610,36 @@ extern "C" {
 int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C, int M, int N, int K, float alpha,
                        int accumulate, const float* Wreg, float beta_w, void* stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int am = sam == 1 ? 0 : (sak == 1 ? 1 : -1);  // 0: m contiguous, 1: k contiguous
+  const int bm = sbn == 1 ? 0 : (sbk == 1 ? 1 : -1);  // 0: n contiguous, 1: k contiguous
+  if (am >= 0 && am == bm) {  // A^T B (weight gradients) or A B^T (input gradients)
+    const int64_t lda = am == 0 ? sak : sam, ldb = bm == 0 ? sbk : sbn;
+    const int gx = (N + 63) / 64, gy = (M + 63) / 64;
+    int splits = 1;
+    if (gx * gy < 768 && K >= 8 * GBK) {  // too few tiles to fill 256 CUs: split K
+      splits = (1024 + gx * gy - 1) / (gx * gy);
+      const int max_splits = K / (4 * GBK);
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+    }
+    int kps = (K + splits - 1) / splits;
+    kps = (kps + GBK - 1) / GBK * GBK;
+    splits = (K + kps - 1) / kps;
+    if (splits > 1 && !accumulate) {
+      hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
+      if (e != hipSuccess) return (int)e;
+    }
+    const int va = ((uintptr_t)A % 16 == 0 && lda % 4 == 0) ? 1 : 0, vb = ((uintptr_t)B % 16 == 0 && ldb % 4 == 0) ? 1 : 0;
+    dim3 grid(gx, gy, splits);
+    if (am == 0)
+      hipLaunchKernelGGL((gemm_tiled_kernel<0, 0>), grid, dim3(256), 0, st, A, lda, B, ldb, C, M, N, K, alpha, accumulate, Wreg, beta_w, kps, va, vb);
+    else
+      hipLaunchKernelGGL((gemm_tiled_kernel<1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, M, N, K, alpha, accumulate, Wreg, beta_w, kps, va, vb);
+    return (int)hipGetLastError();
+  }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
-  hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, M, N, K, alpha, accumulate, Wreg, beta_w);
+  hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, M, N, K, alpha, accumulate, Wreg, beta_w);
   return (int)hipGetLastError();
 }
 
@@ -589,8 +736,8 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
   switch (units) {
-    case 128: hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(1024), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
-    case 64: hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(512), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
+    case 128: hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(512), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
+    case 64: hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();

@@ -283,10 +283,12 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
 // dW[c][tap] += sum_p r[c][p + off(tap)] * du[c][p]   with r = relu_in ? relu(x) : x.  One wave = 64-pixel windows of one
 // (snippet, quad); lanes R..63-R contribute; 4 x k x k accumulators per lane, wave-reduced once at the end.
 template <int KS, int SH>
-__device__ __forceinline__ float lsh(float v) {
+__device__ __forceinline__ float lsh(float v) {  // value of lane (l + SH): one DPP wave shift per lane of distance
   if constexpr (SH == 0) return v;
-  else if constexpr (SH < 0) return __shfl_up(v, -SH, 64);
-  else return __shfl_down(v, SH, 64);
+  else if constexpr (SH < 0)
+    return lsh<KS, SH + 1>(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true)));
+  else
+    return lsh<KS, SH - 1>(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true)));
 }
 
 template <int KS>
@@ -357,32 +359,37 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 // dW0[tap][c] += sum_p in[p + off(tap)] * dv0[c][p]; the single-channel input is the UNPADDED snippet image.
 template <int KS>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ in, int64_t snippet_stride, const float* __restrict__ dv /*[B][4][HP][WP][4]*/,
-                                                           int H, int W, int WP, float* __restrict__ dW /*[KS*KS][16]*/) {
+                                                           int H, int W, int WP, int B, float* __restrict__ dW /*[KS*KS][16]*/) {
+  // block (bx, cq) walks every snippet; one wave reduction + one LDS reduction + 4*k*k atomics per block at the very end
+  // (device-scope float atomics on a handful of addresses serialise at the memory side, so they are kept to gridDim.x per address)
   constexpr int R = KS / 2, KK = KS * KS;
-  const int lane = threadIdx.x & 63;
-  const int cq = blockIdx.y, b = blockIdx.z;
+  __shared__ float red[4][4 * KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = blockIdx.y;
   const int plane = (H + 2 * R) * WP;
-  const float* src = in + (int64_t)b * snippet_stride;
-  const float4* dp = reinterpret_cast<const float4*>(dv) + ((int64_t)b * 4 + cq) * plane;
   float acc[4][KK];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
-  const int64_t total = (int64_t)H * W;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
-    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
-    const float4 g4 = dp[(int64_t)(y + R) * WP + x];
-    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+  const int total = H * W;
+  for (int b = 0; b < B; ++b) {
+    const float* src = in + (int64_t)b * snippet_stride;
+    const float4* dp = reinterpret_cast<const float4*>(dv) + ((int64_t)b * 4 + cq) * plane;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+      const int y = p / W, x = p - y * W;
+      const float4 g4 = dp[(y + R) * WP + x];
+      const float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-    for (int dy = 0; dy < KS; ++dy)
+      for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < KS; ++dx) {
-        const int yy = y + dy - R, xx = x + dx - R;
-        const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(int64_t)yy * W + xx] : 0.0f;
+        for (int dx = 0; dx < KS; ++dx) {
+          const int yy = y + dy - R, xx = x + dx - R;
+          const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[yy * W + xx] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][dy * KS + dx] = fmaf(a, g[j], acc[j][dy * KS + dx]);
-      }
+          for (int j = 0; j < 4; ++j) acc[j][dy * KS + dx] = fmaf(a, g[j], acc[j][dy * KS + dx]);
+        }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -391,8 +398,13 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
       float v = acc[j][t];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) atomicAdd(&dW[t * 16 + cq * 4 + j], v);
+      if (lane == 0) red[wave][j * KK + t] = v;
     }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
+    atomicAdd(&dW[t * 16 + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
 }
 
 // ---------------------------------------------------------------- Keras Reshape layout [B][H][W*C] -> planes (gradient of the final conv)
@@ -535,12 +547,13 @@ int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, 
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream) {
   if (!in || !dv || !dW || B <= 0) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize);
-  dim3 grid(32, 4, B);
+  if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
+  dim3 grid(256, 4);
   hipStream_t st = (hipStream_t)stream;
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(conv0_wgrad_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
-    case 5: hipLaunchKernelGGL(conv0_wgrad_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
-    case 7: hipLaunchKernelGGL(conv0_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, dW); break;
+    case 3: hipLaunchKernelGGL(conv0_wgrad_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, B, dW); break;
+    case 5: hipLaunchKernelGGL(conv0_wgrad_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, B, dW); break;
+    case 7: hipLaunchKernelGGL(conv0_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, B, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();
