@@ -483,36 +483,34 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __re
 
 // =========================================================================================
 // LSTM backward through time for one direction and 16 snippets.  Per step (walking the forward order backwards):
-//   dh = dH[t] + (dz[t_next] * U^T)     (recurrent part accumulated in LDS by all waves with ds_add_f32)
+//   dh = dH[t] + dz[t_next] U^T
 //   do = dh tanh(c); dc += dh o (1 - tanh^2 c); di = dc g; dg = dc i; df = dc c_prev; dc_prev = dc f
 //   dz = (di i(1-i), df f(1-f), dg (1-g^2), do o(1-o))  -> dxz[t] (permuted columns), and the next recurrent term.
-// U/16 waves; wave w owns units [16w, 16w+16) = the 64 contiguous permuted gate columns [64w, 64w+64) (two column
-// groups of the forward kernel); the U^T fragments of those columns stay in registers (2 waves per SIMD, so the 128
-// fragment registers fit without spilling).  Lane (lk, lj) does the gate arithmetic of unit 16w+lj for rows 4lk..4lk+3.
+// U/16 waves.  Wave w owns units [16w, 16w+16): lane (lk, lj) does the gate arithmetic of unit 16w+lj for rows 4lk..4lk+3,
+// and the wave computes the 16 x 16 tile dh[:, 16w..16w+16) = dz[16 x 4U] U^T of the next step with the whole 4U-long
+// contraction in its own MFMA chain (k-step s takes columns {lk*U + s}, so A fragments are contiguous float4 LDS reads
+// and the U^T fragments -- 4U/4 registers -- stay resident).  The D tile comes out exactly in the (row, unit) lane layout
+// of the gate arithmetic, so the recurrent term never leaves registers; dz of all waves is exchanged through a
+// double-buffered LDS tile with one barrier per step.  (LDS float atomics were measured at ~3 clk per lane and are avoided.)
 // =========================================================================================
 template <int U>
 __global__ __launch_bounds__(U * 4) void lstm_bwd_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
                                                           const float* __restrict__ Uw /*[2][U][4U] permuted*/, int B, int T,
                                                           float* __restrict__ dxz /*[B][T][2][4U] permuted*/) {
-  constexpr int NT = U / 16, NW = U / 16, HP = U + 2, ZP = 68;
-  __shared__ float dhbuf[2][16][HP];
-  __shared__ __attribute__((aligned(16))) float dzt[NW][16][ZP];  // per wave: dz[batch][64 columns]
+  constexpr int ZP = 4 * U + 4;  // pitch = 4 (mod 32): the 8 lanes of one float4 LDS read phase cover all 32 banks
+  __shared__ __attribute__((aligned(16))) float dzs[2][16][ZP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int dir = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const float* Ud = Uw + (int64_t)dir * U * 4 * U;
-  // B'[p][k] = U[k][p] for this wave's 64 columns p: k-step s covers p = 4s..4s+3, column tile kt covers k = 16kt..16kt+15
-  float ut[16][NT];
-#pragma unroll
-  for (int s = 0; s < 16; ++s)
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) ut[s][kt] = Ud[(int64_t)(kt * 16 + lj) * (4 * U) + wave * 64 + 4 * s + lk];
-  for (int i = tid; i < 2 * 16 * HP; i += U * 4) (&dhbuf[0][0][0])[i] = 0.0f;
-  float dc[4] = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
   const int unit = wave * 16 + lj;
-  const int pl = (lj >> 3) * 32 + (lj & 7);  // wave-local column of gate i of this unit; f, g, o follow at +8, +16, +24
+  // B operand of k-step s: B[k = lk][j = lj] = U[unit][p = lk*U + s]
+  float ut[U];
+#pragma unroll
+  for (int s = 0; s < U; ++s) ut[s] = Ud[(int64_t)unit * (4 * U) + lk * U + s];
+  float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhr[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pl = wave * 64 + (lj >> 3) * 32 + (lj & 7);  // permuted column of gate i of this unit; f, g, o follow at +8, +16, +24
   // register-prefetched operands of the current step: gates (i,f,g,o), c, c_prev, dH for the lane's 4 batch rows
   float pg[4][4], pc[4], pcp[4], pdh[4];
   auto load_step = [&](int step) {
@@ -523,7 +521,7 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_kernel(const float* __restrict
     for (int r = 0; r < 4; ++r) {
       const int bb = b0 + lk * 4 + r;
       const bool ok = bb < B && step < T;
-      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + pl : 0;
+      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + pl : 0;
       pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
       pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
       pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
@@ -542,49 +540,45 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_kernel(const float* __restrict
 #pragma unroll
       for (int q = 0; q < 4; ++q) cg[r][q] = pg[r][q];
     }
-    load_step(step + 1);  // next step's operands are in flight during this step's arithmetic
+    load_step(step + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = lk * 4 + r;
-      const float dhr = dhbuf[cur][row][unit];
-      dhbuf[cur][row][unit] = 0.0f;  // ready to be accumulated into two steps later
       const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
       const float c = cc[r], cp = ccp[r];
-      const float dh = cdh[r] + dhr;
+      const float dh = cdh[r] + dhr[r];
       const float tc = tanhf_(c);
       const float dO = dh * tc;
       const float dct = dc[r] + dh * go * (1.0f - tc * tc);
       dc[r] = dct * gf;
-      float* zr = &dzt[wave][row][pl];  // rows past B carry zero gates, hence zero dz
+      float* zr = &dzs[cur][lk * 4 + r][pl];  // rows past B carry zero gates, hence zero dz
       zr[0] = dct * gg * gi * (1.0f - gi);
       zr[8] = dct * cp * gf * (1.0f - gf);
       zr[16] = dct * gi * (1.0f - gg * gg);
       zr[24] = dO * go * (1.0f - go);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();  // dz[cur] of every wave is visible; buffer cur^1 is free again after the next barrier
     // dxz[t] rows of this wave's 64 columns: 16 rows x 16 float4, four per lane, 256 B contiguous per row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = i * 4 + lk, bb = b0 + row;
-      const float4 v = *reinterpret_cast<const float4*>(&dzt[wave][row][lj * 4]);
+      const float4 v = *reinterpret_cast<const float4*>(&dzs[cur][row][wave * 64 + lj * 4]);
       if (bb < B) *reinterpret_cast<float4*>(dxz + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + lj * 4) = v;
     }
-    // recurrent term: D[batch][k] = sum_p dz[batch][p] * U[k][p] over this wave's 64 columns, added into dhbuf[next]
-    f32x4 acc[NT];
+    // recurrent term of the next step: D[batch][unit] = sum_p dz[batch][p] U[unit][p], four interleaved accumulator chains
+    f32x4 acc[4];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = &dzs[cur][lj][lk * U];  // A[i = batch lj][k = lk] of k-step s = dz[lj][lk*U + s]
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float a = dzt[wave][lj][4 * s + lk];  // A[i = batch lj][k = column 4s + lk]
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) acc[kt] = mfma16(a, ut[s][kt], acc[kt]);
+    for (int s4 = 0; s4 < U / 4; ++s4) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + 4 * s4);
+      acc[0] = mfma16(a.x, ut[4 * s4 + 0], acc[0]);
+      acc[1] = mfma16(a.y, ut[4 * s4 + 1], acc[1]);
+      acc[2] = mfma16(a.z, ut[4 * s4 + 2], acc[2]);
+      acc[3] = mfma16(a.w, ut[4 * s4 + 3], acc[3]);
     }
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&dhbuf[cur ^ 1][lk * 4 + r][kt * 16 + lj], acc[kt][r]);
-    __syncthreads();
+    for (int r = 0; r < 4; ++r) dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);  // D row 4lk+r, col lj: this lane's (row, unit)
   }
 }
 
