@@ -227,6 +227,11 @@ int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, in
  * result to pixel (2y, 2x) of planes of an H2 x W2 image (input gradient of the stride-2 1x1 residual conv). */
 int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
                          const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream);
+/* The same, additionally storing the depthwise output u (planes of Cin channels, u_out may be NULL): the training forward keeps u
+ * because the pointwise weight gradient is sum_pixels u (x) dv (architectures.py:176-189 differentiated by Keras inside model.fit). */
+int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
+                           const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, float* u_out,
+                           void* stream);
 
 /* BatchNormalization (training) on padded channel-quad planes: batch mean / biased variance (scratch: f64[8*ceil(C/4)]),
  * y = [relu](v*s + t) at interior pixels, backward (dbeta, dgamma, dv) with the optional ReLU folded in. */

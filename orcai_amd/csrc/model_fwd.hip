@@ -178,7 +178,8 @@ template <int KS, int MT>
 __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ in /*[B][CQin][HP][WP][4]*/, int Cin, int H, int W, int WP, int relu_in,
                                                        const float* __restrict__ dw /*[CQin][KS*KS][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo, int RP, int H2, int WP2) {
+                                                       int out_layout, float* __restrict__ out, int tasks, uint32_t magic_WP, int lo, int RP, int H2, int WP2,
+                                                       float* __restrict__ u_out /*optional [B][CQin][HP][WP][4]: the depthwise output*/) {
   constexpr int KK = KS * KS;
   const int R = RP;  // rows of zero padding of the planes (>= KS/2, the tap radius)
   const int VAL = 64 - 2 * lo;  // valid output lanes are [lo, 64 - lo); lo >= R
@@ -236,6 +237,12 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
     }
     float d[4];
     dw_quad<KS>(cur, dw + cq * 4 * KK, relu_lo, d);  // taps of the quad: [KK][4], wave-uniform -> scalar loads
+    if (u_out) {  // training forward: keep u = depthwise output (left operand of the pointwise weight gradient)
+      const int urow = (int)__umulhi((uint32_t)q, magic_WP);
+      const int ux = q - urow * WP;
+      if (lane >= lo && lane < 64 - lo && ux < W && urow < R + H)
+        reinterpret_cast<float4*>(u_out)[((int64_t)b * CQ + cq) * plane + q] = make_float4(d[0], d[1], d[2], d[3]);
+    }
     // d[j] = depthwise output of channel 4cq+j, lane = pixel.  4x4 transpose of 16-lane rows:
     // afterwards d[t] row g = (channel 4cq+g, pixels 16t..16t+15) = B fragment of column tile t.
     swap32(d[0], d[2]);
@@ -985,6 +992,7 @@ struct SepArgs {
   const float *in, *dw, *pw, *scale, *shift;
   float* out;
   int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
+  float* u_out = nullptr;
 };
 
 template <int KS, int MT>
@@ -995,7 +1003,7 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pw, a.scale, a.shift, a.Cout, a.relu_out,
-                     a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2);
+                     a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);
   return (int)hipGetLastError();
 }
 
@@ -1041,13 +1049,13 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
   return orcai_sepconv_planes(in, B, Cin, H, W, ksize, ksize, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, 0, 0, out, stream);
 }
 
-int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
-                         const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream) {
+int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
+                         const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, float* u_out, void* stream) {
   if (!in || !dw || !pw || !scale || !shift || !out || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
   if (Cout > 64 || ((uintptr_t)in & 15) || ktap > ksize_planes) return ORCAI_E_UNSUPPORTED;
   if (out_layout == 3 && (H2 < 2 * H - 1 || W2 < 2 * W - 1)) return ORCAI_E_BADARG;
   SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, orcai_padded_width(W, ksize_planes), ksize_planes / 2, Cout, relu_in, relu_out, out_layout,
-            H2, out_layout == 3 ? orcai_padded_width(W2, ksize_planes) : 0};
+            H2, out_layout == 3 ? orcai_padded_width(W2, ksize_planes) : 0, u_out};
   hipStream_t st = (hipStream_t)stream;
   switch (ktap) {
     case 1: return launch_sepconv<1>(st, a);
@@ -1056,6 +1064,11 @@ int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksiz
     case 7: return launch_sepconv<7>(st, a);
     default: return ORCAI_E_UNSUPPORTED;
   }
+}
+
+int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
+                         const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream) {
+  return orcai_sepconv_planes_u(in, B, Cin, H, W, ksize_planes, ktap, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, H2, W2, out, nullptr, stream);
 }
 
 int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,

@@ -165,44 +165,65 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ a, float* __restric
   if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
 }
 
-// ---------------------------------------------------------------- max-pool backward (gather form)
+// ---------------------------------------------------------------- max-pool backward
 // dy[y][x] = sum over the pooling windows (i, j) containing (y, x) of dout[i][j] * [ybn[y][x] == max of that window]
+// MaxPooling2D((3,2), strides 2, "same"): windows overlap only in rows (row 2i+2-pt closes window i and opens window i+1).
+// One thread owns pooled column j of one (snippet, quad) and walks PB_ROWS pooled rows downwards, carrying the shared
+// row's values and its partial gradient in registers, so every input value is loaded once and every gradient written once
+// (plus a one-window halo at the top of the chunk that recomputes the carry).  Lanes run along j: 32 contiguous bytes per lane.
+constexpr int PB_ROWS = 8;
+
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout /*[B][CQ][Ho+2R][WPo][4]*/, const float* __restrict__ ybn /*[B][CQ][HP][WP][4]*/,
                                                         int C, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, int pad_left,
                                                         float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B) {
   const int CQ = (C + 3) >> 2;
-  const int64_t interior = (int64_t)H * W;
+  const int nchunk = (Ho + PB_ROWS - 1) / PB_ROWS;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)B * CQ * interior) return;
-  const int64_t bq = idx / interior, pix = idx - bq * interior;
-  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  if (idx >= (int64_t)B * CQ * nchunk * Wo) return;
+  const int j = (int)(idx % Wo);
+  const int64_t rest = idx / Wo;
+  const int chunk = (int)(rest % nchunk);
+  const int64_t bq = rest / nchunk;
   const float4* yp = reinterpret_cast<const float4*>(ybn) + bq * ((int64_t)(H + 2 * R) * WP);
   const float4* dp = reinterpret_cast<const float4*>(dout) + bq * ((int64_t)(Ho + 2 * R) * WPo);
-  const float4 me = yp[(int64_t)(yy + R) * WP + xx];
-  const float mv[4] = {me.x, me.y, me.z, me.w};
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  const int j = (xx + pad_left) >> 1;
-  const int i_hi = (yy + pad_top) >> 1;
-  int i_lo = (yy + pad_top - 2 + 1) >> 1;  // ceil((yy + pad_top - 2) / 2)
-  if (yy + pad_top - 2 < 0) i_lo = 0;
-  for (int i = i_lo; i <= i_hi; ++i) {
-    if (i >= Ho || j >= Wo) continue;
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int dyy = 0; dyy < 3; ++dyy)
-      for (int dxx = 0; dxx < 2; ++dxx) {
-        const int y2 = 2 * i - pad_top + dyy, x2 = 2 * j - pad_left + dxx;
-        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
-          const float4 t = yp[(int64_t)(y2 + R) * WP + x2];
-          mx[0] = fmaxf(mx[0], t.x); mx[1] = fmaxf(mx[1], t.y); mx[2] = fmaxf(mx[2], t.z); mx[3] = fmaxf(mx[3], t.w);
-        }
-      }
+  float4* gp = reinterpret_cast<float4*>(dy) + bq * ((int64_t)(H + 2 * R) * WP);
+  const int x0 = 2 * j - pad_left, x1 = x0 + 1;
+  const bool cx0 = x0 >= 0 && x0 < W, cx1 = x1 < W;  // x1 >= 0 always
+  const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto ld = [&](int y, int x, bool cx) -> float4 { return (cx && y >= 0 && y < H) ? yp[(int64_t)(y + R) * WP + x] : ninf; };
+  auto mx4 = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
+  auto sel = [](float4 v, float4 m, float4 d) { return make_float4(v.x == m.x ? d.x : 0.f, v.y == m.y ? d.y : 0.f, v.z == m.z ? d.z : 0.f, v.w == m.w ? d.w : 0.f); };
+  auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+  const int i0 = chunk * PB_ROWS, i1 = (i0 + PB_ROWS < Ho) ? i0 + PB_ROWS : Ho;
+  const int istart = i0 > 0 ? i0 - 1 : 0;  // halo window: only its contribution to the shared row is kept
+  float4 t0 = ld(2 * istart - pad_top, x0, cx0), t1 = ld(2 * istart - pad_top, x1, cx1);  // first row of the current window
+  float4 c0 = zero4, c1 = zero4;                                                            // gradient carried into that row
+  for (int i = istart; i < i1; ++i) {
+    const int r0 = 2 * i - pad_top;
+    const float4 m0 = ld(r0 + 1, x0, cx0), m1 = ld(r0 + 1, x1, cx1);
+    const float4 b0 = ld(r0 + 2, x0, cx0), b1 = ld(r0 + 2, x1, cx1);
     const float4 d = dp[(int64_t)(i + R) * WPo + j];
-    if (mv[0] == mx[0]) g[0] += d.x;
-    if (mv[1] == mx[1]) g[1] += d.y;
-    if (mv[2] == mx[2]) g[2] += d.z;
-    if (mv[3] == mx[3]) g[3] += d.w;
+    const float4 m = mx4(mx4(mx4(t0, t1), mx4(m0, m1)), mx4(b0, b1));
+    if (i >= i0) {
+      if (r0 >= 0) {
+        if (cx0) gp[(int64_t)(r0 + R) * WP + x0] = add4(c0, sel(t0, m, d));
+        if (cx1) gp[(int64_t)(r0 + R) * WP + x1] = add4(c1, sel(t1, m, d));
+      }
+      if (r0 + 1 < H) {  // r0 + 1 >= 0 always
+        if (cx0) gp[(int64_t)(r0 + 1 + R) * WP + x0] = sel(m0, m, d);
+        if (cx1) gp[(int64_t)(r0 + 1 + R) * WP + x1] = sel(m1, m, d);
+      }
+    }
+    c0 = sel(b0, m, d);
+    c1 = sel(b1, m, d);
+    t0 = b0;
+    t1 = b1;
   }
-  reinterpret_cast<float4*>(dy)[bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx] = make_float4(g[0], g[1], g[2], g[3]);
+  const int rl = 2 * i1 - pad_top;  // first row of window i1: written here only when there is no window i1 (else the next chunk owns it)
+  if (i1 == Ho && rl < H) {
+    if (cx0) gp[(int64_t)(rl + R) * WP + x0] = c0;
+    if (cx1) gp[(int64_t)(rl + R) * WP + x1] = c1;
+  }
 }
 
 // ---------------------------------------------------------------- D[ca][cb] += sum_pixels A[ca][p] * Bq[cb][p]
@@ -344,6 +365,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       }
     }
   }
+  // one wave reduction per accumulator, one LDS reduction per block, then 4*k*k atomics per block (same-line device atomics
+  // serialise at ~12 ns each, so they are kept to a few thousand per line)
+  __shared__ float red[4][4 * KK];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -351,8 +375,13 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       float v = acc[j][t];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0 && cq * 4 + j < C) atomicAdd(&dW[(cq * 4 + j) * KK + t], v);
+      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
     }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK;
+    if (cq * 4 + j < C) atomicAdd(&dW[cq * 4 * KK + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
 }
 
 // ---------------------------------------------------------------- conv0 weight gradient
@@ -444,7 +473,7 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
-  if (gx > 512) gx = 512;
+  if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
   hipLaunchKernelGGL(planes_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, v, CQ, plane, B, scratch2C, scratch2C + 4 * CQ);
   hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, scratch2C + 4 * CQ, C, (double)B * H * W, mean, var);
   return (int)hipGetLastError();
@@ -458,7 +487,7 @@ int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, doub
   hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 4 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
-  if (gx > 512) gx = 512;
+  if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
   hipLaunchKernelGGL(planes_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, x, CQ, plane, B, scratchC, (double*)nullptr);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratchC, out, C, accumulate);
   return (int)hipGetLastError();
@@ -482,7 +511,7 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
-  if (gx > 512) gx = 512;
+  if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
   double* db = scratch2C;
   double* dg = scratch2C + 4 * CQ;
   hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
@@ -500,7 +529,7 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
-  const int64_t n = (int64_t)B * ((C + 3) / 4) * H * W;
+  const int64_t n = (int64_t)B * ((C + 3) / 4) * ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
                      orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B);
   return (int)hipGetLastError();
@@ -520,7 +549,7 @@ int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, i
   }
   const int plane = (H + 2 * R) * WP;
   int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
-  int grid = (int)(nchunks < 512 ? nchunks : 512);
+  int grid = (int)(nchunks < 256 ? nchunks : 256);  // one block per CU; each ends with Ca*Cb atomics
   hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
                      a_stride2 ? orcai_padded_width(Wa, ksize) : 0, D, magic_for(WP));
   return (int)hipGetLastError();
@@ -531,7 +560,7 @@ int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, 
   const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
   const int VAL = 64 - 2 * (ktap / 2);
   const int tasks = (H * WP + VAL - 1) / VAL;
-  int tpw = (tasks + 15) / 16;  // ~16 waves per (snippet, quad): the 4*k*k wave reductions + atomics are paid once per wave
+  int tpw = (tasks + 7) / 8;  // 8 waves = 2 blocks per (snippet, quad): the wave / block reductions + atomics are paid once per block
   if (tpw < 8) tpw = 8;
   dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, (C + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;

@@ -268,9 +268,10 @@ class TrunkTrainer:
         out[:c] = w[:, :, :, 0].permute(2, 0, 1).reshape(c, kk)
         return out.reshape(cq, 4, kk).permute(0, 2, 1).contiguous()
 
-    def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0):
-        N.check(self.lib.orcai_sepconv_planes(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
-                                              shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), N.stream_ptr()), "orcai_sepconv_planes")
+    def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0, u_out=None):
+        N.check(self.lib.orcai_sepconv_planes_u(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
+                                                shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), None if u_out is None else u_out.data_ptr(),
+                                                N.stream_ptr()), "orcai_sepconv_planes_u")
 
     def _bn_fwd(self, v, bn, C, H, W, relu, y):
         lib, P, st = self.lib, self.P, N.stream_ptr()
@@ -304,9 +305,12 @@ class TrunkTrainer:
             b[f"u_a{i}"], b[f"du_a{i}"] = self._planes(B, cprev, h, w), self._planes(B, cprev, h, w)  # depthwise output / its gradient (sep_a)
             b[f"u_b{i}"], b[f"du_b{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w)
             b[f"prev{i}"] = self._planes(B, f, shapes[i][0], shapes[i][1])
+            # gradient planes (only interiors are ever written, so the zero pads persist from step to step)
+            b[f"dyb{i}"], b[f"dya{i}"], b[f"dr{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w), self._planes(B, cprev, h, w)
         h, w, c = shapes[-1]
         b["u_f"], b["du_f"] = self._planes(B, c, h, w), self._planes(B, c, h, w)
         b["dvf"] = self._planes(B, FINAL_FILTERS, h, w)
+        b["dprev_f"] = self._planes(B, c, h, w)
         self.buf = b
 
     # ------------------------------------------------------------- forward
@@ -330,7 +334,7 @@ class TrunkTrainer:
             for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], b[f"yb{i}"], 0)):
                 name = f"b{i}/sep_{tag}"
                 self.dwl[name] = self._dw_kernel_layout(name + "/depthwise")
-                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v)
+                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
                 self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y)
             N.check(lib.orcai_pool_res_add(b[f"yb{i}"].data_ptr(), prev.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(), P.W(f"b{i}/res/bias").data_ptr(),
                                            b[f"prev{i}"].data_ptr(), 0, st), "orcai_pool_res_add")
@@ -338,7 +342,7 @@ class TrunkTrainer:
         h, w, _ = shapes[-1]
         self.dwl["sep_f"] = self._dw_kernel_layout("sep_f/depthwise")
         featv = torch.empty((B, h, w * FINAL_FILTERS), dtype=torch.float32, device=self.dev)
-        self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1)
+        self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1, u_out=b["u_f"])
         return featv
 
     def update_moving_stats(self) -> None:
@@ -352,10 +356,9 @@ class TrunkTrainer:
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
-        dwl = self.dwl[name]
-        N.check(lib.orcai_planes_sum(dv.data_ptr(), self.B, Cout, H, W, k, self.scratch.data_ptr(), P.G(name + "/bias").data_ptr(), 0, st), "planes_sum")
-        # u = dw(relu?(x))   (identity pointwise)
-        self._sep(x, Cin, H, W, k, relu_in, dwl, self._eye(Cin), self._zeros(64), Cin, u)
+        # d loss / d bias = sum_pixels dv, and dv is the gradient through a BatchNormalization of batch statistics: that sum is
+        # identically zero (the bias shifts the batch mean, which BN subtracts), so the gradient buffer keeps its zero.
+        # u = dw(relu?(x)) was stored by the forward pass.
         N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), st), "outer_reduce")
         # du = Wpw dv   (pointwise conv with the transposed weights)
         wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
@@ -373,7 +376,7 @@ class TrunkTrainer:
         L = len(m.filters)
         h, w, c = shapes[-1]
         N.check(lib.orcai_feat_to_planes(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
-        dprev = self._planes(B, c, h, w)
+        dprev = b["dprev_f"]
         self._sep_backward("sep_f", b[f"prev{L}"], 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
         for i in range(L, 0, -1):
             f = m.filters[i - 1]
@@ -385,15 +388,15 @@ class TrunkTrainer:
             N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(), st), "outer_reduce")
             N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
             # max-pool branch
-            dyb = self._planes(B, f, h, w)
+            dyb = b[f"dyb{i}"]
             N.check(lib.orcai_pool_bwd(dout.data_ptr(), b[f"yb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), st), "pool_bwd")
             dvb = dyb  # in place
             self._bn_bwd(dyb, b[f"vb{i}"], f"b{i}/bn_b", f, h, w, 0, dvb)
-            dya = self._planes(B, f, h, w)
+            dya = b[f"dya{i}"]
             self._sep_backward(f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, dvb, b[f"u_b{i}"], b[f"du_b{i}"], dya)
             dva = dya
             self._bn_bwd(dya, b[f"va{i}"], f"b{i}/bn_a", f, h, w, 1, dva)
-            dr = self._planes(B, cprev, h, w)
+            dr = b[f"dr{i}"]
             self._sep_backward(f"b{i}/sep_a", prev, 1, cprev, f, h, w, dva, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
             N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), prev.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
@@ -404,7 +407,7 @@ class TrunkTrainer:
         dv0 = dprev
         self._bn_bwd(dprev, b["v0"], "bn0", 16, H, W, 1, dv0)
         N.check(lib.orcai_conv0_wgrad(self.src.data_ptr(), self.snippet_stride, dv0.data_ptr(), B, H, W, k, P.G("conv0/kernel").data_ptr(), st), "conv0_wgrad")
-        N.check(lib.orcai_planes_sum(dv0.data_ptr(), B, 16, H, W, k, self.scratch.data_ptr(), P.G("conv0/bias").data_ptr(), 0, st), "planes_sum")
+        # conv0/bias feeds bn0: zero gradient (see _sep_backward)
 
 
 class Trainer:
