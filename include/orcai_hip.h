@@ -245,8 +245,10 @@ int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, doub
 /* gradient of MaxPooling2D((3,2), 2, "same"): dy[y][x] = sum of dout over the windows whose maximum is ybn[y][x] */
 int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream);
 /* D[ca][cb] += sum over snippets and pixels of A[ca][p] * Bq[cb][p] (pointwise / residual weight gradients); with a_stride2 the A planes
- * are an Ha x Wa image sampled at (2i, 2j) for pixel (i, j) of the H x W image of Bq. */
-int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, void* stream);
+ * are an Ha x Wa image sampled at (2i, 2j) for pixel (i, j) of the H x W image of Bq.  workspace: device scratch for the per-workgroup
+ * partial products (up to 512 * Ca * Cb floats are used; fewer workgroups run if it is smaller). */
+int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
+                       float* workspace, int64_t workspace_floats, void* stream);
 /* dW[c][tap] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient) */
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */

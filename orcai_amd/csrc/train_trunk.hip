@@ -228,12 +228,16 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------- D[ca][cb] += sum_pixels A[ca][p] * Bq[cb][p]
 // (pointwise / residual weight gradients).  256 pixels per pass go through LDS as [channel][pixel] (pitch 258: the
-// 16 channel rows x 2 pixels of a half-wave hit 32 distinct banks), then MFMA with k = pixel.
+// 16 channel rows x 2 pixels of a half-wave hit 32 distinct banks), then MFMA with k = pixel.  The next pass's global
+// loads are issued into registers before the MFMA phase.  Every block writes its partial product to a workspace and a
+// second kernel adds the partials into D: same-line float atomics serialise at ~12 ns each, which with 512 blocks cost
+// more than the whole reduction.
 // a_mode 1: A is sampled at pixel (2i, 2j) of planes (Ha, Wa) for each pixel (i, j) of the Bq planes (stride-2 1x1 conv).
 constexpr int OR_P = 258;
+constexpr int OR_MAXQ = 16;  // up to 64 channels per operand
 
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ A, int Ca, const float* __restrict__ Bq, int Cb, int H, int W, int WP, int R,
-                                                            int B, int a_mode, int Ha, int WPa, float* __restrict__ D /*[Ca][Cb]*/, uint32_t magic_WP) {
+                                                            int B, int a_mode, int Ha, int WPa, float* __restrict__ part /*[gridDim.x][Ca*Cb]*/, uint32_t magic_WP) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CQa = (Ca + 3) >> 2, CQb = (Cb + 3) >> 2;
   const int MT = (Ca + 15) >> 4, NT = (Cb + 15) >> 4, ntile = MT * NT;
@@ -249,10 +253,11 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int chunks_per_plane = (plane + 255) >> 8;
   const int64_t nchunks = (int64_t)B * chunks_per_plane;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  float4 ra[OR_MAXQ], rb[OR_MAXQ];
+  auto fetch = [&](int64_t ch) {
     const int64_t b = ch / chunks_per_plane;
     const int p = (int)(ch - b * chunks_per_plane) * 256 + tid;  // this thread's pixel
-    const bool pin = p < plane;
+    const bool pin = ch < nchunks && p < plane;
     int pa = p;
     bool ain = pin;
     if (a_mode) {
@@ -261,18 +266,26 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
       ain = pin && i >= 0 && i < H && x < W;
       pa = ain ? (2 * i + R) * WPa + 2 * x : 0;
     }
-    __syncthreads();
-    for (int q = 0; q < CQa; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ain) v = reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa];
-      As[(4 * q + 0) * OR_P + tid] = v.x; As[(4 * q + 1) * OR_P + tid] = v.y; As[(4 * q + 2) * OR_P + tid] = v.z; As[(4 * q + 3) * OR_P + tid] = v.w;
+#pragma unroll
+    for (int q = 0; q < OR_MAXQ; ++q) {
+      ra[q] = (q < CQa && ain) ? reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa] : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[q] = (q < CQb && pin) ? reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int q = 0; q < CQb; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pin) v = reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p];
-      Bs[(4 * q + 0) * OR_P + tid] = v.x; Bs[(4 * q + 1) * OR_P + tid] = v.y; Bs[(4 * q + 2) * OR_P + tid] = v.z; Bs[(4 * q + 3) * OR_P + tid] = v.w;
+  };
+  fetch(blockIdx.x);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    __syncthreads();  // previous pass's MFMA reads are done (also orders the initial zero fill)
+#pragma unroll
+    for (int q = 0; q < OR_MAXQ; ++q) {
+      if (q < CQa) {
+        As[(4 * q + 0) * OR_P + tid] = ra[q].x; As[(4 * q + 1) * OR_P + tid] = ra[q].y; As[(4 * q + 2) * OR_P + tid] = ra[q].z; As[(4 * q + 3) * OR_P + tid] = ra[q].w;
+      }
+      if (q < CQb) {
+        Bs[(4 * q + 0) * OR_P + tid] = rb[q].x; Bs[(4 * q + 1) * OR_P + tid] = rb[q].y; Bs[(4 * q + 2) * OR_P + tid] = rb[q].z; Bs[(4 * q + 3) * OR_P + tid] = rb[q].w;
+      }
     }
     __syncthreads();
+    fetch(ch + gridDim.x);  // in flight during the MFMA phase
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const int tile = wave + 4 * ti;
@@ -280,12 +293,16 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
         const int mt = tile / NT, nt = tile - mt * NT;
         const float* ar = As + (mt * 16 + lj) * OR_P + lk;
         const float* br = Bs + (nt * 16 + lj) * OR_P + lk;
-        f32x4 c = acc[ti];
-        for (int s = 0; s < 64; ++s) c = mfma16(ar[4 * s], br[4 * s], c);  // A[i = ca][k = pixel], B[k = pixel][j = cb]
-        acc[ti] = c;
+        f32x4 c0 = acc[ti], c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 64; s += 2) {  // A[i = ca][k = pixel], B[k = pixel][j = cb]; two interleaved accumulator chains
+          c0 = mfma16(ar[4 * s], br[4 * s], c0);
+          c1 = mfma16(ar[4 * s + 4], br[4 * s + 4], c1);
+        }
+        acc[ti] = c0 + c1;
       }
     }
   }
+  float* mine = part + (int64_t)blockIdx.x * Ca * Cb;
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
     const int tile = wave + 4 * ti;
@@ -294,10 +311,22 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
-        if (ca < Ca && cb < Cb) atomicAdd(&D[ca * Cb + cb], acc[ti][r]);
+        if (ca < Ca && cb < Cb) mine[ca * Cb + cb] = acc[ti][r];
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void add_partials_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nparts; k += 4) {
+    s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 1) * n + i]; s2 += part[(int64_t)(k + 2) * n + i]; s3 += part[(int64_t)(k + 3) * n + i];
+  }
+  for (; k < nparts; ++k) s0 += part[(int64_t)k * n + i];
+  D[i] += (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------- depthwise weight gradient
@@ -535,11 +564,10 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
   return (int)hipGetLastError();
 }
 
-int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, void* stream) {
-  if (!A || !Bq || !D || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0) return ORCAI_E_BADARG;
+int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
+                       float* workspace, int64_t workspace_floats, void* stream) {
+  if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
-  const int CQa = (Ca + 3) / 4, CQb = (Cb + 3) / 4;
-  (void)CQa; (void)CQb;
   const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * OR_P * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
@@ -548,10 +576,14 @@ int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, i
     lds_set = lds;
   }
   const int plane = (H + 2 * R) * WP;
-  int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
-  int grid = (int)(nchunks < 256 ? nchunks : 256);  // one block per CU; each ends with Ca*Cb atomics
-  hipLaunchKernelGGL(outer_reduce_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
-                     a_stride2 ? orcai_padded_width(Wa, ksize) : 0, D, magic_for(WP));
+  const int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
+  int64_t grid = nchunks < 512 ? nchunks : 512;
+  if (grid * Ca * Cb > workspace_floats) grid = workspace_floats / ((int64_t)Ca * Cb);
+  if (grid < 1) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(outer_reduce_kernel, dim3((unsigned)grid), dim3(256), lds, st, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
+                     a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Ca * Cb)), dim3(256), 0, st, workspace, (int)grid, Ca * Cb, D);
   return (int)hipGetLastError();
 }
 

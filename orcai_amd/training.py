@@ -238,6 +238,7 @@ class TrunkTrainer:
         self.B = None
         self.consts = {}
         self.scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad, <= 64 channels
+        self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
     # ------------------------------------------------------------- helpers
     def _planes(self, B, c, h, w):
@@ -359,7 +360,8 @@ class TrunkTrainer:
         # d loss / d bias = sum_pixels dv, and dv is the gradient through a BatchNormalization of batch statistics: that sum is
         # identically zero (the bias shifts the batch mean, which BN subtracts), so the gradient buffer keeps its zero.
         # u = dw(relu?(x)) was stored by the forward pass.
-        N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), st), "outer_reduce")
+        N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                       self.partials.numel(), st), "outer_reduce")
         # du = Wpw dv   (pointwise conv with the transposed weights)
         wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
         self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
@@ -385,7 +387,8 @@ class TrunkTrainer:
             prev = b[f"prev{i - 1}"] if i > 1 else b["y0"]
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
             # residual 1x1 stride-2 conv: weight / bias gradients
-            N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(), st), "outer_reduce")
+            N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
+                                           self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
             N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
             # max-pool branch
             dyb = b[f"dyb{i}"]
