@@ -43,6 +43,19 @@ def kernel_costs():
     return costs
 
 
+def measured_traffic(symbol: str, workload: str = "predict"):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE
+    in separate runs; gfx950: FETCH_SIZE counts wide reads at half, MI355X_MICROARCH.md HBM section), or None if not collected."""
+    import json
+    from pathlib import Path
+
+    f = Path(__file__).resolve().parent / "profiles" / "r01_pmc_traffic.json"
+    if not f.exists():
+        return None
+    rec = json.loads(f.read_text()).get(workload, {}).get("kernels", {}).get(symbol)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
+
+
 class PredictWorkload:
     name = "orcai-V1 predict, 1 h synthetic recording @48 kHz, 1833 snippets"
     metric = "audio_seconds_per_s"
@@ -80,26 +93,54 @@ class PredictWorkload:
 
     events: dict = {}
 
+    @staticmethod
+    def kernel_symbol(label: str) -> str:
+        """HIP kernel symbol a timed label runs as (the name rocprofv3 --kernel-trace --stats reports): the separable-conv and
+        pool kernels are templated on the tap size and on ceil(Cout/16) output tiles, so several layers share one symbol."""
+        couts = {"b1": 30, "b2": 40, "b3": 50, "b4": 60}
+        if label == "conv0":
+            return "conv0_kernel<3>"
+        if label == "sep_f":
+            return "sepconv_kernel<3, 3>"
+        blk, _, op = label.partition("/")
+        if blk in couts and op in ("sep_a", "sep_b"):
+            return f"sepconv_kernel<3, {(couts[blk] + 15) // 16}>"
+        if blk in couts and op == "pool_res":
+            return f"pool_res_add_kernel<{(couts[blk] + 15) // 16}>"
+        return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
+
     def roofline(self):
-        totals = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}  # ms over all timed steps
+        """Dominant kernel SYMBOL (as rocprofv3 names it): average launch duration from HIP events recorded on the launch
+        stream around every launch of the timed steps; achieved = algorithmic bytes per launch / that duration."""
+        per_label_ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}  # ms over all timed steps
         n_steps = max(1, len(self.events["dense2"]))  # the head runs once per step
-        dominant = max(totals, key=totals.get)
         costs = kernel_costs()
-        launches = len(self.events[dominant])
-        avg_ms = totals[dominant] / launches
-        snippets_per_launch = self.n_snippets * n_steps / launches
-        out = {"kernel": dominant, "kernel_ms": round(avg_ms, 4), "snippets_per_launch": round(snippets_per_launch, 2)}
-        if dominant in costs:
-            nbytes, flops = costs[dominant]
-            achieved = nbytes * snippets_per_launch / (avg_ms * 1e-3) / 1e9
+        sym = {}
+        for label, ms in per_label_ms.items():
+            d = sym.setdefault(self.kernel_symbol(label), {"ms": 0.0, "launches": 0, "bytes": 0.0, "flops": 0.0, "labels": []})
+            launches = len(self.events[label])
+            d["ms"] += ms
+            d["launches"] += launches
+            d["labels"].append(label)
+            if label in costs:  # whole-run algorithmic cost of this label: per-snippet cost x snippets x timed steps
+                d["bytes"] += costs[label][0] * self.n_snippets * n_steps
+                d["flops"] += costs[label][1] * self.n_snippets * n_steps
+        dominant = max(sym, key=lambda k: sym[k]["ms"])
+        d = sym[dominant]
+        avg_ms = d["ms"] / d["launches"]
+        out = {"kernel": dominant, "layers": sorted(d["labels"]), "kernel_ms": round(avg_ms, 4), "launches_per_step": d["launches"] // n_steps,
+               "snippets_per_launch": round(self.n_snippets * n_steps * len(d["labels"]) / d["launches"], 2)}
+        if d["bytes"] > 0:
+            achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
             out.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "kernel_tflops": round(flops * snippets_per_launch / (avg_ms * 1e-3) / 1e12, 2)})
+                        "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "traffic": measured_traffic(dominant),
+                        "kernel_tflops": round(d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12, 2)})
         else:
             out.update({"bound": "mfma", "achieved": None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None})
-        model_ms = sum(totals.values()) / n_steps
+        model_ms = sum(per_label_ms.values()) / n_steps
         out["model_ms_per_step"] = round(model_ms, 3)
         out["model_tflops"] = round(FWD_FLOP_PER_SNIPPET * self.n_snippets / (model_ms * 1e-3) / 1e12, 2)
-        out["per_kernel_ms_per_step"] = {k: round(v / n_steps, 3) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
+        out["per_layer_ms_per_step"] = {k: round(v / n_steps, 3) for k, v in sorted(per_label_ms.items(), key=lambda kv: -kv[1])}
         return out
 
     def cpu_baseline(self):
@@ -117,8 +158,8 @@ class PredictWorkload:
         spec, _, _ = F.make_spectrogram_ref(y, {"spectrogram": SPEC_PARAM})
         t_fe = time.perf_counter() - t0
         p = M.random_params(seed=1)
-        n_snip = 32
-        snippets = np.stack([spec[i * 368 : i * 368 + 736] for i in range(n_snip)])[..., None]
+        n_snip = 128  # ~10-15 s of 16-thread CPU work
+        snippets = np.stack([spec[(i % 50) * 368 : (i % 50) * 368 + 736] for i in range(n_snip)])[..., None]
         M.forward_ref(p, snippets[:4])  # warm-up
         t0 = time.perf_counter()
         for s in range(0, n_snip, 16):
@@ -179,11 +220,14 @@ class TrainWorkload:
         torch.set_num_threads(cores)
         p = M.random_params(seed=1)
         rng = np.random.default_rng(0)
-        n = 4
+        n = 8
         x = rng.random((n, 736, 171, 1), dtype=np.float32)
         y = (rng.random((n, 46, 7)) > 0.7).astype(np.float32)
-        t0 = time.perf_counter()
-        T.loss_and_grads(p, x, y, None, 0.0, dtype=torch.float32)
+        T.loss_and_grads(p, x[:2], y[:2], None, 0.0, dtype=torch.float32)  # warm-up
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 12.0:
+            T.loss_and_grads(p, x, y, None, 0.0, dtype=torch.float32)
+            done += n
         dt = time.perf_counter() - t0
-        return {"value": round(n / dt, 2), "unit": self.unit, "cores": cores, "kind": "port",
-                "sample": f"oracle.train_ref.loss_and_grads (torch-CPU autograd, fp32, {cores} threads) on {n} snippets: {dt:.1f} s"}
+        return {"value": round(done / dt, 2), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"oracle.train_ref.loss_and_grads (torch-CPU autograd forward+backward, fp32, {cores} threads) on {done} snippets in batches of {n}: {dt:.1f} s"}
