@@ -392,14 +392,27 @@ class ResNetLSTM:
             self.trunk_device(src[s * snippet_stride :], snippet_stride, B, feat[s:], keep=keep if s == 0 else None)
         self.head_device(feat, out, keep=keep)
 
-    def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 64) -> torch.Tensor:
+    def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 64, shard: bool = False) -> torch.Tensor:
         """All 50 %-overlapping snippets of a device spectrogram [T][W] -> f32 cuda [n][steps][labels].
-        Snippet i = rows [i*H/2, i*H/2 + H) (predict.py:244-261), read in place (no snippet copy)."""
+        Snippet i = rows [i*H/2, i*H/2 + H) (predict.py:244-261), read in place (no snippet copy).
+        shard=True inside an initialised process group: every rank holds the spectrogram, runs a contiguous block of the
+        snippets and the blocks are all-gathered; the result is identical on every rank and to shard=False."""
         H, W = self.input_hw
         assert spectrogram.is_cuda and spectrogram.dtype == torch.float32 and spectrogram.is_contiguous()
         assert spectrogram.shape[1] == W
         shift = H // 2
         n = (spectrogram.shape[0] - H) // shift + 1
+        if shard and n > 0:
+            import torch.distributed as dist
+
+            from orcai_amd import parallel
+
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                i0, i1 = parallel.contiguous_range(n, dist.get_rank(), dist.get_world_size())
+                local = torch.empty((i1 - i0, self.out_steps, self.num_labels), dtype=torch.float32, device=spectrogram.device)
+                if i1 > i0:
+                    self.forward_device(spectrogram.view(-1)[i0 * shift * W :], shift * W, i1 - i0, local, chunk=chunk)
+                return parallel.all_gather_rows(local, n)
         out = torch.empty((max(n, 0), self.out_steps, self.num_labels), dtype=torch.float32, device=spectrogram.device)
         if n > 0:
             self.forward_device(spectrogram.view(-1), shift * W, n, out, chunk=chunk)

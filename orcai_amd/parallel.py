@@ -46,6 +46,33 @@ def shard_indices(n_items: int, rank: int, size: int, costs=None) -> list[int]:
     return sorted(mine)
 
 
+def contiguous_range(n_items: int, rank: int, size: int) -> tuple[int, int]:
+    """[start, stop) of the contiguous block of n_items this rank owns (sizes differ by at most one, earlier ranks larger).
+    Used to shard the snippets of ONE recording: rank r needs spectrogram rows [shift*start, shift*(stop-1) + length)."""
+    base, extra = divmod(max(n_items, 0), size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """Concatenate the ranks' row blocks (made with contiguous_range) along dim 0: the one exchange step of a predict
+    sharded by snippet ranges ([n_g, 46, 7] f32, 1.3 KB per snippet).  Blocks are padded to the largest block
+    because all_gather needs equal shapes.  RCCL when the group is nccl; staged through the host for gloo."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    size = dist.get_world_size()
+    counts = [contiguous_range(n_total, r, size) for r in range(size)]
+    biggest = max(b - a for a, b in counts)
+    nccl = dist.get_backend() == "nccl"
+    buf = local if nccl else local.cpu()
+    padded = torch.zeros((biggest,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    padded[: buf.shape[0]] = buf
+    parts = [torch.empty_like(padded) for _ in range(size)]
+    dist.all_gather(parts, padded)
+    out = torch.cat([parts[r][: b - a] for r, (a, b) in enumerate(counts)], dim=0)
+    return out if nccl else out.to(local.device)
+
+
 def gather_objects(obj):
     """All ranks' objects, in rank order (small summaries only: never the data path)."""
     if not dist.is_initialized():

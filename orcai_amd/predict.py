@@ -119,7 +119,8 @@ def compute_aggregated_predictions(recording_path: Path, spectrogram, model, orc
     native = hasattr(model, "predict_spectrogram")
     if native:
         spec_dev = spectrogram if isinstance(spectrogram, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(spectrogram, dtype=np.float32)).cuda()
-        predictions = model.predict_spectrogram(spec_dev.contiguous())
+        # inside a process group the snippets of this recording are split into contiguous per-rank blocks and all-gathered
+        predictions = model.predict_spectrogram(spec_dev.contiguous(), shard=bool(orcai_parameter.get("shard_snippets", False)))
     else:
         spec_host = spectrogram.cpu().numpy() if isinstance(spectrogram, torch.Tensor) else spectrogram
         snippets = np.array([spec_host[i * shift : i * shift + snippet_length] for i in range(num_snippets)])

@@ -29,7 +29,14 @@ def _worker(rank, size, port, q):
     mine_lb = parallel.shard_indices(len(durations), r, s, costs=durations)
     everyone = parallel.gather_objects({"rank": r, "rr": mine_rr, "lb": mine_lb})
     slowest = parallel.max_over_ranks(1.0 + r)
-    q.put((r, everyone, slowest))
+    # one recording sharded by contiguous snippet ranges: rank blocks of a fake prediction tensor gather back to the whole
+    import torch
+
+    n = 29  # snippets of a 60 s recording
+    whole = torch.arange(n * 46 * 7, dtype=torch.float32).reshape(n, 46, 7)
+    a, b = parallel.contiguous_range(n, r, s)
+    gathered = parallel.all_gather_rows(whole[a:b].clone(), n)
+    q.put((r, everyone, slowest, (a, b), bool(torch.equal(gathered, whole))))
     import torch.distributed as dist
 
     dist.barrier()
@@ -47,7 +54,9 @@ def test_two_rank_sharding_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, everyone, slowest in results:
+    assert sorted(res[3] for res in results) == [(0, 15), (15, 29)]
+    assert all(res[4] for res in results)
+    for rank, everyone, slowest, _, _ in results:
         assert [e["rank"] for e in everyone] == [0, 1]
         rr = sorted(everyone[0]["rr"] + everyone[1]["rr"])
         lb = sorted(everyone[0]["lb"] + everyone[1]["lb"])
@@ -64,3 +73,15 @@ def test_single_process_defaults():
 
     assert parallel.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert parallel.gather_objects("x") == ["x"] and parallel.max_over_ranks(3.5) == 3.5
+
+
+def test_contiguous_range_is_a_partition():
+    from orcai_amd.parallel import contiguous_range
+
+    for n in (0, 1, 7, 29, 1833):
+        for size in (1, 2, 3, 8):
+            blocks = [contiguous_range(n, r, size) for r in range(size)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[k][1] == blocks[k + 1][0] for k in range(size - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)

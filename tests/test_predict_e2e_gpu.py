@@ -143,3 +143,48 @@ def test_create_spectrograms(tmp_path):
     assert spec.shape == ref.shape and np.abs(spec - ref).max() <= 2e-4
     t = read_json(out / "r1" / "spectrogram" / "times.json")
     assert t["length"] == len(times) and t["max"] == times[-1]
+
+
+def _shard_worker(rank, world, port, q):
+    import os
+    import sys
+
+    sys.path.insert(0, str(ROOT))
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import torch
+    import torch.distributed as dist
+
+    from orcai_amd.architectures import ResNetLSTM
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = ResNetLSTM((64, 20, 1), 3, [10, 20], 3, 0.0, 64, seed=5)
+    model.prepare()
+    g = torch.Generator().manual_seed(11)
+    spec = torch.rand((64 + 32 * 8 + 5, 20), generator=g).cuda()  # 9 snippets: blocks of 5 and 4
+    whole = model.predict_spectrogram(spec)
+    sharded = model.predict_spectrogram(spec, shard=True)
+    q.put((rank, tuple(whole.shape), bool(torch.equal(whole, sharded))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_predict_sharded_by_snippet_ranges_two_ranks():
+    """one recording, snippets split into contiguous per-rank blocks, one all_gather; bit-identical to one rank."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    assert all(r[1] == (9, 16, 3) and r[2] for r in results), results
