@@ -74,7 +74,7 @@ class PredictWorkload:
         self.fe = FrontEnd(device)
         self.model = ResNetLSTM((736, 171, 1), 7, FILTERS, 3, 0.0, 128, seed=1)
         self.model.prepare()
-        self.chunk = int(os.environ.get("ORCAI_BENCH_CHUNK", "64"))
+        self.chunk = int(os.environ.get("ORCAI_BENCH_CHUNK", "128"))
         self.T = 1 + self.n_samples // 256
         self.n_snippets = (self.T - 736) // 368 + 1
         self.units_per_step = self.seconds

@@ -266,9 +266,10 @@ class ResNetLSTM:
 
     def _buffers(self, B: int) -> dict:
         """Zero-padded activation planes for a trunk chunk of B snippets (see "Padded plane layout" in
-        csrc/model_fwd.hip).  Allocated ZEROED once per chunk size; the kernels never write the pads."""
-        if B in self._ws:
-            return self._ws[B]
+        csrc/model_fwd.hip).  Allocated ZEROED once for the largest chunk seen; the kernels never write the pads."""
+        for cap, ws in self._ws.items():  # planes are snippet-major: a smaller chunk uses the head of a larger workspace
+            if cap >= B:
+                return ws
         shapes = self.stage_shapes()
         dev = torch.device("cuda", torch.cuda.current_device())
         R = self.kernel_size // 2
@@ -283,7 +284,7 @@ class ResNetLSTM:
             wx = (wd + 1) // 2  # x-pooled output of the block's second separable conv: [B][CQ][H][roundup4(ceil(W/2))][4]
             ws[f"b{b}"] = torch.zeros((B, (f + 3) // 4, h, (wx + 3) & ~3, 4), dtype=torch.float32, device=dev)
             ws[f"prev{b}"] = planes(f, shapes[b][0], shapes[b][1])
-        self._ws = {B: ws}  # keep only the latest chunk size resident
+        self._ws = {B: ws}  # keep only the largest chunk size resident
         return ws
 
     def _launch(self, label: str, what: str, fn, *args) -> None:
@@ -342,10 +343,12 @@ class ResNetLSTM:
                 widths.update({f"a{i}": shapes[i - 1][1], f"b{i}": shapes[i - 1][1], f"prev{i}": shapes[i][1]})
             for name, t in ws.items():
                 if name.startswith("b"):  # x-pooled (unpadded rows): [B][CQ][H][WPx][4] -> [B][C][H][ceil(W/2)]
+                    t = t[:B]  # the workspace may be larger than this chunk
                     Bq, CQ, hh, WPx, _ = t.shape
                     full = t.permute(0, 1, 4, 2, 3).reshape(Bq, CQ * 4, hh, WPx)
                     keep[name] = full[:, : chans[name], :, : (widths[name] + 1) // 2].clone()
                     continue
+                t = t[:B]
                 Bq, CQ, HPp, WPp, _ = t.shape
                 hh = HPp - 2 * R
                 full = t.permute(0, 1, 4, 2, 3).reshape(Bq, CQ * 4, HPp, WPp)
@@ -381,7 +384,7 @@ class ResNetLSTM:
         if keep is not None:
             keep.update({"feat": feat.clone(), "h1": h1.clone(), "h2": h2.clone()})
 
-    def forward_device(self, src: torch.Tensor, snippet_stride: int, n: int, out: torch.Tensor, chunk: int = 64, keep: dict | None = None) -> None:
+    def forward_device(self, src: torch.Tensor, snippet_stride: int, n: int, out: torch.Tensor, chunk: int = 128, keep: dict | None = None) -> None:
         """n snippets starting at ``src`` (f32 cuda), snippet i at element offset i*snippet_stride, each [H][W] row-major
         (unpadded).  Writes probabilities into out[n][steps][labels].  The trunk runs in chunks of `chunk` snippets
         (bounds activation memory); the recurrent head runs once over all n."""
@@ -392,7 +395,7 @@ class ResNetLSTM:
             self.trunk_device(src[s * snippet_stride :], snippet_stride, B, feat[s:], keep=keep if s == 0 else None)
         self.head_device(feat, out, keep=keep)
 
-    def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 64, shard: bool = False) -> torch.Tensor:
+    def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 128, shard: bool = False) -> torch.Tensor:
         """All 50 %-overlapping snippets of a device spectrogram [T][W] -> f32 cuda [n][steps][labels].
         Snippet i = rows [i*H/2, i*H/2 + H) (predict.py:244-261), read in place (no snippet copy).
         shard=True inside an initialised process group: every rank holds the spectrogram, runs a contiguous block of the
