@@ -222,6 +222,13 @@ int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void
 int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
                        int relu, float* out, void* stream);
 
+/* ResNet1DConv head (architectures.py:10-15 ReduceFrequencyMean, :107-115 Conv1D(num_labels, kernel_size = 36, "same", sigmoid)).
+ * orcai_freq_mean: feat [M][W*C] in the Keras Reshape layout (feature = x*C + c) -> out [M][C] = mean over x.
+ * orcai_conv1d_sigmoid: x [B][T][C], w [K][C][L] (Keras Conv1D kernel layout), bias [L] -> out [B][T][L];
+ * "same" padding as TensorFlow: (K-1)/2 zero steps before, K/2 after. */
+int orcai_freq_mean(const float* feat, int64_t M, int W, int C, float* out, void* stream);
+int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int B, int T, int C, int K, int L, float* out, void* stream);
+
 /* orcai_sepconv_bn with the tap size (ktap in {1,3,5,7}) decoupled from the padding of the planes (ksize_planes >= ktap), used by the
  * backward pass: ktap = 1 is a pure pointwise conv (input gradient through the pointwise weights), out_layout 3 scatter-ADDS the
  * result to pixel (2y, 2x) of planes of an H2 x W2 image (input gradient of the stride-2 1x1 residual conv). */

@@ -226,6 +226,38 @@ def forward_ref(p: dict, snippets: np.ndarray, n_blocks: int | None = None, dtyp
     return out
 
 
+def forward_ref_1dconv(p: dict, snippets: np.ndarray, n_blocks: int | None = None, dtype=torch.float32, return_intermediates=False):
+    """ResNet1DConv inference forward (architectures.py:18-117): the same convolutional trunk (Dropout layers are identity at
+    inference), ReduceFrequencyMean = mean over the frequency axis (:10-15), Conv1D(num_labels, kernel_size = 36 channels,
+    padding "same", sigmoid) over time (:107-115).  Keras/TF "same" with an even kernel pads (K-1)//2 left, K//2 right."""
+    if n_blocks is None:
+        n_blocks = sum(1 for k in p if k.endswith("/res/kernel"))
+    inter = {}
+    with torch.no_grad():
+        x = _t(snippets, dtype).permute(0, 3, 1, 2)
+        x = _conv_same(x, p["conv0/kernel"], p["conv0/bias"], 1, dtype)
+        x = torch.relu(_bn_infer(x, p, "bn0", dtype))
+        prev = x
+        for b in range(1, n_blocks + 1):
+            x = torch.relu(x)
+            x = torch.relu(_bn_infer(_sepconv(x, p, f"b{b}/sep_a", dtype), p, f"b{b}/bn_a", dtype))
+            x = _bn_infer(_sepconv(x, p, f"b{b}/sep_b", dtype), p, f"b{b}/bn_b", dtype)
+            x = _maxpool_same(x) + _conv_same(prev, p[f"b{b}/res/kernel"], p[f"b{b}/res/bias"], 2, dtype)
+            prev = x
+        x = torch.relu(_bn_infer(_sepconv(x, p, "sep_f", dtype), p, "bn_f", dtype))  # (B, 36, T', W')
+        x = x.mean(dim=3).permute(0, 2, 1)  # ReduceFrequencyMean: (B, T', 36)
+        inter["freq_mean"] = x
+        w = _t(p["conv1d/kernel"], dtype)  # (K, C, L)
+        K = w.shape[0]
+        xp = torch.nn.functional.pad(x.permute(0, 2, 1), ((K - 1) // 2, K // 2))  # (B, C, T' + K - 1)
+        y = torch.nn.functional.conv1d(xp, w.permute(2, 1, 0).contiguous(), _t(p["conv1d/bias"], dtype))  # weight (L, C, K)
+        x = torch.sigmoid(y.permute(0, 2, 1))
+    out = x.numpy()
+    if return_intermediates:
+        return out, {k: v.numpy() for k, v in inter.items()}
+    return out
+
+
 def masked_bce_ref(y_true: np.ndarray, y_pred: np.ndarray, mask_value=-1.0) -> float:
     """architectures.py:262-270: BCE over unmasked elements (probabilities clipped to [1e-7, 1-1e-7]), mean."""
     m = y_true != mask_value

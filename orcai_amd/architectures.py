@@ -110,21 +110,27 @@ class ResNetLSTM:
     def out_steps(self) -> int:
         return self.stage_shapes()[-1][0]
 
-    def variable_spec(self):
-        """Ordered (name, shape, initializer-kind, trainable)."""
-        k, u = self.kernel_size, self.lstm_units
-        spec = [("conv0/kernel", (k, k, 1, ENTRY_FILTERS), "he", True), ("conv0/bias", (ENTRY_FILTERS,), "zeros", True)]
+    conv_kind = "he"  # he_normal: orcai-V1's conv_initializer (models/orcai-V1/orcai_parameter.json:13)
+
+    def _trunk_spec(self):
+        k, ck = self.kernel_size, self.conv_kind
+        spec = [("conv0/kernel", (k, k, 1, ENTRY_FILTERS), ck, True), ("conv0/bias", (ENTRY_FILTERS,), "zeros", True)]
         spec += self._bn_spec("bn0", ENTRY_FILTERS)
         c = ENTRY_FILTERS
         for b, s in enumerate(self.filters, start=1):
-            spec += [(f"b{b}/sep_a/depthwise", (k, k, c, 1), "he", True), (f"b{b}/sep_a/pointwise", (1, 1, c, s), "he", True), (f"b{b}/sep_a/bias", (s,), "zeros", True)]
+            spec += [(f"b{b}/sep_a/depthwise", (k, k, c, 1), ck, True), (f"b{b}/sep_a/pointwise", (1, 1, c, s), ck, True), (f"b{b}/sep_a/bias", (s,), "zeros", True)]
             spec += self._bn_spec(f"b{b}/bn_a", s)
-            spec += [(f"b{b}/sep_b/depthwise", (k, k, s, 1), "he", True), (f"b{b}/sep_b/pointwise", (1, 1, s, s), "he", True), (f"b{b}/sep_b/bias", (s,), "zeros", True)]
+            spec += [(f"b{b}/sep_b/depthwise", (k, k, s, 1), ck, True), (f"b{b}/sep_b/pointwise", (1, 1, s, s), ck, True), (f"b{b}/sep_b/bias", (s,), "zeros", True)]
             spec += self._bn_spec(f"b{b}/bn_b", s)
-            spec += [(f"b{b}/res/kernel", (1, 1, c, s), "he", True), (f"b{b}/res/bias", (s,), "zeros", True)]
+            spec += [(f"b{b}/res/kernel", (1, 1, c, s), ck, True), (f"b{b}/res/bias", (s,), "zeros", True)]
             c = s
-        spec += [("sep_f/depthwise", (k, k, c, 1), "he", True), ("sep_f/pointwise", (1, 1, c, FINAL_FILTERS), "he", True), ("sep_f/bias", (FINAL_FILTERS,), "zeros", True)]
+        spec += [("sep_f/depthwise", (k, k, c, 1), ck, True), ("sep_f/pointwise", (1, 1, c, FINAL_FILTERS), ck, True), ("sep_f/bias", (FINAL_FILTERS,), "zeros", True)]
         spec += self._bn_spec("bn_f", FINAL_FILTERS)
+        return spec
+
+    def _head_spec(self):
+        u = self.lstm_units
+        spec = []
         feat = self.stage_shapes()[-1][1] * FINAL_FILTERS
         for layer, fin in ((1, feat), (2, 2 * u)):
             for d in ("fwd", "bwd"):
@@ -134,6 +140,10 @@ class ResNetLSTM:
         spec += self._bn_spec("bn_d", DENSE_UNITS)
         spec += [("dense2/kernel", (DENSE_UNITS, self.num_labels), "glorot", True), ("dense2/bias", (self.num_labels,), "zeros", True)]
         return spec
+
+    def variable_spec(self):
+        """Ordered (name, shape, initializer-kind, trainable)."""
+        return self._trunk_spec() + self._head_spec()
 
     @staticmethod
     def _bn_spec(name, c):
@@ -150,8 +160,9 @@ class ResNetLSTM:
                     fan_in = shape[0]
                 std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
                 w = np.clip(rng.standard_normal(shape), -2.0, 2.0) * std
-            elif kind == "glorot":
-                limit = math.sqrt(6.0 / (shape[0] + shape[1]))
+            elif kind == "glorot":  # keras fans: receptive field x in / out channels for conv kernels
+                rf = int(np.prod(shape[:-2]))
+                limit = math.sqrt(6.0 / (rf * shape[-2] + rf * shape[-1]))
                 w = rng.uniform(-limit, limit, shape)
             elif kind == "orthogonal":
                 a = rng.standard_normal((shape[1], shape[0]))
@@ -245,19 +256,7 @@ class ResNetLSTM:
             d[f"b{b}/res/w"] = self._upload(w[f"b{b}/res/kernel"][0, 0])
             d[f"b{b}/res/b"] = self._upload(w[f"b{b}/res/bias"])
         sep("sep_f", "bn_f")
-        perm = lstm_column_permutation(self.lstm_units)
-        for layer in (1, 2):
-            ks = [w[f"lstm{layer}/{dd}/kernel"][:, perm] for dd in ("fwd", "bwd")]
-            bs = [w[f"lstm{layer}/{dd}/bias"][perm] for dd in ("fwd", "bwd")]
-            us = [w[f"lstm{layer}/{dd}/recurrent"][:, perm] for dd in ("fwd", "bwd")]
-            d[f"lstm{layer}/W"] = self._upload(np.concatenate(ks, axis=1))  # [Fin][2*4u]
-            d[f"lstm{layer}/b"] = self._upload(np.concatenate(bs))
-            d[f"lstm{layer}/U"] = self._upload(np.stack(us))  # [2][u][4u]
-        d["dense1/W"] = self._upload(w["dense1/kernel"])
-        d["dense1/b"] = self._upload(w["dense1/bias"])
-        d["dense1/scale"], d["dense1/shift"] = self._fold_bn("bn_d")
-        d["dense2/W"] = self._upload(w["dense2/kernel"])
-        d["dense2/b"] = self._upload(w["dense2/bias"])
+        self._prepare_head(d)
         self._dev = d
         return d
 
@@ -286,6 +285,22 @@ class ResNetLSTM:
             ws[f"prev{b}"] = planes(f, shapes[b][0], shapes[b][1])
         self._ws = {B: ws}  # keep only the largest chunk size resident
         return ws
+
+    def _prepare_head(self, d: dict) -> None:
+        w = self.weights
+        perm = lstm_column_permutation(self.lstm_units)
+        for layer in (1, 2):
+            ks = [w[f"lstm{layer}/{dd}/kernel"][:, perm] for dd in ("fwd", "bwd")]
+            bs = [w[f"lstm{layer}/{dd}/bias"][perm] for dd in ("fwd", "bwd")]
+            us = [w[f"lstm{layer}/{dd}/recurrent"][:, perm] for dd in ("fwd", "bwd")]
+            d[f"lstm{layer}/W"] = self._upload(np.concatenate(ks, axis=1))  # [Fin][2*4u]
+            d[f"lstm{layer}/b"] = self._upload(np.concatenate(bs))
+            d[f"lstm{layer}/U"] = self._upload(np.stack(us))  # [2][u][4u]
+        d["dense1/W"] = self._upload(w["dense1/kernel"])
+        d["dense1/b"] = self._upload(w["dense1/bias"])
+        d["dense1/scale"], d["dense1/shift"] = self._fold_bn("bn_d")
+        d["dense2/W"] = self._upload(w["dense2/kernel"])
+        d["dense2/b"] = self._upload(w["dense2/bias"])
 
     def _launch(self, label: str, what: str, fn, *args) -> None:
         """Call one C-ABI launcher; optionally bracket it with HIP events on the launch stream (bench.py)."""
@@ -466,8 +481,45 @@ def res_net_LSTM_arch(input_shape, num_labels, filters, kernel_size, dropout_rat
     return ResNetLSTM(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units, conv_initializer, lstm_initializer, **unused)
 
 
-def res_net_1Dconv_arch(*args, **kwargs):
-    raise NotImplementedError("ResNet1DConv (architectures.py:18-117) is not on the orcai-V1 hot path yet (SURVEY 8f row 1)")
+class ResNet1DConv(ResNetLSTM):
+    """CNN with residual connections + frequency mean + one Conv1D over time (architectures.py:18-117).  The convolutional trunk
+    is the ResNetLSTM one (the per-block Dropout layers are the identity at inference); the head is ReduceFrequencyMean
+    (:10-15) and Conv1D(num_labels, kernel_size = 36, "same", sigmoid) (:107-115).  Inference only: compile/fit raise."""
+
+    architecture = "ResNet1DConv"
+    conv_kind = "glorot"  # conv_initializer default "glorot_uniform" (architectures.py:24)
+
+    def __init__(self, input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, conv_initializer="glorot_uniform", seed=None, **unused):
+        super().__init__(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units=128, conv_initializer=conv_initializer, seed=seed)
+
+    def _head_spec(self):
+        k1 = FINAL_FILTERS  # k_size = x.shape[2] after the frequency mean = the channel count (architectures.py:108)
+        return [("conv1d/kernel", (k1, FINAL_FILTERS, self.num_labels), self.conv_kind, True), ("conv1d/bias", (self.num_labels,), "zeros", True)]
+
+    def _prepare_head(self, d: dict) -> None:
+        d["conv1d/W"] = self._upload(self.weights["conv1d/kernel"])
+        d["conv1d/b"] = self._upload(self.weights["conv1d/bias"])
+
+    def head_device(self, feat: torch.Tensor, out: torch.Tensor, keep: dict | None = None) -> None:
+        lib = N.lib()
+        d = self.prepare()
+        st = N.stream_ptr()
+        n, h, fin = int(feat.shape[0]), int(feat.shape[1]), int(feat.shape[2])
+        wd = fin // FINAL_FILTERS
+        fm = torch.empty((n, h, FINAL_FILTERS), dtype=torch.float32, device=feat.device)
+        self._launch("freq_mean", "orcai_freq_mean", lib.orcai_freq_mean, N.ptr(feat), n * h, wd, FINAL_FILTERS, N.ptr(fm), st)
+        self._launch("conv1d", "orcai_conv1d_sigmoid", lib.orcai_conv1d_sigmoid, N.ptr(fm), N.ptr(d["conv1d/W"]), N.ptr(d["conv1d/b"]), n, h, FINAL_FILTERS,
+                     FINAL_FILTERS, self.num_labels, out.data_ptr(), st)
+        if keep is not None:
+            keep.update({"feat": feat.clone(), "freq_mean": fm.clone()})
+
+    def compile(self, *args, **kwargs):
+        raise NotImplementedError("ResNet1DConv: only the inference path is built (training kernels cover ResNetLSTM, the orcai-V1 architecture)")
+
+
+def res_net_1Dconv_arch(input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, conv_initializer="glorot_uniform", **unused) -> ResNet1DConv:
+    """architectures.py:18-117."""
+    return ResNet1DConv(input_shape, num_labels, filters, kernel_size, dropout_rate, conv_initializer, **unused)
 
 
 ORCAI_ARCHITECTURES_FN = {"ResNet1DConv": res_net_1Dconv_arch, "ResNetLSTM": res_net_LSTM_arch}

@@ -988,6 +988,42 @@ __global__ __launch_bounds__(256) void overlap_average_kernel(const float* __res
 
 inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }  // __umulhi(n, magic) == n / d while n*d < 2^32
 
+// ---------------------------------------------------------------- ResNet1DConv head (architectures.py:10-15, 107-115)
+// ReduceFrequencyMean on the Keras Reshape layout: out[m][c] = mean over x of feat[m][x*C + c]
+__global__ __launch_bounds__(256) void freq_mean_kernel(const float* __restrict__ feat, int64_t M, int W, int C, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * C) return;
+  const int64_t m = i / C;
+  const int c = (int)(i - m * C);
+  const float* src = feat + m * (int64_t)W * C + c;
+  float s = 0.0f;
+  for (int x = 0; x < W; ++x) s += src[(int64_t)x * C];
+  out[i] = s / (float)W;
+}
+
+// Conv1D over time, "same" padding ((K-1)/2 left, K/2 right), sigmoid: one workgroup per snippet, x[T][C] staged in LDS,
+// thread (t, l) accumulates K*C products in the order (k, c).
+__global__ __launch_bounds__(512) void conv1d_sigmoid_kernel(const float* __restrict__ x /*[B][T][C]*/, const float* __restrict__ w /*[K][C][L]*/,
+                                                             const float* __restrict__ bias, int T, int C, int K, int L, float* __restrict__ out /*[B][T][L]*/) {
+  extern __shared__ float xs[];  // [T][C]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < T * C; i += blockDim.x) xs[i] = x[(int64_t)b * T * C + i];
+  __syncthreads();
+  const int left = (K - 1) / 2;
+  for (int o = threadIdx.x; o < T * L; o += blockDim.x) {
+    const int t = o / L, l = o - t * L;
+    float acc = bias[l];
+    for (int k = 0; k < K; ++k) {
+      const int tt = t + k - left;
+      if (tt < 0 || tt >= T) continue;
+      const float* xr = xs + tt * C;
+      const float* wr = w + (int64_t)k * C * L + l;
+      for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[(int64_t)c * L], acc);
+    }
+    out[((int64_t)b * T + t) * L + l] = 1.0f / (1.0f + __expf(-acc));
+  }
+}
+
 struct SepArgs {
   const float *in, *dw, *pw, *scale, *shift;
   float* out;
@@ -1021,6 +1057,20 @@ int launch_sepconv(hipStream_t st, const SepArgs& a) {
 }  // namespace
 
 extern "C" {
+
+int orcai_freq_mean(const float* feat, int64_t M, int W, int C, float* out, void* stream) {
+  if (!feat || !out || M <= 0 || W <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(freq_mean_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, feat, M, W, C, out);
+  return (int)hipGetLastError();
+}
+
+int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int B, int T, int C, int K, int L, float* out, void* stream) {
+  if (!x || !w || !bias || !out || B <= 0 || T <= 0 || C <= 0 || K <= 0 || L <= 0) return ORCAI_E_BADARG;
+  const size_t lds = (size_t)T * C * sizeof(float);
+  if (lds > 64 * 1024) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(conv1d_sigmoid_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, x, w, bias, T, C, K, L, out);
+  return (int)hipGetLastError();
+}
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 

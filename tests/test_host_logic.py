@@ -152,3 +152,20 @@ def test_resample_table_design():
     assert t.shape == (320, 128) and t.dtype == np.float32
     assert abs(float(t[0].astype(np.float64).sum()) - 1.0) < 1e-3  # unity DC gain
     assert design_table(1, 2).shape[1] == 256  # down-sampling widens the filter
+
+
+def test_architecture_registry_builds_both_architectures():
+    """architectures.py:307-359: both registered architectures construct (host side only: no kernels run)."""
+    from orcai_amd.architectures import ORCAI_ARCHITECTURES, build_model
+
+    assert ORCAI_ARCHITECTURES == ["ResNet1DConv", "ResNetLSTM"]
+    base = {"name": "t", "calls": ["A", "B", "C"], "model": {"filters": [10, 20], "kernel_size": 3, "dropout_rate": 0.4, "lstm_units": 64}}
+    lstm = build_model((64, 20, 1), dict(base, architecture="ResNetLSTM"))
+    conv = build_model((64, 20, 1), dict(base, architecture="ResNet1DConv"))  # lstm_units is swallowed by **unused, as in the reference
+    assert lstm.output_shape == conv.output_shape == (None, 16, 3)
+    assert conv.count_params() < lstm.count_params()
+    assert conv.weights["conv1d/kernel"].shape == (36, 36, 3)
+    import pytest
+
+    with pytest.raises(ValueError):
+        build_model((64, 20, 1), dict(base, architecture="nope"))

@@ -135,3 +135,41 @@ def test_fused_block_variants_match_unfused(variant):
     out = model.predict(x, batch_size=3)
     assert np.abs(out - ref).max() <= 2e-6
     assert np.abs(out - M.forward_ref(p, x)).max() <= 1e-5
+
+
+def make_1dconv(seed, input_shape, filters, kernel_size, num_labels=7):
+    """Calibrated trunk parameters of the oracle + a glorot Conv1D head (architectures.py:107-115)."""
+    from orcai_amd.architectures import FINAL_FILTERS, ResNet1DConv
+
+    p = M.calibrated_params(seed=seed, input_shape=input_shape, num_labels=num_labels, filters=filters, kernel_size=kernel_size, lstm_units=64)
+    p = {k: v for k, v in p.items() if not k.startswith(("lstm", "dense", "bn_d"))}
+    rng = np.random.default_rng(seed + 100)
+    lim = np.sqrt(6.0 / (FINAL_FILTERS * FINAL_FILTERS + FINAL_FILTERS * num_labels))
+    p["conv1d/kernel"] = rng.uniform(-lim, lim, (FINAL_FILTERS, FINAL_FILTERS, num_labels)).astype(np.float32)
+    p["conv1d/bias"] = (0.1 * rng.standard_normal(num_labels)).astype(np.float32)
+    model = ResNet1DConv(input_shape, num_labels, list(filters), kernel_size, 0.3)
+    model.set_weights_dict(p)
+    return model, p
+
+
+@pytest.mark.parametrize("input_shape,filters,k", [((736, 171, 1), (30, 40, 50, 60), 3), ((96, 20, 1), (10, 20), 5)])
+def test_resnet_1dconv_forward(input_shape, filters, k):
+    """ResNet1DConv = same trunk + ReduceFrequencyMean + Conv1D(k = 36, same, sigmoid); |delta p| <= 1e-5."""
+    model, p = make_1dconv(7, input_shape, filters, k)
+    H, W, _ = input_shape
+    steps = H // 2 ** len(filters)
+    assert model.output_shape == (None, steps, 7) and model.architecture == "ResNet1DConv"
+    rng = np.random.default_rng(2)
+    x = rng.random((3, H, W, 1), dtype=np.float32)
+    ref, inter = M.forward_ref_1dconv(p, x, return_intermediates=True)
+    xd = torch.from_numpy(x[..., 0].copy()).cuda()
+    out = torch.empty((3, steps, 7), dtype=torch.float32, device="cuda")
+    keep = {}
+    model.forward_device(xd.view(-1), H * W, 3, out, keep=keep)
+    close(keep["freq_mean"].cpu().numpy(), inter["freq_mean"])
+    o = out.cpu().numpy()
+    assert np.abs(o - ref).max() <= 1e-5, np.abs(o - ref).max()
+    assert np.abs(o - M.forward_ref_1dconv(p, x, dtype=torch.float64)).max() <= 1e-5
+    assert np.abs(model.predict(x, batch_size=2) - ref).max() <= 1e-5  # the keras-shaped entry point
+    with pytest.raises(NotImplementedError):
+        model.compile()
