@@ -1,6 +1,6 @@
 """``orcai`` command line for the hot path.  Same subcommand names, arguments and option flags as the
-reference's ``src/orcAI/cli.py`` for the four in-scope commands (predict :93-184, create-spectrograms
-:359-416, train :630-677, hpsearch :732-788); the data-preparation subcommands are out of scope.
+reference's ``src/orcAI/cli.py`` for the in-scope commands (predict :93-184, create-spectrograms
+:359-416, train :630-677, test :680-729, hpsearch :732-788); the data-preparation subcommands are out of scope.
 Workflow modules are imported lazily, like the reference does.
 """
 
@@ -102,6 +102,24 @@ def cli_hpsearch(**kwargs):
     from orcai_amd.hpsearch import hyperparameter_search
 
     hyperparameter_search(**kwargs)
+
+
+@cli.command(name="test", short_help="Tests a model.", no_args_is_help=True, epilog=EPILOG,
+             help="Tests a model at MODEL_DIR on the test dataset in DATA_DIR and saves the results to OUTPUT_DIR.")
+@click.argument("model_dir", type=DirR)
+@click.argument("data_dir", type=DirR)
+@click.option("--test_unfiltered", "-tu", is_flag=True, help="If set, the model is also tested on the unfiltered test dataset.")
+@click.option("--output_dir", "-o", type=DirWcreate, default=None, show_default="None", help="Path to the output directory. None to save in the same directory as the model.")
+@click.option("--data_compression", "-dc", type=click.Choice(["GZIP", "None"], case_sensitive=False), default="GZIP", show_default=True, help="Data compression of saved datasets")
+@click.option("--verbosity", "-v", type=click.IntRange(0, 3), default=2, show_default=True, help="0: Errors only, 1: Warnings, 2: Info, 3: Debug")
+def cli_test(**kwargs):
+    """cli.py:680-729."""
+    kwargs["msgr"] = Messenger(verbosity=kwargs["verbosity"], title=f"Testing model {kwargs['model_dir'].name}")
+    if kwargs["data_compression"] == "None":
+        kwargs["data_compression"] = None
+    from orcai_amd.test import test_model
+
+    test_model(**kwargs)
 
 
 if __name__ == "__main__":

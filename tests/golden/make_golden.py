@@ -10,7 +10,8 @@ The reference's third-party dependencies that are absent from this image
 modules *before* import; only the reference's own numpy/pandas functions are
 executed (preprocess_spectrogram, compute_aggregated_predictions,
 compute_binary_predictions, compute_labels, find_consecutive_ones,
-save_predictions, filter_predictions) plus ``numpy.percentile`` itself for the
+save_predictions, filter_predictions, and test.py's compute_confusion_table /
+compute_misclassification_tables with the real scikit-learn) plus ``numpy.percentile`` itself for the
 virtual-index table.  Outputs are data only -- no reference source or bytecode
 is written anywhere.
 """
@@ -238,6 +239,35 @@ def gen_consecutive(A):
     (HERE / "consecutive_ones.json").write_text(json.dumps({"mask_value": float(A.MASK_VALUE), "cases": out}, indent=1))
 
 
+def gen_test_tables():
+    """orcai test (test.py:37-225): confusion table and both misclassification tables on a seeded label / probability batch."""
+    import orcAI.test as Tm
+
+    rng = np.random.default_rng(4242)
+    B, T, L = 40, 46, 7
+    y_true = np.zeros((B, T, L), dtype=np.float32)
+    hot = rng.integers(0, L + 3, size=(B, T))  # values >= L: no label in that row
+    for l in range(L):
+        y_true[..., l] = hot == l
+    extra = rng.random((B, T)) < 0.03  # a few rows with two labels (dropped by the at-most-one-1 mask)
+    y_true[..., 1][extra] = 1.0
+    for b in range(0, B, 3):  # one label column masked in a third of the snippets
+        y_true[b, :, (b // 3) % L] = -1.0
+    y_pred = np.clip(0.15 + 0.7 * (y_true == 1) + 0.25 * rng.standard_normal((B, T, L)), 0.0, 1.0).astype(np.float32)
+    y_pred[0, 0, 0] = 0.5  # exactly the threshold: counted as predicted (>=)
+    conf = Tm.compute_confusion_table(y_true, y_pred, CALLS)
+    stacked_true = Tm._stack_batch(y_true)
+    stacked_pred = Tm._stack_batch((y_pred >= 0.5).astype(int))
+    mis = Tm.compute_misclassification_tables(stacked_true, stacked_pred, "true", "pred", CALLS)
+    # values as float64 arrays (exact); row / column labels in the json
+    np.savez_compressed(HERE / "test_tables.npz", y_true=y_true, y_pred=y_pred, confusion=conf.to_numpy(dtype=np.float64),
+                        **{"mis_" + k: v.to_numpy(dtype=np.float64) for k, v in mis.items()})
+    out = {"confusion": {"index": list(conf.index), "columns": list(conf.columns)},
+           "misclassification": {k: {"index": list(v.index), "columns": list(v.columns)} for k, v in mis.items()}}
+    (HERE / "test_tables.json").write_text(json.dumps(out, indent=1))
+    print("test tables", conf.shape, {k: v.shape for k, v in mis.items()})
+
+
 def main():
     S, P, A = import_reference()
     gen_preprocess(S)
@@ -245,6 +275,7 @@ def main():
     gen_aggregate(P)
     gen_labels(P)
     gen_consecutive(A)
+    gen_test_tables()
 
 
 if __name__ == "__main__":

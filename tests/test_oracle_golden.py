@@ -98,3 +98,21 @@ def test_consecutive_ones(golden_dir):
     for c in j["cases"]:
         s, e = P.find_consecutive_ones_ref(np.array(c["input"]))
         assert list(s) == c["starts"] and list(e) == c["stops"]
+
+
+def test_orcai_test_tables_match_reference(golden_dir):
+    """test.py:37-225 (confusion table, both misclassification tables) against tables the reference's own functions produced
+    (scikit-learn confusion_matrix included) on a seeded batch with masked columns, double labels and a probability of exactly 0.5."""
+    from orcai_amd.test import _stack_batch, compute_confusion_table, compute_misclassification_tables
+
+    with np.load(golden_dir / "test_tables.npz") as z:
+        g = {k: z[k] for k in z.files}
+    want = json.loads((golden_dir / "test_tables.json").read_text())
+    conf = compute_confusion_table(g["y_true"], g["y_pred"], CALLS)
+    assert list(conf.index) == want["confusion"]["index"] and list(conf.columns) == want["confusion"]["columns"]
+    assert np.array_equal(conf.to_numpy(dtype=np.float64), g["confusion"], equal_nan=True)
+    mis = compute_misclassification_tables(_stack_batch(g["y_true"]), _stack_batch((g["y_pred"] >= 0.5).astype(int)), "true", "pred", CALLS)
+    assert sorted(mis) == sorted(want["misclassification"])
+    for key, table in mis.items():
+        assert list(table.index) == want["misclassification"][key]["index"] and list(table.columns) == want["misclassification"][key]["columns"]
+        assert np.array_equal(table.to_numpy(dtype=np.float64), g["mis_" + key], equal_nan=True), key

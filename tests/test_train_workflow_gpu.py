@@ -168,3 +168,41 @@ def test_hyperband_and_tiny_search(tmp_path):
 
     trials = pd.read_csv(out / "hps_logs" / "all_trials.csv")
     assert len(trials) >= 4 and {"filters", "score", "status", "val_MBA"} <= set(trials.columns)
+
+
+def test_orcai_test_command_after_training(tmp_path):
+    """SURVEY 8f row 3 (`orcai test`, test.py:318-420): train a tiny model, evaluate it on test / unfiltered-test datasets through
+    the CLI; the saved confusion table equals the table computed from the oracle's forward pass on the same snippets."""
+    import pandas as pd
+    from click.testing import CliRunner
+
+    from oracle import model_ref as M
+    from orcai_amd.cli import cli
+    from orcai_amd.datasets import make_synthetic_dataset
+    from orcai_amd.io import load_orcai_model
+    from orcai_amd.test import compute_confusion_table
+    from orcai_amd.train import train
+
+    d = _data(tmp_path, n_train=32, n_val=8)
+    make_synthetic_dataset(d / "test_dataset", 24, seed=6, input_shape=(32, 12), out_steps=8, n_labels=3)
+    make_synthetic_dataset(d / "test_unfiltered_dataset", 16, seed=7, input_shape=(32, 12), out_steps=8, n_labels=3)
+    out = tmp_path / "out"
+    out.mkdir()
+    train(d, out, _param(epochs=1), verbosity=0)
+    mdir = out / "orcai-v1"
+    res = CliRunner().invoke(cli, ["test", str(mdir), str(d), "-tu", "-o", str(tmp_path / "results"), "-v", "0"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    for name in ("test_data", "test_unfiltered_dataset"):
+        for suffix in ("_metrics.json", "_confusion_table.csv", "_misclassification_table_true_pred.csv", "_misclassification_table_pred_true.csv"):
+            assert (tmp_path / "results" / (name + suffix)).exists(), name + suffix
+    metrics = json.loads((tmp_path / "results" / "test_data_metrics.json").read_text())
+    assert set(metrics) >= {"loss", "MBA"} and np.isfinite(metrics["loss"])
+    # same table from the CPU oracle's probabilities (batch 8 divides 24: every snippet is evaluated exactly once)
+    model, _, _ = load_orcai_model(mdir)
+    x, y = np.load(d / "test_dataset" / "spectrogram.npy"), np.load(d / "test_dataset" / "labels.npy")
+    probs = M.forward_ref(model.weights, x[..., None] if x.ndim == 3 else x)
+    want = compute_confusion_table(y, probs, ["A", "B", "C"])
+    got = pd.read_csv(tmp_path / "results" / "test_data_confusion_table.csv", index_col="Label")
+    near = np.abs(probs - 0.5) < 1e-4  # a probability this close to the threshold may flip between fp32 implementations
+    if not near.any():
+        assert np.allclose(got.loc[want.index].to_numpy(dtype=np.float64), want.to_numpy(dtype=np.float64), rtol=0, atol=1e-12, equal_nan=True)
