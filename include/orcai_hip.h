@@ -222,6 +222,14 @@ int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void
 int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
                        int relu, float* out, void* stream);
 
+/* Training-data path (replaces DataLoader.__getitem__ io.py:128-147 + reshape_labels io.py:101-126 and the
+ * materialised tf.data snapshot io.py:187-218).  store: [total_rows][cols] f32 resident in HBM (recordings concatenated along time);
+ * row_starts: device int64[B], first store row of each snippet (caller guarantees start + rows <= total_rows).
+ * orcai_gather_snippets: out[b] = rows [start_b, start_b + rows) of the store, as [B][rows][cols].
+ * orcai_downsample_labels: out[b][s][l] = round_half_even(mean over the `factor` rows of group s); rows % factor != 0 -> BADARG. */
+int orcai_gather_snippets(const float* store, const int64_t* row_starts, int B, int rows, int cols, float* out, void* stream);
+int orcai_downsample_labels(const float* labels, const int64_t* row_starts, int B, int rows, int L, int factor, float* out, void* stream);
+
 /* ResNet1DConv head (architectures.py:10-15 ReduceFrequencyMean, :107-115 Conv1D(num_labels, kernel_size = 36, "same", sigmoid)).
  * orcai_freq_mean: feat [M][W*C] in the Keras Reshape layout (feature = x*C + c) -> out [M][C] = mean over x.
  * orcai_conv1d_sigmoid: x [B][T][C], w [K][C][L] (Keras Conv1D kernel layout), bias [L] -> out [B][T][L];

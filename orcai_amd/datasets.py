@@ -125,3 +125,113 @@ def make_synthetic_dataset(path: Path | str, n: int, seed: int = 4, input_shape=
         if rng.random() < 0.3:
             y[i, :, int(rng.integers(n_labels))] = -1.0
     save_dataset(np.clip(x, 0, 1), y, path, overwrite=overwrite)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM-resident snippet store: the snippet table indexes rows of per-recording arrays; nothing is
+# materialised.  Replaces DataLoader (io.py:17-147) + Dataset.save/load (io.py:150-218) for training.
+# ------------------------------------------------------------------------------------------------------------------
+def snippet_rows(times_meta: dict, t_start: float, snippet_duration: float, n_filters: int) -> tuple[int, int]:
+    """Index arithmetic of ``_make_snippet_table`` (snippets.py:98-133): the spectrogram time axis is
+    ``linspace(min, max, length)``; a snippet starting at ``t_start`` covers rows
+    ``[searchsorted(times, t_start, "left") - 1,  + 2**n * ((snippet_duration / delta_t) // 2**n))``."""
+    times = np.linspace(times_meta["min"], times_meta["max"], times_meta["length"])
+    delta_t = times[1] - times[0]
+    f = 2**n_filters
+    n_steps = int(f * ((snippet_duration / delta_t) // f))
+    start = int(np.searchsorted(times, t_start, side="left") - 1)
+    return start, start + n_steps
+
+
+class RecordingStore:
+    """Spectrogram [T,W] and label [T,L] arrays of many recordings, concatenated along time and resident in HBM.
+    On disk (the stand-in for spectrogram.zarr / labels.zarr, io.py:296-331): ``<dir>/spectrogram/spectrogram.npy`` and
+    ``<dir>/labels/labels.npy``."""
+
+    def __init__(self, recording_dirs, device=None):
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.offsets: dict[str, int] = {}
+        self.lengths: dict[str, int] = {}
+        specs, labs = [], []
+        total = 0
+        for d in dict.fromkeys(str(x) for x in recording_dirs):  # unique, first-seen order
+            s = np.load(Path(d) / "spectrogram" / "spectrogram.npy", mmap_mode="r")
+            lab = np.load(Path(d) / "labels" / "labels.npy", mmap_mode="r")
+            if s.shape[0] != lab.shape[0]:
+                raise ValueError(f"{d}: spectrogram has {s.shape[0]} rows, labels {lab.shape[0]}")
+            self.offsets[d], self.lengths[d] = total, int(s.shape[0])
+            total += int(s.shape[0])
+            specs.append(torch.from_numpy(np.array(s, dtype=np.float32)))  # np.array copies out of the read-only memory map
+            labs.append(torch.from_numpy(np.array(lab, dtype=np.float32)))
+        self.spec = torch.cat(specs).to(self.device)
+        self.labels = torch.cat(labs).to(self.device)
+        self.total_rows = total
+
+    def global_rows(self, recording_dirs, row_start, row_stop) -> np.ndarray:
+        """Store row of the first row of every snippet; bounds are checked here, on the host, once."""
+        start = np.asarray(row_start, dtype=np.int64)
+        stop = np.asarray(row_stop, dtype=np.int64)
+        out = np.empty(len(start), dtype=np.int64)
+        for i, d in enumerate(recording_dirs):
+            d = str(d)
+            if start[i] < 0 or stop[i] > self.lengths[d] or stop[i] <= start[i]:
+                raise IndexError(f"snippet {i}: rows [{start[i]}, {stop[i]}) outside recording {d} of {self.lengths[d]} rows")
+            out[i] = self.offsets[d] + start[i]
+        return out
+
+
+class SnippetTableDataset:
+    """Batches (spectrogram cuda f32 [B][H][W], labels cuda f32 [B][H/2**n][L]) gathered on the GPU from a RecordingStore by the
+    kernels of csrc/datapath.hip.  ``snippet_table``: DataFrame with columns recording_data_dir, row_start, row_stop (the table
+    DataLoader takes, io.py:20-37).  Same iteration contract as SnippetDataset (shuffle buffer, drop remainder, rank slicing)."""
+
+    def __init__(self, snippet_table, n_filters: int, batch_size: int, seed=None, shuffle: bool = True, rank: int = 0, world_size: int = 1,
+                 store: RecordingStore | None = None):
+        from orcai_amd import _native as N
+
+        self._N = N
+        self.lib = N.lib()
+        dirs = [str(d) for d in snippet_table["recording_data_dir"]]
+        self.store = store if store is not None else RecordingStore(dirs)
+        lengths = (np.asarray(snippet_table["row_stop"], dtype=np.int64) - np.asarray(snippet_table["row_start"], dtype=np.int64))
+        if len(lengths) and not np.all(lengths == lengths[0]):
+            raise ValueError("all snippets must have the same number of rows")
+        self.rows = int(lengths[0]) if len(lengths) else 0
+        self.factor = 2**n_filters
+        if self.rows % self.factor:
+            raise ValueError("The number of rows in 'arr' must be divisible by 2**'n_filters'.")  # io.py:123-126
+        self.starts = torch.from_numpy(self.store.global_rows(dirs, snippet_table["row_start"], snippet_table["row_stop"])).to(self.store.device)
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1)[0])
+        self.epoch = 0
+        self.rank, self.world_size = rank, world_size
+
+    def __len__(self) -> int:
+        return (len(self.starts) // self.batch_size) // self.world_size
+
+    _order = SnippetDataset._order
+
+    @property
+    def x(self):  # SnippetDataset._order only needs len(self.x)
+        return self.starts
+
+    def batch(self, idx: torch.Tensor):
+        N, lib, st = self._N, self.lib, self.store
+        B = int(idx.numel())
+        W, L = int(st.spec.shape[1]), int(st.labels.shape[1])
+        starts = self.starts[idx].contiguous()
+        x = torch.empty((B, self.rows, W), dtype=torch.float32, device=st.device)
+        y = torch.empty((B, self.rows // self.factor, L), dtype=torch.float32, device=st.device)
+        s = N.stream_ptr()
+        N.check(lib.orcai_gather_snippets(st.spec.data_ptr(), starts.data_ptr(), B, self.rows, W, x.data_ptr(), s), "orcai_gather_snippets")
+        N.check(lib.orcai_downsample_labels(st.labels.data_ptr(), starts.data_ptr(), B, self.rows, L, self.factor, y.data_ptr(), s), "orcai_downsample_labels")
+        return x, y
+
+    def __iter__(self):
+        order = self._order()
+        self.epoch += 1
+        nb = len(order) // self.batch_size
+        batches = [order[i * self.batch_size : (i + 1) * self.batch_size] for i in range(nb)]
+        for idx in batches[self.rank :: self.world_size][: len(self)]:
+            yield self.batch(torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.store.device))

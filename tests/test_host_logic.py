@@ -128,7 +128,7 @@ def test_predict_rejects_bad_suffix_and_existing_output(tmp_path):
 
 
 def test_cli_surface_matches_reference_options():
-    """Option flags of the four in-scope subcommands (reference cli.py:93-184, 359-416, 630-677, 732-788)."""
+    """Option flags of the in-scope subcommands (reference cli.py:93-184, 359-416, 630-677, 680-729, 732-788)."""
     from orcai_amd.cli import cli
 
     expect = {
@@ -136,6 +136,7 @@ def test_cli_surface_matches_reference_options():
         "create-spectrograms": {"-bdr", "-p", "-en", "-enp", "-ow", "-v"},
         "train": {"-p", "-dc", "-lm", "-v"},
         "hpsearch": {"-p", "-hp", "-pl", "-dc", "-v"},
+        "test": {"-tu", "-o", "-dc", "-v"},
     }
     assert set(cli.commands) == set(expect)
     for name, flags in expect.items():
@@ -169,3 +170,21 @@ def test_architecture_registry_builds_both_architectures():
 
     with pytest.raises(ValueError):
         build_model((64, 20, 1), dict(base, architecture="nope"))
+
+
+def test_snippet_row_arithmetic_matches_numpy_restatement():
+    """snippets.py:98-133: row_start = searchsorted(linspace(min, max, length), t_start, 'left') - 1, row_stop = row_start + steps."""
+    from orcai_amd.datasets import snippet_rows
+
+    meta = {"min": 0.0, "max": 11250 * 256 / 48000, "length": 11251}
+    times = np.linspace(meta["min"], meta["max"], meta["length"])
+    dt = times[1] - times[0]
+    assert int(16 * ((4 / dt) // 16)) == 736  # orcai-V1: 4 s snippets -> 736 frames
+    rng = np.random.default_rng(0)
+    for t in list(rng.uniform(0, 50, 200)) + [0.0, float(times[5]), float(times[5]) + 1e-12, float(np.nextafter(times[5], 0))]:
+        a, b = snippet_rows(meta, t, 4, 4)
+        assert b - a == 736
+        assert a == int(np.searchsorted(times, t, side="left")) - 1
+        if a >= 0:
+            assert times[a] < t <= times[a + 1] or t <= times[0]
+    assert snippet_rows(meta, 0.0, 4, 4)[0] == -1  # the reference's own edge: t_start exactly 0 indexes row -1 (snippets.py:128)
