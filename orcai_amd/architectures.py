@@ -83,6 +83,10 @@ class ResNetLSTM:
         self.fuse_min_width = int(os.environ.get("ORCAI_FUSE_MIN_WIDTH", "0")) or 10**9
         self.fuse_variant = os.environ.get("ORCAI_FUSE_VARIANT", "rows")
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
+        # Inference trunk in two phases: blocks < tail_from_block in chunks of `chunk` snippets (their planes are large), the
+        # later blocks (planes of a few thousand pixels: a chunk of 128 snippets is < 2 waves per SIMD) over up to tail_chunk snippets.
+        self.tail_from_block = int(os.environ.get("ORCAI_TAIL_FROM_BLOCK", "3"))
+        self.tail_chunk = int(os.environ.get("ORCAI_TAIL_CHUNK", "2048"))
 
     # ------------------------------------------------------------------ structure
     @property
@@ -263,12 +267,15 @@ class ResNetLSTM:
     def padded_width(self, w: int) -> int:
         return (w + self.kernel_size // 2 + 3) & ~3
 
-    def _buffers(self, B: int) -> dict:
-        """Zero-padded activation planes for a trunk chunk of B snippets (see "Padded plane layout" in
-        csrc/model_fwd.hip).  Allocated ZEROED once for the largest chunk seen; the kernels never write the pads."""
-        for cap, ws in self._ws.items():  # planes are snippet-major: a smaller chunk uses the head of a larger workspace
-            if cap >= B:
-                return ws
+    def _buffers(self, B: int, first: int = 1, last: int | None = None, need_input: bool = True) -> dict:
+        """Zero-padded activation planes of residual blocks first..last for a trunk chunk of B snippets (see "Padded plane
+        layout" in csrc/model_fwd.hip).  Allocated ZEROED once for the largest chunk seen; the kernels never write the pads.
+        `prev{first-1}` (the input of block `first`) is included when need_input."""
+        last = len(self.filters) if last is None else last
+        key = (first, last)
+        have = self._ws.get(key)
+        if have is not None and have[0] >= B:  # planes are snippet-major: a smaller chunk uses the head of a larger workspace
+            return have[1]
         shapes = self.stage_shapes()
         dev = torch.device("cuda", torch.cuda.current_device())
         R = self.kernel_size // 2
@@ -276,14 +283,17 @@ class ResNetLSTM:
         def planes(c, h, w):  # [B][channel quad][HP][WP][4]
             return torch.zeros((B, (c + 3) // 4, h + 2 * R, self.padded_width(w), 4), dtype=torch.float32, device=dev)
 
-        ws = {"prev0": planes(ENTRY_FILTERS, shapes[0][0], shapes[0][1])}
-        for b, f in enumerate(self.filters, start=1):
+        ws = {}
+        if need_input:
+            ws[f"prev{first - 1}"] = planes(shapes[first - 1][2], shapes[first - 1][0], shapes[first - 1][1])
+        for b in range(first, last + 1):
+            f = self.filters[b - 1]
             h, wd, _ = shapes[b - 1]
             ws[f"a{b}"] = planes(f, h, wd)
             wx = (wd + 1) // 2  # x-pooled output of the block's second separable conv: [B][CQ][H][roundup4(ceil(W/2))][4]
             ws[f"b{b}"] = torch.zeros((B, (f + 3) // 4, h, (wx + 3) & ~3, 4), dtype=torch.float32, device=dev)
             ws[f"prev{b}"] = planes(f, shapes[b][0], shapes[b][1])
-        self._ws = {B: ws}  # keep only the largest chunk size resident
+        self._ws[key] = (B, ws)
         return ws
 
     def _prepare_head(self, d: dict) -> None:
@@ -314,20 +324,27 @@ class ResNetLSTM:
         e1.record()
         ev.setdefault(label, []).append((e0, e1))
 
-    def trunk_device(self, src: torch.Tensor, snippet_stride: int, B: int, feat: torch.Tensor, keep: dict | None = None) -> None:
-        """Convolutional trunk for one chunk of B snippets: entry conv, the residual separable-conv blocks, final
-        separable conv; writes the LSTM input features feat[B][steps][W_last*36]."""
+    def trunk_device(self, src: torch.Tensor, snippet_stride: int, B: int, feat: torch.Tensor, keep: dict | None = None, first: int = 0,
+                     last: int | None = None, ws: dict | None = None) -> dict:
+        """Convolutional trunk for one chunk of B snippets, stages first..last: stage 0 = entry conv, b = residual block b,
+        len(filters)+1 = final separable conv (writes the LSTM input features feat[B][steps][W_last*36]).  Returns the workspace
+        (its `prev{last}` planes are the input of stage last+1)."""
         lib = N.lib()
         d = self.prepare()
-        ws = self._buffers(B)
+        nb = len(self.filters)
+        last = nb + 1 if last is None else last
+        if ws is None:
+            ws = self._buffers(B, max(first, 1), min(last, nb))
         st = N.stream_ptr()
         H, W = self.input_hw
         k = self.kernel_size
         shapes = self.stage_shapes()
-        self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]),
-                     N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(ws["prev0"]), st)
-        c = ENTRY_FILTERS
-        for b, f in enumerate(self.filters, start=1):
+        if first == 0:
+            self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]),
+                         N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(ws["prev0"]), st)
+        for b in range(max(first, 1), min(last, nb) + 1):
+            f = self.filters[b - 1]
+            c = shapes[b - 1][2]
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
@@ -344,11 +361,10 @@ class ResNetLSTM:
                              N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
                          N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 1, st)
-            c = f
-        h, wd, _ = shapes[-1]
-        last = ws[f"prev{len(self.filters)}"]
-        self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(last), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]),
-                     N.ptr(d["sep_f/scale"]), N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, feat.data_ptr(), st)
+        if last == nb + 1:
+            h, wd, c = shapes[-1]
+            self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(ws[f"prev{nb}"]), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]),
+                         N.ptr(d["sep_f/scale"]), N.ptr(d["sep_f/shift"]), FINAL_FILTERS, 1, 1, feat.data_ptr(), st)
         if keep is not None:  # test hook: planes back to [B][C][H][W]
             R = k // 2
             chans = {"prev0": ENTRY_FILTERS}
@@ -371,6 +387,7 @@ class ResNetLSTM:
                 pads = full.clone()
                 pads[:, : chans[name], R : R + hh, : widths[name]] = 0
                 keep[name + "/pads"] = pads
+        return ws
 
     def head_device(self, feat: torch.Tensor, out: torch.Tensor, keep: dict | None = None) -> None:
         """Both BiLSTM layers, Dense(128)+BN and Dense(labels)+sigmoid for ALL n snippets at once
@@ -405,9 +422,24 @@ class ResNetLSTM:
         (bounds activation memory); the recurrent head runs once over all n."""
         steps, wd, _ = self.stage_shapes()[-1]
         feat = torch.empty((n, steps, wd * FINAL_FILTERS), dtype=torch.float32, device=src.device)
-        for s in range(0, n, chunk):
-            B = min(chunk, n - s)
-            self.trunk_device(src[s * snippet_stride :], snippet_stride, B, feat[s:], keep=keep if s == 0 else None)
+        nb = len(self.filters)
+        split = self.tail_from_block  # blocks >= split (small planes) run over `tail_chunk` snippets per launch to fill the chip
+        if keep is not None or split > nb or n <= chunk:
+            for s in range(0, n, chunk):
+                B = min(chunk, n - s)
+                self.trunk_device(src[s * snippet_stride :], snippet_stride, B, feat[s:], keep=keep if s == 0 else None)
+        else:
+            big = min(n, self.tail_chunk)
+            tail = self._buffers(big, split, nb, need_input=True)  # its prev{split-1} planes receive the head stages' output
+            carry = tail[f"prev{split - 1}"]
+            for t0 in range(0, n, big):
+                nt = min(big, n - t0)
+                for s in range(t0, t0 + nt, chunk):
+                    B = min(chunk, t0 + nt - s)
+                    head = dict(self._buffers(B, 1, split - 1))
+                    head[f"prev{split - 1}"] = carry[s - t0 :]  # the last head stage writes straight into the tail's input planes
+                    self.trunk_device(src[s * snippet_stride :], snippet_stride, B, None, first=0, last=split - 1, ws=head)
+                self.trunk_device(None, snippet_stride, nt, feat[t0:], first=split, last=nb + 1, ws=tail)
         self.head_device(feat, out, keep=keep)
 
     def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 128, shard: bool = False) -> torch.Tensor:
