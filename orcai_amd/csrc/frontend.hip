@@ -24,6 +24,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 #include <cstring>
 #include <mutex>
 
@@ -170,18 +171,19 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
   float pmax = 0.0f;
 
   const int64_t n_groups = (n_frames + 15) >> 4;
-  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
+  // One group of 4 frames per wave.  FAST (compile-time): hop 256, all 4 frames inside the recording, the 1280 samples they
+  // cover inside the PCM array and 16-byte aligned -> no per-element predicates anywhere in the body.
+  auto process = [&](auto fast_tag, int64_t t0w) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const int64_t t = t0w + fsub;
-    const bool valid = t < n_frames;
+    const bool valid = FAST ? true : (t < n_frames);
     const int64_t s0 = t * (int64_t)hop - (NFFT / 2);
 
     float re[16], im[16];
     // The wave's 4 frames cover padded samples [hop*t0w, hop*(t0w+3) + 512): for the default hop 256 that is one
     // contiguous run of 1280 floats, fetched as 5 dwordx4 per lane (1 KiB per instruction) into the wave's tile.
     const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);  // first sample the wave needs
-    const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
-    if (fast) {
+    if constexpr (FAST) {
       float* st = reinterpret_cast<float*>(my_tile);
       const float4* gp = reinterpret_cast<const float4*>(pcm + w0);
 #pragma unroll
@@ -275,6 +277,13 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
     for (int i = (n4 << 2) + lane; i < count; i += 64) dst[i] = src[i];
     wave_lds_fence();
+  };
+  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
+    const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);
+    const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
+    if (fast) process(std::true_type{}, t0w);  // wave-uniform
+    else process(std::false_type{}, t0w);
   }
 
   // wave max -> one atomic per wave

@@ -114,6 +114,10 @@ def compute_aggregated_predictions(recording_path: Path, spectrogram, model, orc
     n_filters = len(orcai_parameter["model"]["filters"])
     n_frames = int(spectrogram.shape[0])
     num_snippets = (n_frames - snippet_length) // shift + 1
+    if num_snippets <= 0:
+        # predict.py:244-268 is unguarded here: the empty snippet array reaches model.predict and Keras raises on its shape.
+        # Same outcome (an exception, caught per recording in table mode, predict.py:752-755), with a usable message.
+        raise ValueError(f"recording too short: {n_frames} spectrogram frames, one snippet needs {snippet_length}")
     msgr.info(f"slicing into {num_snippets} snippets for prediction")
     msgr.info("Prediction of snippets")
     native = hasattr(model, "predict_spectrogram")

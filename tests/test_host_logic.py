@@ -188,3 +188,21 @@ def test_snippet_row_arithmetic_matches_numpy_restatement():
         if a >= 0:
             assert times[a] < t <= times[a + 1] or t <= times[0]
     assert snippet_rows(meta, 0.0, 4, 4)[0] == -1  # the reference's own edge: t_start exactly 0 indexes row -1 (snippets.py:128)
+
+
+def test_recording_shorter_than_one_snippet_raises():
+    """predict.py:244-268: T < 736 gives zero (or -1) snippets and the reference fails inside model.predict; here a ValueError."""
+    import pytest
+
+    from orcai_amd.auxiliary import Messenger
+    from orcai_amd.predict import compute_aggregated_predictions
+
+    class Fake:
+        def predict(self, snippets, verbose=0):
+            raise AssertionError("must not be reached")
+
+    param = {"model": {"filters": [30, 40, 50, 60]}}
+    shape = {"input_shape": [736, 171, 1], "num_labels": 7}
+    for T in (735, 500, 368, 10):
+        with pytest.raises(ValueError, match="too short"):
+            compute_aggregated_predictions(Path("x.wav"), np.zeros((T, 171), dtype=np.float32), Fake(), param, shape, msgr=Messenger(verbosity=0))
