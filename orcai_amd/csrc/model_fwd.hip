@@ -795,11 +795,15 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
 // =========================================================================================
 constexpr int GP = 128 + 16;  // LDS pitch: rows k and k+1 16 banks apart
 
+constexpr int GBK = 32;
+
+// 128 x 128 x 32 tiles; the next tile's global loads (16 bytes per lane where alignment allows) are in flight in registers
+// while the MFMAs of the current tile run; A is transposed into LDS as [k][m].
 __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ bias,
                                                     const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ C,
-                                                    int M, int N, int K, int act) {
-  __shared__ float As[16][GP];
-  __shared__ float Bs[16][GP];
+                                                    int M, int N, int K, int act, int vec) {
+  __shared__ __attribute__((aligned(16))) float As[GBK][GP];
+  __shared__ __attribute__((aligned(16))) float Bs[GBK][GP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lk = lane >> 4, lj = lane & 15;
@@ -811,29 +815,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // A tile: 128 rows x 16 k; thread loads 8 consecutive k of one row half
-    {
-      const int row = tid >> 1, kh = (tid & 1) * 8;
-      const int64_t m = m0 + row;
+  float4 ra[4], rb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = k0 + kh + q;
-        As[kh + q][row] = (m < M && k < K) ? A[m * K + k] : 0.0f;
+    for (int g = 0; g < 4; ++g) {
+      const int f = tid + 256 * g;
+      {  // A: row m = f & 127, k group (f >> 7) * 4
+        const int64_t m = m0 + (f & 127);
+        const int k = k0 + (f >> 7) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+          const float* p = A + m * K + k;
+          if (vec && k + 3 < K) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (k + e < K) ? p[e] : 0.0f;
+          }
+        }
+        ra[g] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      {  // B: k row f >> 5, n group (f & 31) * 4
+        const int k = k0 + (f >> 5), n = n0 + (f & 31) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+          const float* p = Bm + (int64_t)k * N + n;
+          if (vec && n + 3 < N) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (n + e < N) ? p[e] : 0.0f;
+          }
+        }
+        rb[g] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    // B tile: 16 k x 128 n; thread loads 8 consecutive n of one k row
-    {
-      const int k = tid >> 4, nn = (tid & 15) * 8;
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += GBK) {
+    __syncthreads();  // previous tile consumed
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int n = n0 + nn + q;
-        Bs[k][nn + q] = (k0 + k < K && n < N) ? Bm[(int64_t)(k0 + k) * N + n] : 0.0f;
-      }
+    for (int g = 0; g < 4; ++g) {
+      const int f = tid + 256 * g;
+      const int m = f & 127, k = (f >> 7) * 4;
+      As[k][m] = ra[g].x; As[k + 1][m] = ra[g].y; As[k + 2][m] = ra[g].z; As[k + 3][m] = ra[g].w;
+      *reinterpret_cast<float4*>(&Bs[f >> 5][(f & 31) * 4]) = rb[g];
     }
     __syncthreads();
+    if (k0 + GBK < K) fetch(k0 + GBK);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < GBK / 4; ++kk) {
       float a[4], bq[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = As[kk * 4 + lk][wm * 64 + i * 16 + lj];
@@ -844,7 +877,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], bq[j], acc[i][j]);
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1215,7 +1247,8 @@ int orcai_gemm_bias_act(const float* A, const float* Bm, const float* bias, cons
                         int K, int act, void* stream) {
   if (!A || !Bm || !C || M <= 0 || N <= 0 || K <= 0 || (scale && !shift)) return ORCAI_E_BADARG;
   dim3 grid((N + 127) / 128, (unsigned)((M + 127) / 128));
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, Bm, bias, scale, shift, C, (int)M, N, K, act);
+  const int vec = (((uintptr_t)A | (uintptr_t)Bm) % 16 == 0 && K % 4 == 0 && N % 4 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, Bm, bias, scale, shift, C, (int)M, N, K, act, vec);
   return (int)hipGetLastError();
 }
 
