@@ -317,16 +317,20 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
   }
 }
 
+// D[i] += sum over the partial products: lanes run along i (coalesced), blockIdx.y takes one eighth of the partials and adds its
+// share with one atomic (8 adds per address).
 __global__ __launch_bounds__(256) void add_partials_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nparts; k += 4) {
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {
     s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 1) * n + i]; s2 += part[(int64_t)(k + 2) * n + i]; s3 += part[(int64_t)(k + 3) * n + i];
   }
-  for (; k < nparts; ++k) s0 += part[(int64_t)k * n + i];
-  D[i] += (s0 + s1) + (s2 + s3);
+  for (; k < k1; ++k) s0 += part[(int64_t)k * n + i];
+  if (k1 > k0) atomicAdd(&D[i], (s0 + s1) + (s2 + s3));
 }
 
 // ---------------------------------------------------------------- depthwise weight gradient
@@ -583,7 +587,7 @@ int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, i
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(outer_reduce_kernel, dim3((unsigned)grid), dim3(256), lds, st, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
                      a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
-  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Ca * Cb)), dim3(256), 0, st, workspace, (int)grid, Ca * Cb, D);
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Ca * Cb), 8), dim3(256), 0, st, workspace, (int)grid, Ca * Cb, D);
   return (int)hipGetLastError();
 }
 
