@@ -77,12 +77,11 @@ __device__ __forceinline__ float power_to_db(float p) {
 }
 // Monotone map key -> level-1 bucket: 128 buckets per octave for 0.125 <= |x| < 128, one bucket around 0.
 __device__ __forceinline__ int bucket1(uint32_t key) {
-  uint32_t k16 = key >> 16;
-  if (k16 < 0x3D00u) return 0;
-  if (k16 <= 0x41FFu) return (int)(k16 - 0x3D00u);
-  if (k16 < 0xBE00u) return 1280;
-  if (k16 <= 0xC2FFu) return 1281 + (int)(k16 - 0xBE00u);
-  return 2560;
+  // k16 <  0x3D00 -> 0;  0x3D00..0x41FF -> k16 - 0x3D00;  0x4200..0xBDFF -> 1280;  0xBE00..0xC2FF -> 1281 + (k16 - 0xBE00);  above -> 2560
+  const int k16 = (int)(key >> 16);
+  const int lo = min(max(k16 - 0x3D00, 0), 1280);
+  const int hi = 1281 + min(k16 - 0xBE00, 0x4FF);
+  return k16 >= 0xBE00 ? hi : lo;
 }
 __device__ __forceinline__ void bucket1_range(int b, uint32_t& klo, uint64_t& width) {
   if (b == 0) { klo = 0u; width = 0x3D010000ull; }
@@ -149,9 +148,14 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool EVEN_HOP>
+// FAST_ONLY: every group in [g_begin, g_end) is known (by the launcher) to satisfy the fast-path conditions for all four of its
+// waves, so the generic body is not even instantiated (134 VGPRs and no spills instead of 168 + spills).  KC > 0: k_crop is the
+// compile-time constant KC (171 for orcai-V1), which removes the per-bin crop branches from the real-FFT split.
+template <bool EVEN_HOP, bool FAST_ONLY, int KC>
 __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict__ pcm, int64_t n_samples, int hop, int64_t n_frames,
-                                                       int k_crop, float* __restrict__ out, Workspace* __restrict__ ws) {
+                                                       int k_crop_arg, float* __restrict__ out, Workspace* __restrict__ ws, int64_t g_begin,
+                                                       int64_t g_end) {
+  const int k_crop = KC > 0 ? KC : k_crop_arg;
   __shared__ StftLds lds;
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
@@ -170,7 +174,6 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
   unsigned char* my_frame = my_tile + fsub * FRAME_BYTES;
   float pmax = 0.0f;
 
-  const int64_t n_groups = (n_frames + 15) >> 4;
   // One group of 4 frames per wave.  FAST (compile-time): hop 256, all 4 frames inside the recording, the 1280 samples they
   // cover inside the PCM array and 16-byte aligned -> no per-element predicates anywhere in the body.
   auto process = [&](auto fast_tag, int64_t t0w) {
@@ -278,12 +281,16 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     for (int i = (n4 << 2) + lane; i < count; i += 64) dst[i] = src[i];
     wave_lds_fence();
   };
-  for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+  for (int64_t g = g_begin + blockIdx.x; g < g_end; g += gridDim.x) {
     const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
-    const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);
-    const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
-    if (fast) process(std::true_type{}, t0w);  // wave-uniform
-    else process(std::false_type{}, t0w);
+    if constexpr (FAST_ONLY) {
+      process(std::true_type{}, t0w);
+    } else {
+      const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);
+      const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
+      if (fast) process(std::true_type{}, t0w);  // wave-uniform
+      else process(std::false_type{}, t0w);
+    }
   }
 
   // wave max -> one atomic per wave
@@ -584,12 +591,39 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
   std::call_once(g_tables_once, init_tables);
   if (g_tables_err) return g_tables_err;
   const int64_t n_groups = (n_frames + 15) / 16;
-  int grid = (int)(n_groups < 256 * 3 ? n_groups : 256 * 3);
   Workspace* ws = (Workspace*)workspace;
-  if ((hop & 1) == 0)
-    hipLaunchKernelGGL(stft_db_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, hop, n_frames, k_crop, out_db, ws);
-  else
-    hipLaunchKernelGGL(stft_db_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, hop, n_frames, k_crop, out_db, ws);
+  hipStream_t st = (hipStream_t)stream;
+  auto grid_for_groups = [](int64_t n) { return dim3((unsigned)(n < 256 * 3 ? n : 256 * 3)); };
+  if ((hop & 1) != 0) {
+    hipLaunchKernelGGL((stft_db_kernel<false, false, 0>), grid_for_groups(n_groups), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws,
+                       (int64_t)0, n_groups);
+    return (int)hipGetLastError();
+  }
+  // Interior groups [g_lo, g_hi): all 16 frames exist and the samples of every wave lie inside the recording, 16-byte aligned
+  // (hop 256): t0w >= 1 for the first wave of the group, (16g + 12) * 256 + 1024 <= n_samples and 16g + 15 < n_frames for the last.
+  int64_t g_lo = n_groups, g_hi = n_groups;
+  if (hop == 256) {
+    g_lo = 1;
+    const int64_t by_samples = n_samples >= 4096 ? ((n_samples - 1024) / 256 - 12) / 16 + 1 : 0;  // groups g with (16g+12)*256+1024 <= n_samples
+    const int64_t by_frames = n_frames >= 16 ? (n_frames - 16) / 16 + 1 : 0;                       // groups g with 16g + 15 < n_frames
+    g_hi = by_samples < by_frames ? by_samples : by_frames;
+    if (g_hi > n_groups) g_hi = n_groups;
+    if (g_hi < g_lo) g_lo = g_hi = n_groups;  // no interior: everything goes through the mixed kernel
+  }
+  if (g_hi > g_lo) {
+    if (k_crop == 171)
+      hipLaunchKernelGGL((stft_db_kernel<true, true, 171>), grid_for_groups(g_hi - g_lo), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws, g_lo, g_hi);
+    else
+      hipLaunchKernelGGL((stft_db_kernel<true, true, 0>), grid_for_groups(g_hi - g_lo), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws, g_lo, g_hi);
+    if (g_lo > 0)
+      hipLaunchKernelGGL((stft_db_kernel<true, false, 0>), grid_for_groups(g_lo), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws, (int64_t)0, g_lo);
+    if (g_hi < n_groups)
+      hipLaunchKernelGGL((stft_db_kernel<true, false, 0>), grid_for_groups(n_groups - g_hi), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws, g_hi,
+                         n_groups);
+  } else {
+    hipLaunchKernelGGL((stft_db_kernel<true, false, 0>), grid_for_groups(n_groups), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws, (int64_t)0,
+                       n_groups);
+  }
   return (int)hipGetLastError();
 }
 
