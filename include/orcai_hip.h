@@ -230,6 +230,13 @@ int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, in
 int orcai_gather_snippets(const float* store, const int64_t* row_starts, int B, int rows, int cols, float* out, void* stream);
 int orcai_downsample_labels(const float* labels, const int64_t* row_starts, int B, int rows, int L, int factor, float* out, void* stream);
 
+/* Second half of a residual block in one launch (architectures.py:183-196): SepConv(C->C, k = 3)(a) -> BN (scale/shift) ->
+ * MaxPooling2D((3,2), 2, "same") + Conv2D(1x1, strides 2)(prev; wr [Cp][C], br [C]) -> out planes [B][CQ][H/2+2][WPo][4].
+ * The full-resolution output of the separable conv never goes to HBM.  k = 3 and even H only (UNSUPPORTED otherwise:
+ * use orcai_sepconv_bn(out_layout 2) + orcai_pool_res_add). */
+int orcai_sep_pool_res(const float* a, const float* prev, int B, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
+                       const float* scale, const float* shift, const float* wr, const float* br, float* out, void* stream);
+
 /* ResNet1DConv head (architectures.py:10-15 ReduceFrequencyMean, :107-115 Conv1D(num_labels, kernel_size = 36, "same", sigmoid)).
  * orcai_freq_mean: feat [M][W*C] in the Keras Reshape layout (feature = x*C + c) -> out [M][C] = mean over x.
  * orcai_conv1d_sigmoid: x [B][T][C], w [K][C][L] (Keras Conv1D kernel layout), bias [L] -> out [B][T][L];

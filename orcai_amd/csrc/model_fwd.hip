@@ -332,6 +332,173 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
 }
 
 // =========================================================================================
+// sep_pool_res: the second half of a residual block in one launch (architectures.py:183-196, k = 3, even H):
+//   a -> SepConv(F) -> BN -> MaxPooling2D((3,2), 2, "same")  +  Conv2D(1x1, strides 2)(prev) + bias
+// One wave owns pooled row i and a 64-lane window of image columns x = 60 w - 2 + lane (lanes 2..61 are outputs, windows
+// never wrap around a row, so row parity is the same for every lane).  The separable conv of the three pooling rows 2i, 2i+1,
+// 2i+2 is run row after row through the register-tile pipeline of sepconv_kernel and folded into a running maximum, so the
+// full-resolution activation never goes to HBM (the unfused pair writes 8 MB and reads it back per snippet in block 1).
+// Price: row 2i+2 is also row 0 of pooled row i+1 -> 1.5x the separable-conv arithmetic, and its input rows are re-read
+// from cache.  Then the column-pair maximum (one shfl_xor), the strided 1x1 residual as a second MFMA contraction on prev
+// at pixel (2i, x), the add, and one dwordx4 store per even lane.
+// =========================================================================================
+template <int MT>
+__global__ __launch_bounds__(256) void sep_pool_res_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int C, int H, int W, int WP, int relu_in,
+                                                            const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
+                                                            int Cp, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
+                                                            float* __restrict__ out /*[B][CQ][Ho+2][WPo][4]*/, int Ho, int Wo, int WPo, int nwin, int tasks) {
+  constexpr int KS = 3, KK = 9, R = 1, LO = 2, VAL = 64 - 2 * LO;
+  const int lane = threadIdx.x & 63;
+  int bx, b;
+  xcd_remap(bx, b);
+  const int task = bx * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;  // whole wave; no barriers
+  const int lk = lane >> 4, lj = lane & 15;
+  const int pi = task / nwin, win = task - pi * nwin;  // pooled row, window
+  const int x0 = win * VAL - LO;                        // image column of lane 0 (may be -2: the previous row's zero pad columns)
+  const int plane = (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
+  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
+  const float relu_lo = relu_in ? 0.0f : -INFINITY;
+
+  float sc_r[MT][4], sh_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      sc_r[m][r] = co < C ? scale[co] : 0.0f;
+      sh_r[m][r] = co < C ? shift[co] : 0.0f;
+    }
+  float mx[MT][4][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx[m][t][r] = -INFINITY;
+
+  f32x4 acc[MT][4];
+  for (int pr = 0; pr < 3; ++pr) {  // the three rows of the pooling window ("same": H is even, so only the bottom row can be padding)
+    const int y = 2 * pi + pr;
+    if (y >= H) break;
+    const int q = (y + R) * WP + x0 + lane;
+    int ridx[KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      const int i = q + (dy - R) * WP;
+      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 nxt[KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
+    for (int cq = 0; cq < CQ; ++cq) {
+      float4 cur[KS];
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) cur[dy] = nxt[dy];
+      if (cq + 1 < CQ) {
+        const float4* pn = src + (int64_t)(cq + 1) * plane;
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy) nxt[dy] = pn[ridx[dy]];
+      }
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < C && co < C;
+        const float av = pw[ok ? ci * C + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      float d[4];
+      dw_quad<KS>(cur, dw + cq * 4 * KK, relu_lo, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool inside = x0 + 16 * t + lj < W;  // columns past the image are the pooling's -inf padding (x0 + ... >= 0 for output lanes)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]);
+          mx[m][t][r] = inside ? fmaxf(mx[m][t][r], v) : mx[m][t][r];
+        }
+    }
+  }
+
+  // residual: 1x1 conv of prev at pixel (2 pi, x) -- lane = pixel, same transposes, into the (reset) accumulators
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    int qp = (2 * pi + R) * WP + x0 + lane;
+    qp = qp < 0 ? 0 : (qp >= plane ? plane - 1 : qp);
+    const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + qp;
+    float4 nx = pp[0];
+    for (int cq = 0; cq < CQp; ++cq) {
+      const float4 cur = nx;
+      if (cq + 1 < CQp) nx = pp[(int64_t)(cq + 1) * plane];
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ci = cq * 4 + lk, co = m * 16 + lj;
+        const bool ok = ci < Cp && co < C;
+        const float av = wr[ok ? ci * C + co : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      float d[4] = {cur.x, cur.y, cur.z, cur.w};
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+    }
+  }
+  float br_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      br_r[m][r] = co < C ? br[co] : 0.0f;
+    }
+  float4* outp = reinterpret_cast<float4*>(out) + (int64_t)b * CQ * plane_o + (int64_t)(pi + R) * WPo;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int wl = 16 * t + lj, x = x0 + wl;
+    const bool live = wl >= LO && wl < 64 - LO && x < W && (x & 1) == 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float other = __shfl_xor(mx[m][t][r], 1, 64);  // column x + 1 (-inf when it is past the image)
+        const float pooled = fmaxf(mx[m][t][r], other);
+        o[r] = (m * 16 + lk * 4 + r < C) ? pooled + (acc[m][t][r] + br_r[m][r]) : 0.0f;
+      }
+      const int oq = m * 4 + lk;
+      if (live && oq < CQ) outp[(int64_t)oq * plane_o + (x >> 1)] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// =========================================================================================
 // block_sep2: the two separable convolutions of a residual block fused (architectures.py:173-189), k = 3:
 //   x -> ReLU -> SepConv(F) -> BN -> ReLU  (= a, never written to HBM)  -> SepConv(F) -> BN -> column-pair max (x-pooled)
 // One workgroup (4 waves) owns a 64-column window x TH output rows of one snippet.  Phase 1: the waves compute the
@@ -1240,6 +1407,30 @@ int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, 
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_POOL_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int orcai_sep_pool_res(const float* a, const float* prev, int B, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
+                       const float* scale, const float* shift, const float* wr, const float* br, float* out, void* stream) {
+  if (!a || !prev || !dw || !pw || !scale || !shift || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (ksize != 3 || (H & 1) || C > 64 || Cp > 64) return ORCAI_E_UNSUPPORTED;  // odd H pads the pooling window at the top as well
+  const int WP = orcai_padded_width(W, ksize), Ho = H / 2, Wo = (W + 1) / 2, WPo = orcai_padded_width(Wo, ksize);
+  if ((int64_t)(H + 2) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  const int nwin = (W + 59) / 60;
+  const int tasks = Ho * nwin;
+  dim3 grid((tasks + 3) / 4, B);
+  hipStream_t st = (hipStream_t)stream;
+#define ORCAI_SPR(MT_)                                                                                                                            \
+  hipLaunchKernelGGL((sep_pool_res_kernel<MT_>), grid, dim3(256), 0, st, a, C, H, W, WP, relu_in, dw, pw, scale, shift, prev, Cp, wr, br, out, Ho, Wo, \
+                     WPo, nwin, tasks)
+  switch ((C + 15) / 16) {
+    case 1: ORCAI_SPR(1); break;
+    case 2: ORCAI_SPR(2); break;
+    case 3: ORCAI_SPR(3); break;
+    case 4: ORCAI_SPR(4); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_SPR
   return (int)hipGetLastError();
 }
 
