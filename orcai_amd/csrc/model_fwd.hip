@@ -135,16 +135,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // [k*k][4] (channel innermost, wave-uniform -> scalar loads); relu_lo = 0 (ReLU on load) or -inf.
 // By linearity the horizontal taps are applied to per-column partial sums: p_dx = sum_dy w[dy][dx] * a_dy (lane-local,
 // packed two channels per v_pk_fma_f32), d = sum_dx shift(p_dx, dx - R): k - 1 lane shifts per channel instead of k*(k-1).
-template <int KS>
-__device__ __forceinline__ void dw_quad(const float4 (&rows)[KS], const float* __restrict__ wq, float relu_lo, float (&d)[4]) {
+template <int KS, bool RELU>
+__device__ __forceinline__ void dw_quad_impl(const float4 (&rows)[KS], const float* __restrict__ wq, float (&d)[4]) {
   constexpr int R = KS / 2;
+  constexpr float relu_lo = 0.0f;
   f32x2 p01[KS], p23[KS];
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx) { p01[dx] = (f32x2){0.f, 0.f}; p23[dx] = (f32x2){0.f, 0.f}; }
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) {
-    const f32x2 a01 = {fmaxf(rows[dy].x, relu_lo), fmaxf(rows[dy].y, relu_lo)};
-    const f32x2 a23 = {fmaxf(rows[dy].z, relu_lo), fmaxf(rows[dy].w, relu_lo)};
+    const f32x2 a01 = {RELU ? fmaxf(rows[dy].x, relu_lo) : rows[dy].x, RELU ? fmaxf(rows[dy].y, relu_lo) : rows[dy].y};
+    const f32x2 a23 = {RELU ? fmaxf(rows[dy].z, relu_lo) : rows[dy].z, RELU ? fmaxf(rows[dy].w, relu_lo) : rows[dy].w};
 #pragma unroll
     for (int dx = 0; dx < KS; ++dx) {
       const float* w = wq + (dy * KS + dx) * 4;
@@ -172,6 +173,13 @@ __device__ __forceinline__ void dw_quad(const float4 (&rows)[KS], const float* _
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) d[j] = acc[j];
+}
+
+// relu_lo: 0 -> ReLU on load, -inf -> none (wave-uniform branch: the 12 v_max per quad are not issued when there is no ReLU)
+template <int KS>
+__device__ __forceinline__ void dw_quad(const float4 (&rows)[KS], const float* __restrict__ wq, float relu_lo, float (&d)[4]) {
+  if (relu_lo == 0.0f) dw_quad_impl<KS, true>(rows, wq, d);
+  else dw_quad_impl<KS, false>(rows, wq, d);
 }
 
 template <int KS, int MT>
