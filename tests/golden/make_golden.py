@@ -268,6 +268,33 @@ def gen_test_tables():
     print("test tables", conf.shape, {k: v.shape for k, v in mis.items()})
 
 
+def gen_label_raster():
+    """labels.py:18-123 on a crafted annotation file: intervals touching frame times exactly (inclusive bounds), overlapping
+    intervals of one label, a label present without annotations, masked labels, an original label missing from the equivalences."""
+    import tempfile
+
+    import orcAI.labels as Lb
+    from orcAI.auxiliary import Messenger
+
+    calls = ["BR", "BUZZ", "HERDING", "PHS", "SS"]
+    times = {"min": 0.0, "max": 299 * 256 / 48000, "length": 300}
+    t = np.linspace(times["min"], times["max"], times["length"])
+    rows = [(float(t[10]), float(t[20]), "br1"), (float(t[18]) + 1e-9, float(t[25]) - 1e-9, "br2"), (0.5, 0.52, "buzz"), (float(t[100]), float(t[100]), "ss"),
+            (1.2, 1.3, "unknown"), (float(t[298]), 5.0, "buzz"), (-1.0, float(t[0]), "ss")]
+    eq = {"br1": "BR", "br2": "BR", "buzz": "BUZZ", "ss": "SS"}
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        (d / "rec7" / "spectrogram").mkdir(parents=True)
+        (d / "rec7" / "spectrogram" / "times.json").write_text(json.dumps(times))
+        ann = d / "rec7.txt"
+        ann.write_text("".join(f"{a!r}\t{b!r}\t{c}\n" for a, b, c in rows))
+        arr, label_dict = Lb._convert_annotation(ann, d, calls, ["BR", "BUZZ", "SS", "PHS"], ["HERDING"], eq, Messenger(verbosity=0))
+    np.savez_compressed(HERE / "labels_raster.npz", array=arr.to_numpy(dtype=np.float64))
+    (HERE / "labels_raster.json").write_text(json.dumps({"calls": calls, "times": times, "rows": rows, "equivalences": eq, "present": ["BR", "BUZZ", "SS", "PHS"],
+                                                          "masked": ["HERDING"], "columns": list(arr.columns), "label_dict": label_dict}, indent=1))
+    print("label raster", arr.shape, arr.sum().to_dict())
+
+
 def main():
     S, P, A = import_reference()
     gen_preprocess(S)
@@ -276,6 +303,7 @@ def main():
     gen_labels(P)
     gen_consecutive(A)
     gen_test_tables()
+    gen_label_raster()
 
 
 if __name__ == "__main__":

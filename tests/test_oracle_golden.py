@@ -116,3 +116,30 @@ def test_orcai_test_tables_match_reference(golden_dir):
     for key, table in mis.items():
         assert list(table.index) == want["misclassification"][key]["index"] and list(table.columns) == want["misclassification"][key]["columns"]
         assert np.array_equal(table.to_numpy(dtype=np.float64), g["mis_" + key], equal_nan=True), key
+
+
+def test_label_rasterisation_matches_reference(golden_dir, tmp_path):
+    """labels.py:18-123 (`t_vec >= start & t_vec <= stop`, masked columns, call equivalences) against the array the reference's
+    own `_convert_annotation` produced; then the table driver writes the arrays the GPU data path loads."""
+    from orcai_amd.labels import _convert_annotation, create_label_arrays
+
+    g = json.loads((golden_dir / "labels_raster.json").read_text())
+    want = np.load(golden_dir / "labels_raster.npz")["array"]
+    (tmp_path / "rec7" / "spectrogram").mkdir(parents=True)
+    (tmp_path / "rec7" / "spectrogram" / "times.json").write_text(json.dumps(g["times"]))
+    ann = tmp_path / "rec7.txt"
+    ann.write_text("".join(f"{a!r}\t{b!r}\t{c}\n" for a, b, c in g["rows"]))
+    arr, label_dict = _convert_annotation(ann, tmp_path, g["calls"], g["present"], g["masked"], g["equivalences"])
+    assert list(arr.columns) == g["columns"] and label_dict == g["label_dict"]
+    assert np.array_equal(arr.to_numpy(dtype=np.float64), want)
+    with pytest.raises(KeyError):  # the reference only creates the label column when equivalences are given (labels.py:66-77)
+        _convert_annotation(ann, tmp_path, g["calls"], g["present"], g["masked"], None)
+    import pandas as pd
+
+    table = pd.DataFrame({"recording": ["rec7"], "base_dir_annotation": [str(tmp_path)], "rel_annotation_path": ["rec7.txt"],
+                          **{c: [c in g["present"]] for c in g["calls"]}})
+    table.to_csv(tmp_path / "table.csv", index=False)
+    create_label_arrays(tmp_path / "table.csv", tmp_path, orcai_parameter={"calls": g["calls"]}, call_equivalences=g["equivalences"], verbosity=0)
+    saved = np.load(tmp_path / "rec7" / "labels" / "labels.npy")
+    assert saved.dtype == np.float32 and np.array_equal(saved.astype(np.float64), want)
+    assert json.loads((tmp_path / "rec7" / "labels" / "label_list.json").read_text()) == g["label_dict"]
