@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_frontend -- python3 $R/bench.py --workload frontend --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_frontend.log 2>&1 && echo frontend-trace-ok && \
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 && echo fetch-ok && \
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1 && echo write-ok && \
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.log 2>&1 && echo mfma-ok && \
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_fe -- python3 $R/bench.py --workload frontend --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_fe.log 2>&1 && \
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_fe -- python3 $R/bench.py --workload frontend --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_fe.log 2>&1 && echo fe-pmc-ok
 find $O -name "*.csv" | head -40

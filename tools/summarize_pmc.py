@@ -22,19 +22,18 @@ def main():
     out = {}
     for d in sys.argv[1:]:
         for path in glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True):
-            per_dispatch = defaultdict(float)
+            per_dispatch = defaultdict(float)  # (counter, dispatch) -> value summed over the reported instances
             kern = {}
-            counter = None
             with open(path, newline="") as fh:
                 for row in csv.DictReader(fh):
-                    key = row["Dispatch_Id"]
+                    key = (row["Counter_Name"], row["Dispatch_Id"])
                     per_dispatch[key] += float(row["Counter_Value"])
-                    kern[key] = short(row["Kernel_Name"])
-                    counter = row["Counter_Name"]
-            agg = defaultdict(list)
-            for k, v in per_dispatch.items():
-                agg[kern[k]].append(v)
-            out.setdefault(counter, {}).update({k: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "total": sum(v)} for k, v in agg.items()})
+                    kern[row["Dispatch_Id"]] = short(row["Kernel_Name"])
+            agg = defaultdict(lambda: defaultdict(list))
+            for (counter, disp), v in per_dispatch.items():
+                agg[counter][kern[disp]].append(v)
+            for counter, per_kernel in agg.items():
+                out.setdefault(counter, {}).update({k: {"launches": len(v), "mean_per_launch": sum(v) / len(v), "total": sum(v)} for k, v in per_kernel.items()})
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 
