@@ -143,3 +143,26 @@ def test_label_rasterisation_matches_reference(golden_dir, tmp_path):
     saved = np.load(tmp_path / "rec7" / "labels" / "labels.npy")
     assert saved.dtype == np.float32 and np.array_equal(saved.astype(np.float64), want)
     assert json.loads((tmp_path / "rec7" / "labels" / "label_list.json").read_text()) == g["label_dict"]
+
+
+def test_stft_oracle_agrees_with_independent_implementations():
+    """The STFT stage has no reference fixture (librosa is absent: parity unpinned).  As a cross-check, the numpy restatement is
+    compared with two independent implementations of the same definition (centred, zero padding, periodic Hann, hop 256):
+    torch.stft in float64 and scipy.signal.stft rescaled; plus the frame-count formula T = 1 + N // hop (spectrogram.py:34-39)."""
+    import scipy.signal
+    import torch
+
+    rng = np.random.default_rng(3)
+    for n in (256 * 40, 256 * 40 + 1, 256 * 40 + 255, 700, 100):
+        y = (rng.standard_normal(n) * 0.2).astype(np.float32)
+        S = F.stft_ref(y)
+        assert S.shape == (257, 1 + n // 256) and S.dtype == np.complex64
+        win = torch.hann_window(512, periodic=True, dtype=torch.float64)
+        St = torch.stft(torch.from_numpy(y.astype(np.float64)), 512, hop_length=256, window=win, center=True, pad_mode="constant", return_complex=True).numpy()
+        assert St.shape == S.shape
+        assert np.abs(S - St).max() <= 1e-5 * max(1.0, np.abs(St).max())
+        if n >= 512:
+            _, _, Ss = scipy.signal.stft(y.astype(np.float64), window="hann", nperseg=512, noverlap=256, boundary="zeros", padded=False)
+            Ss = Ss * scipy.signal.get_window("hann", 512).sum()  # scipy normalises by the window sum
+            k = min(Ss.shape[1], S.shape[1])
+            assert np.abs(S[:, :k] - Ss[:, :k]).max() <= 1e-5 * max(1.0, np.abs(Ss).max())
