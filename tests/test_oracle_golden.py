@@ -166,3 +166,32 @@ def test_stft_oracle_agrees_with_independent_implementations():
             Ss = Ss * scipy.signal.get_window("hann", 512).sum()  # scipy normalises by the window sum
             k = min(Ss.shape[1], S.shape[1])
             assert np.abs(S[:, :k] - Ss[:, :k]).max() <= 1e-5 * max(1.0, np.abs(Ss).max())
+
+
+def test_lstm_oracle_agrees_with_torch_nn_lstm():
+    """The Keras layers have no fixture here (parity unpinned).  Cross-check of the oracle's Bidirectional(LSTM) restatement
+    (gate order i, f, c, o; one bias vector; backward direction returned in input time order; concat [fwd, bwd],
+    architectures.py:210-229) against torch.nn.LSTM, an independent implementation with the same gate order."""
+    import torch
+
+    from oracle import model_ref as M
+
+    rng = np.random.default_rng(9)
+    B, T, Fin, u = 3, 11, 20, 16
+    p = {}
+    for d in ("fwd", "bwd"):
+        p[f"l/{d}/kernel"] = (rng.standard_normal((Fin, 4 * u)) * 0.3).astype(np.float32)
+        p[f"l/{d}/recurrent"] = (rng.standard_normal((u, 4 * u)) * 0.3).astype(np.float32)
+        p[f"l/{d}/bias"] = (rng.standard_normal(4 * u) * 0.1).astype(np.float32)
+    x = rng.standard_normal((B, T, Fin)).astype(np.float32)
+    got = M._bilstm(torch.tensor(x, dtype=torch.float64), p, "l", torch.float64).numpy()
+    ref = torch.nn.LSTM(Fin, u, batch_first=True, bidirectional=True).double()
+    with torch.no_grad():
+        for d, suffix in (("fwd", ""), ("bwd", "_reverse")):
+            getattr(ref, "weight_ih_l0" + suffix).copy_(torch.tensor(p[f"l/{d}/kernel"].T, dtype=torch.float64))
+            getattr(ref, "weight_hh_l0" + suffix).copy_(torch.tensor(p[f"l/{d}/recurrent"].T, dtype=torch.float64))
+            getattr(ref, "bias_ih_l0" + suffix).copy_(torch.tensor(p[f"l/{d}/bias"], dtype=torch.float64))
+            getattr(ref, "bias_hh_l0" + suffix).zero_()
+        want = ref(torch.tensor(x, dtype=torch.float64))[0].numpy()
+    assert got.shape == want.shape == (B, T, 2 * u)
+    assert np.abs(got - want).max() <= 1e-12
