@@ -222,6 +222,13 @@ int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void
 int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
                        int relu, float* out, void* stream);
 
+/* ResNet1DConv head, backward (architectures.py:100-115; Keras differentiates these inside model.fit, train.py:201-219):
+ * orcai_freq_mean_bwd: dfeat[m][x*C + c] = dfm[m][c] / W (gradient of ReduceFrequencyMean on the Keras Reshape layout).
+ * orcai_conv1d_bwd: x [B][T][C], w [K][C][L], dz [B][T][L] = gradient at the pre-sigmoid output; dW [K][C][L] is ACCUMULATED
+ * (zero it first), dx [B][T][C] is written.  The bias gradient is the column sum of dz (orcai_colsum). */
+int orcai_freq_mean_bwd(const float* dfm, int64_t M, int W, int C, float* dfeat, void* stream);
+int orcai_conv1d_bwd(const float* x, const float* w, const float* dz, int B, int T, int C, int K, int L, float* dW, float* dx, void* stream);
+
 /* Training-data path (replaces DataLoader.__getitem__ io.py:128-147 + reshape_labels io.py:101-126 and the
  * materialised tf.data snapshot io.py:187-218).  store: [total_rows][cols] f32 resident in HBM (recordings concatenated along time);
  * row_starts: device int64[B], first store row of each snippet (caller guarantees start + rows <= total_rows).

@@ -113,6 +113,47 @@ def forward_train(p: dict, x_nhwc: torch.Tensor, masks: dict | None, rate: float
     return torch.sigmoid(x @ p["dense2/kernel"] + p["dense2/bias"]), new_stats
 
 
+def forward_train_1dconv(p: dict, x_nhwc: torch.Tensor, masks: dict | None, rate: float, n_blocks: int):
+    """ResNet1DConv in training mode (architectures.py:54-115): Dropout after every residual block (the residual branch of the
+    NEXT block reads the un-dropped tensor, :73-97), after the final BN+ReLU, then frequency mean and Conv1D(k = 36, same) + sigmoid.
+    masks: {'block1'.., 'final'} 0/1 tensors shaped like the NCHW tensors they multiply, or None for no dropout."""
+    new_stats = {}
+    keep = 1.0 - rate
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x = torch.relu(_bn_train(_conv_same(x, p["conv0/kernel"], p["conv0/bias"], 1), p, "bn0", new_stats))
+    prev = x
+    for b in range(1, n_blocks + 1):
+        x = torch.relu(x)
+        x = torch.relu(_bn_train(_sepconv(x, p, f"b{b}/sep_a"), p, f"b{b}/bn_a", new_stats))
+        x = _bn_train(_sepconv(x, p, f"b{b}/sep_b"), p, f"b{b}/bn_b", new_stats)
+        x = _maxpool_same(x)
+        x = x + _conv_same(prev, p[f"b{b}/res/kernel"], p[f"b{b}/res/bias"], 2)
+        prev = x
+        if masks is not None:
+            x = x * masks[f"block{b}"] / keep
+    x = torch.relu(_bn_train(_sepconv(x, p, "sep_f"), p, "bn_f", new_stats))
+    if masks is not None:
+        x = x * masks["final"] / keep
+    x = x.mean(dim=3).permute(0, 2, 1)  # (B, T', 36)
+    w = p["conv1d/kernel"]
+    K = w.shape[0]
+    xp = F.pad(x.permute(0, 2, 1), ((K - 1) // 2, K // 2))
+    y = F.conv1d(xp, w.permute(2, 1, 0).contiguous(), p["conv1d/bias"])
+    return torch.sigmoid(y.permute(0, 2, 1)), new_stats
+
+
+def loss_and_grads_1dconv(params_np: dict, x: np.ndarray, y: np.ndarray, masks_np: dict | None, rate: float, dtype=torch.float64):
+    """One forward + backward of ResNet1DConv (masked BCE; the architecture has no weight regularisers)."""
+    p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=is_trainable(k)) for k, v in params_np.items()}
+    n_blocks = sum(1 for k in p if k.endswith("/res/kernel"))
+    masks = None if masks_np is None else {k: torch.tensor(v, dtype=dtype) for k, v in masks_np.items()}
+    probs, new_stats = forward_train_1dconv(p, torch.tensor(x, dtype=dtype), masks, rate, n_blocks)
+    bce = masked_bce(torch.tensor(y, dtype=dtype), probs)
+    bce.backward()
+    grads = {k: v.grad.numpy() for k, v in p.items() if v.requires_grad}
+    return {"loss": float(bce.detach()), "bce": float(bce.detach()), "grads": grads, "probs": probs.detach().numpy(), "new_stats": {k: v.numpy() for k, v in new_stats.items()}}
+
+
 def masked_bce(y_true: torch.Tensor, y_pred: torch.Tensor, mask_value=-1.0) -> torch.Tensor:
     """architectures.py:262-270."""
     m = y_true != mask_value

@@ -526,7 +526,8 @@ def res_net_LSTM_arch(input_shape, num_labels, filters, kernel_size, dropout_rat
 class ResNet1DConv(ResNetLSTM):
     """CNN with residual connections + frequency mean + one Conv1D over time (architectures.py:18-117).  The convolutional trunk
     is the ResNetLSTM one (the per-block Dropout layers are the identity at inference); the head is ReduceFrequencyMean
-    (:10-15) and Conv1D(num_labels, kernel_size = 36, "same", sigmoid) (:107-115).  Inference only: compile/fit raise."""
+    (:10-15) and Conv1D(num_labels, kernel_size = 36, "same", sigmoid) (:107-115).  Training adds the Dropout after every block and
+    after BN_f (orcai_amd.training.Conv1DHeadTrainer, TrunkTrainer.block_masks)."""
 
     architecture = "ResNet1DConv"
     conv_kind = "glorot"  # conv_initializer default "glorot_uniform" (architectures.py:24)
@@ -554,9 +555,6 @@ class ResNet1DConv(ResNetLSTM):
                      FINAL_FILTERS, self.num_labels, out.data_ptr(), st)
         if keep is not None:
             keep.update({"feat": feat.clone(), "freq_mean": fm.clone()})
-
-    def compile(self, *args, **kwargs):
-        raise NotImplementedError("ResNet1DConv: only the inference path is built (training kernels cover ResNetLSTM, the orcai-V1 architecture)")
 
 
 def res_net_1Dconv_arch(input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, conv_initializer="glorot_uniform", **unused) -> ResNet1DConv:

@@ -595,6 +595,60 @@ __global__ __launch_bounds__(256) void lstm_hprev_kernel(const float* __restrict
   hp[i] = (tp >= 0 && tp < T) ? h[(b * T + tp) * (2 * U) + dir * U + u] : 0.0f;
 }
 
+// =========================================================================================
+// ResNet1DConv head, backward (architectures.py:100-115): ReduceFrequencyMean and Conv1D(num_labels, k, "same").
+// =========================================================================================
+// dfeat[m][x*C + c] = dfm[m][c] / W
+__global__ __launch_bounds__(256) void freq_mean_bwd_kernel(const float* __restrict__ dfm, int64_t M, int W, int C, float* __restrict__ dfeat) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * W * C) return;
+  const int64_t m = i / ((int64_t)W * C);
+  const int c = (int)(i % C);
+  dfeat[i] = dfm[m * C + c] / (float)W;
+}
+
+// dW[k][c][l] += sum_{b,t} x[b][t + k - left][c] * dz[b][t][l]      (one thread per weight; 2944 terms at batch 64)
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz, int B, int T, int C, int K, int L,
+                                                            float* __restrict__ dW) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * C * L) return;
+  const int l = i % L, c = (i / L) % C, k = i / (L * C);
+  const int left = (K - 1) / 2;
+  const int t_lo = left - k > 0 ? left - k : 0;                   // t + k - left >= 0
+  const int t_hi = T - 1 + left - k < T - 1 ? T - 1 + left - k : T - 1;  // t + k - left <= T - 1
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    const float* xb = x + ((int64_t)b * T + (k - left)) * C + c;
+    const float* zb = dz + (int64_t)b * T * L + l;
+    int t = t_lo;
+    for (; t + 1 <= t_hi; t += 2) {
+      s0 = fmaf(xb[(int64_t)t * C], zb[(int64_t)t * L], s0);
+      s1 = fmaf(xb[(int64_t)(t + 1) * C], zb[(int64_t)(t + 1) * L], s1);
+    }
+    if (t <= t_hi) s0 = fmaf(xb[(int64_t)t * C], zb[(int64_t)t * L], s0);
+  }
+  dW[i] += s0 + s1;
+}
+
+// dx[b][t][c] = sum_k sum_l W[k][c][l] * dz[b][t - k + left][l]
+__global__ __launch_bounds__(256) void conv1d_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dz, int B, int T, int C, int K, int L,
+                                                            float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * T * C) return;
+  const int c = (int)(i % C), t = (int)((i / C) % T);
+  const int64_t b = i / ((int64_t)C * T);
+  const int left = (K - 1) / 2;
+  float s = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    const int tz = t - k + left;
+    if (tz < 0 || tz >= T) continue;
+    const float* wr = w + ((int64_t)k * C + c) * L;
+    const float* zr = dz + (b * T + tz) * L;
+    for (int l = 0; l < L; ++l) s = fmaf(wr[l], zr[l], s);
+  }
+  dx[i] = s;
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -634,6 +688,20 @@ int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B,
   }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   hipLaunchKernelGGL(gemm_strided_kernel, grid, dim3(256), 0, st, A, sam, sak, B, sbk, sbn, C, M, N, K, alpha, accumulate, Wreg, beta_w);
+  return (int)hipGetLastError();
+}
+
+int orcai_freq_mean_bwd(const float* dfm, int64_t M, int W, int C, float* dfeat, void* stream) {
+  if (!dfm || !dfeat || M <= 0 || W <= 0 || C <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(freq_mean_bwd_kernel, dim3(blocks_for(M * W * C)), dim3(256), 0, (hipStream_t)stream, dfm, M, W, C, dfeat);
+  return (int)hipGetLastError();
+}
+
+int orcai_conv1d_bwd(const float* x, const float* w, const float* dz, int B, int T, int C, int K, int L, float* dW, float* dx, void* stream) {
+  if (!x || !w || !dz || !dW || !dx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || L <= 0) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(blocks_for((int64_t)K * C * L)), dim3(256), 0, st, x, dz, B, T, C, K, L, dW);
+  hipLaunchKernelGGL(conv1d_dgrad_kernel, dim3(blocks_for((int64_t)B * T * C)), dim3(256), 0, st, w, dz, B, T, C, K, L, dx);
   return (int)hipGetLastError();
 }
 

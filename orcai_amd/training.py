@@ -216,6 +216,69 @@ class HeadTrainer:
         return {"acc": acc, "dfeatv": dfeatv}
 
 
+class Conv1DHeadTrainer:
+    """ResNet1DConv head in training mode (architectures.py:100-115): BN_f + ReLU of the final separable conv (Keras Reshape
+    layout), Dropout, ReduceFrequencyMean, Conv1D(num_labels, k = 36, same) + sigmoid, masked BCE (no weight regularisers)."""
+
+    def __init__(self, model, params: FlatParams):
+        self.model, self.P = model, params
+        self.lib = N.lib()
+        self.cache = None
+
+    def forward(self, featv: torch.Tensor, masks: dict | None, rate: float) -> torch.Tensor:
+        lib, P, st = self.lib, self.P, N.stream_ptr()
+        n, T, cols = featv.shape
+        M, Wd = n * T, cols // FINAL_FILTERS
+        f32 = dict(dtype=torch.float32, device=featv.device)
+        keep = 1.0 - rate
+        c = {"featv": featv, "n": n, "T": T, "rate": rate, "masks": masks, "Wd": Wd}
+        c["f_mean"], c["f_var"] = torch.empty(FINAL_FILTERS, **f32), torch.empty(FINAL_FILTERS, **f32)
+        N.check(lib.orcai_bn_rows_stats(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), st), "bn_rows_stats")
+        x1 = torch.empty_like(featv)
+        N.check(lib.orcai_bn_rows_apply(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), P.W("bn_f/gamma").data_ptr(),
+                                        P.W("bn_f/beta").data_ptr(), BN_EPS, 1, x1.data_ptr(), st), "bn_rows_apply")
+        if masks is not None:
+            N.check(lib.orcai_mask_scale(x1.data_ptr(), masks["final"].data_ptr(), 1.0 / keep, x1.numel(), x1.data_ptr(), st), "mask_scale")
+        fm = torch.empty((n, T, FINAL_FILTERS), **f32)
+        N.check(lib.orcai_freq_mean(x1.data_ptr(), M, Wd, FINAL_FILTERS, fm.data_ptr(), st), "freq_mean")
+        L = self.model.num_labels
+        probs = torch.empty((n, T, L), **f32)
+        N.check(lib.orcai_conv1d_sigmoid(fm.data_ptr(), P.W("conv1d/kernel").data_ptr(), P.W("conv1d/bias").data_ptr(), n, T, FINAL_FILTERS, FINAL_FILTERS, L,
+                                         probs.data_ptr(), st), "conv1d_sigmoid")
+        c["fm"], c["probs"] = fm, probs
+        self.cache = c
+        return probs
+
+    def update_moving_stats(self) -> None:
+        c, S = self.cache, self.P.stats
+        S["bn_f/mean"].mul_(BN_MOMENTUM).add_(c["f_mean"], alpha=1 - BN_MOMENTUM)
+        S["bn_f/var"].mul_(BN_MOMENTUM).add_(c["f_var"], alpha=1 - BN_MOMENTUM)
+
+    def loss_and_backward(self, labels: torch.Tensor) -> dict:
+        lib, P, c, st = self.lib, self.P, self.cache, N.stream_ptr()
+        n, T, Wd = c["n"], c["T"], c["Wd"]
+        M, L = n * T, self.model.num_labels
+        f32 = dict(dtype=torch.float32, device=labels.device)
+        keep = 1.0 - c["rate"]
+        acc = torch.zeros(4, dtype=torch.float64, device=labels.device)  # bce sum, count, correct, l2 (stays 0)
+        dz = torch.empty((M, L), **f32)
+        N.check(lib.orcai_masked_bce(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz.data_ptr(), st), "masked_bce")
+        dfm = torch.empty((n, T, FINAL_FILTERS), **f32)
+        N.check(lib.orcai_conv1d_bwd(c["fm"].data_ptr(), P.W("conv1d/kernel").data_ptr(), dz.data_ptr(), n, T, FINAL_FILTERS, FINAL_FILTERS, L,
+                                     P.G("conv1d/kernel").data_ptr(), dfm.data_ptr(), st), "conv1d_bwd")  # the gradient buffer was zeroed at the start of the step
+        N.check(lib.orcai_colsum(dz.data_ptr(), M, L, P.G("conv1d/bias").data_ptr(), 0, st), "colsum")
+        dx1 = torch.empty_like(c["featv"])
+        N.check(lib.orcai_freq_mean_bwd(dfm.data_ptr(), M, Wd, FINAL_FILTERS, dx1.data_ptr(), st), "freq_mean_bwd")
+        if c["masks"] is not None:
+            N.check(lib.orcai_mask_scale(dx1.data_ptr(), c["masks"]["final"].data_ptr(), 1.0 / keep, dx1.numel(), dx1.data_ptr(), st), "mask_scale")
+        dfeatv = torch.empty_like(c["featv"])
+        cols = c["featv"].shape[2]
+        N.check(lib.orcai_bn_rows_bwd(dx1.data_ptr(), c["featv"].data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(),
+                                      P.W("bn_f/gamma").data_ptr(), P.W("bn_f/beta").data_ptr(), BN_EPS, 1, P.G("bn_f/beta").data_ptr(), P.G("bn_f/gamma").data_ptr(),
+                                      dfeatv.data_ptr(), st), "bn_rows_bwd")
+        return {"acc": acc, "dfeatv": dfeatv}
+
+
 def adam_step(params: FlatParams, lr: float, step: int, gscale: float = 1.0, b1=0.9, b2=0.999, eps=1e-7) -> None:
     N.check(N.lib().orcai_adam_step(params.w.data_ptr(), params.g.data_ptr(), params.m.data_ptr(), params.v.data_ptr(), params.n_trainable, lr, b1, b2, eps, step,
                                     gscale, N.stream_ptr()), "orcai_adam_step")
@@ -238,6 +301,9 @@ class TrunkTrainer:
         self.B = None
         self.consts = {}
         self.scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad, <= 64 channels
+        # ResNet1DConv drops out the output of every residual block (architectures.py:97); ResNetLSTM has no Dropout in the trunk
+        self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
+        self.block_masks = None  # list of 0/1 plane tensors (one per block) for the current step, or None
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
     # ------------------------------------------------------------- helpers
@@ -306,6 +372,8 @@ class TrunkTrainer:
             b[f"u_a{i}"], b[f"du_a{i}"] = self._planes(B, cprev, h, w), self._planes(B, cprev, h, w)  # depthwise output / its gradient (sep_a)
             b[f"u_b{i}"], b[f"du_b{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w)
             b[f"prev{i}"] = self._planes(B, f, shapes[i][0], shapes[i][1])
+            if self.block_rate > 0.0:
+                b[f"prevd{i}"] = self._planes(B, f, shapes[i][0], shapes[i][1])
             # gradient planes (only interiors are ever written, so the zero pads persist from step to step)
             b[f"dyb{i}"], b[f"dya{i}"], b[f"dr{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w), self._planes(B, cprev, h, w)
         h, w, c = shapes[-1]
@@ -329,21 +397,32 @@ class TrunkTrainer:
                                        0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
         self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
         prev, c = b["y0"], 16
+        res_in = prev
         self.dwl = {}
+        self.block_in = {}
         for i, f in enumerate(m.filters, start=1):
             h, w, _ = shapes[i - 1]
+            self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
             for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], b[f"yb{i}"], 0)):
                 name = f"b{i}/sep_{tag}"
                 self.dwl[name] = self._dw_kernel_layout(name + "/depthwise")
                 self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
                 self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y)
-            N.check(lib.orcai_pool_res_add(b[f"yb{i}"].data_ptr(), prev.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(), P.W(f"b{i}/res/bias").data_ptr(),
+            # the residual branch reads the block input BEFORE the previous block's Dropout (architectures.py:88-97)
+            N.check(lib.orcai_pool_res_add(b[f"yb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(), P.W(f"b{i}/res/bias").data_ptr(),
                                            b[f"prev{i}"].data_ptr(), 0, st), "orcai_pool_res_add")
             prev, c = b[f"prev{i}"], f
+            res_in = prev
+            if self.block_masks is not None:  # ResNet1DConv: Dropout after every block; the dropped tensor feeds the next separable conv only
+                dropped = b[f"prevd{i}"]
+                N.check(lib.orcai_mask_scale(prev.data_ptr(), self.block_masks[i - 1].data_ptr(), 1.0 / (1.0 - self.block_rate), prev.numel(), dropped.data_ptr(), st),
+                        "mask_scale")
+                prev = dropped
         h, w, _ = shapes[-1]
         self.dwl["sep_f"] = self._dw_kernel_layout("sep_f/depthwise")
         featv = torch.empty((B, h, w * FINAL_FILTERS), dtype=torch.float32, device=self.dev)
         self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1, u_out=b["u_f"])
+        self.final_in = prev
         return featv
 
     def update_moving_stats(self) -> None:
@@ -379,12 +458,15 @@ class TrunkTrainer:
         h, w, c = shapes[-1]
         N.check(lib.orcai_feat_to_planes(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
         dprev = b["dprev_f"]
-        self._sep_backward("sep_f", b[f"prev{L}"], 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
+        self._sep_backward("sep_f", self.final_in, 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
         for i in range(L, 0, -1):
             f = m.filters[i - 1]
             h, w, cprev = shapes[i - 1]
             ho, wo, _ = shapes[i]
-            prev = b[f"prev{i - 1}"] if i > 1 else b["y0"]
+            x_in, prev = self.block_in[i]  # input of sep_a (dropped for ResNet1DConv) / input of the residual conv
+            if self.block_masks is not None and i == L:  # sep_f read Dropout(prev_L): its input gradient goes back through that Dropout
+                N.check(lib.orcai_mask_scale(dprev.data_ptr(), self.block_masks[i - 1].data_ptr(), 1.0 / (1.0 - self.block_rate), dprev.numel(), dprev.data_ptr(), st),
+                        "mask_scale")
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
             # residual 1x1 stride-2 conv: weight / bias gradients
             N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
@@ -400,9 +482,11 @@ class TrunkTrainer:
             dva = dya
             self._bn_bwd(dya, b[f"va{i}"], f"b{i}/bn_a", f, h, w, 1, dva)
             dr = b[f"dr{i}"]
-            self._sep_backward(f"b{i}/sep_a", prev, 1, cprev, f, h, w, dva, b[f"u_a{i}"], b[f"du_a{i}"], dr)
+            self._sep_backward(f"b{i}/sep_a", x_in, 1, cprev, f, h, w, dva, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
-            N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), prev.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
+            N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
+            if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
+                N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")
             wrt = P.W(f"b{i}/res/kernel")[0, 0].t().contiguous()  # [f][cprev]
             self._sep(dout, f, ho, wo, 1, 0, self._ones(4 * ((f + 3) // 4)), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
             dprev = dr
@@ -423,7 +507,8 @@ class Trainer:
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.P = FlatParams(model, self.dev)
         self.trunk = TrunkTrainer(model, self.P)
-        self.head = HeadTrainer(model, self.P)
+        self.conv1d = getattr(model, "architecture", "") == "ResNet1DConv"
+        self.head = Conv1DHeadTrainer(model, self.P) if self.conv1d else HeadTrainer(model, self.P)
         self.lr = float(learning_rate)
         self.step_count = 0
         self.seed = int(seed)
@@ -434,9 +519,16 @@ class Trainer:
             return None
         lib, st = N.lib(), N.stream_ptr()
         out = {}
-        for j, d in (("drop1", 2 * self.model.lstm_units), ("drop2", 2 * self.model.lstm_units), ("drop3", DENSE_UNITS)):
-            mk = torch.empty((n, T, d), dtype=torch.float32, device=self.dev)
-            seed = (self.seed * 1000003 + self.step_count * 3 + int(j[-1])) & 0xFFFFFFFFFFFFFFFF
+        if self.conv1d:  # one mask per residual block (plane layout, drawn over the whole buffer: the pads are zero anyway) + one after BN_f
+            shapes = self.model.stage_shapes()
+            R = self.model.kernel_size // 2
+            todo = [(f"block{i}", (n, (shapes[i][2] + 3) // 4, shapes[i][0] + 2 * R, self.model.padded_width(shapes[i][1]), 4)) for i in range(1, len(self.model.filters) + 1)]
+            todo.append(("final", (n, T, shapes[-1][1] * FINAL_FILTERS)))
+        else:
+            todo = [("drop1", (n, T, 2 * self.model.lstm_units)), ("drop2", (n, T, 2 * self.model.lstm_units)), ("drop3", (n, T, DENSE_UNITS))]
+        for idx, (j, shape) in enumerate(todo):
+            mk = torch.empty(shape, dtype=torch.float32, device=self.dev)
+            seed = (self.seed * 1000003 + self.step_count * 16 + idx + 1) & 0xFFFFFFFFFFFFFFFF
             N.check(lib.orcai_dropout_mask(mk.data_ptr(), mk.numel(), seed, 1.0 - rate, st), "dropout_mask")
             out[j] = mk
         return out
@@ -444,9 +536,10 @@ class Trainer:
     def forward_backward(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor, masks: dict | None = "auto") -> dict:
         """Gradients of (masked BCE + L2) into the flat gradient buffer.  Returns device accumulators {bce sum, count, correct, l2}."""
         self.P.g.zero_()
-        featv = self.trunk.forward(src, snippet_stride, B)
         if isinstance(masks, str):
-            masks = self._masks(B, featv.shape[1])
+            masks = self._masks(B, self.model.out_steps)
+        self.trunk.block_masks = [masks[f"block{i}"] for i in range(1, len(self.model.filters) + 1)] if (self.conv1d and masks is not None) else None
+        featv = self.trunk.forward(src, snippet_stride, B)
         probs = self.head.forward(featv, masks, self.model.dropout_rate)
         out = self.head.loss_and_backward(labels)
         self.trunk.backward(out["dfeatv"])

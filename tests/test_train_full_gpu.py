@@ -88,3 +88,66 @@ def test_training_reduces_loss_and_roundtrips_weights():
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::5]
     tr.P.to_model(model)
     assert np.isfinite(model.predict(x[..., None])).all()
+
+
+def _planes_mask_from_nchw(mask, ksize):
+    """[B][C][H][W] 0/1 mask -> the padded channel-quad plane layout [B][CQ][H+2R][WP][4] the trunk kernels use."""
+    B, C, H, W = mask.shape
+    R = ksize // 2
+    WP = (W + R + 3) & ~3
+    CQ = (C + 3) // 4
+    out = np.zeros((B, CQ * 4, H + 2 * R, WP), dtype=np.float32)
+    out[:, :C, R : R + H, :W] = mask
+    return np.ascontiguousarray(out.reshape(B, CQ, 4, H + 2 * R, WP).transpose(0, 1, 3, 4, 2))
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.4])
+def test_resnet_1dconv_training_step_vs_autograd(rate):
+    """SURVEY 8f row 1, training: ResNet1DConv (Dropout after every block -- the residual branch reads the un-dropped tensor --
+    and after BN_f, frequency mean, Conv1D head) forward + masked BCE + full backward against torch autograd (float64)."""
+    from orcai_amd.architectures import FINAL_FILTERS, ResNet1DConv
+    from orcai_amd.training import Trainer
+
+    cfg = dict(input_shape=(48, 21, 1), filters=(12, 30, 40), kernel_size=3, lstm_units=64, num_labels=5)
+    p = M.calibrated_params(seed=6, **cfg)
+    p = {k: v for k, v in p.items() if not k.startswith(("lstm", "dense", "bn_d"))}
+    rng = np.random.default_rng(6)
+    for k in p:
+        if k.endswith(("gamma", "beta")):
+            p[k] = (p[k] + 0.2 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    L = cfg["num_labels"]
+    p["conv1d/kernel"] = (0.1 * rng.standard_normal((FINAL_FILTERS, FINAL_FILTERS, L))).astype(np.float32)
+    p["conv1d/bias"] = (0.1 * rng.standard_normal(L)).astype(np.float32)
+    B, (H, W, _) = 3, cfg["input_shape"]
+    steps = H // 8
+    x = rng.random((B, H, W, 1), dtype=np.float32)
+    y = (rng.random((B, steps, L)) > 0.5).astype(np.float32)
+    y[1, :, 2] = -1.0
+    model = ResNet1DConv(cfg["input_shape"], L, list(cfg["filters"]), 3, rate)
+    model.set_weights_dict(p)
+    shapes = model.stage_shapes()
+    masks_np, masks_dev = None, None
+    if rate > 0:
+        masks_np = {f"block{i}": (rng.random((B, shapes[i][2], shapes[i][0], shapes[i][1])) > rate).astype(np.float32) for i in range(1, 4)}
+        masks_np["final"] = (rng.random((B, FINAL_FILTERS, shapes[-1][0], shapes[-1][1])) > rate).astype(np.float32)
+        masks_dev = {k: torch.from_numpy(_planes_mask_from_nchw(v, 3)).cuda() for k, v in masks_np.items() if k != "final"}
+        # after BN_f the tensor is in the Keras Reshape layout [B][T][W*36]: feature = x*36 + c
+        masks_dev["final"] = torch.from_numpy(np.ascontiguousarray(masks_np["final"].transpose(0, 2, 3, 1).reshape(B, shapes[-1][0], -1))).cuda()
+    ref = T.loss_and_grads_1dconv(p, x, y, masks_np, rate)
+    tr = Trainer(model, learning_rate=1e-3)
+    out = tr.forward_backward(torch.from_numpy(np.ascontiguousarray(x[..., 0])).cuda().view(-1), H * W, B, torch.from_numpy(y).cuda(), masks=masks_dev)
+    acc = out["acc"].cpu().numpy()
+    assert np.abs(out["probs"].cpu().numpy() - ref["probs"]).max() <= 5e-6
+    assert abs(acc[0] / acc[1] - ref["loss"]) <= 2e-6 * max(1.0, abs(ref["loss"])) and acc[3] == 0.0
+    bad = {}
+    for name, g in ref["grads"].items():
+        got = tr.P.G(name).cpu().numpy()
+        zero_mean_bias = name.endswith("/bias") and "res" not in name and not name.startswith("conv1d")
+        scale = max(1e-3, float(np.abs(g).max())) if not zero_mean_bias else 1.0
+        err = float(np.abs(got - g).max()) / scale
+        if err > (5e-4 if not zero_mean_bias else 1e-4):
+            bad[name] = err
+    assert not bad, bad
+    # Adam + moving statistics run for this architecture as well
+    tr.apply()
+    assert bool(torch.isfinite(tr.P.w).all())

@@ -206,3 +206,24 @@ def test_orcai_test_command_after_training(tmp_path):
     near = np.abs(probs - 0.5) < 1e-4  # a probability this close to the threshold may flip between fp32 implementations
     if not near.any():
         assert np.allclose(got.loc[want.index].to_numpy(dtype=np.float64), want.to_numpy(dtype=np.float64), rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_train_resnet_1dconv_architecture(tmp_path):
+    """`orcai train` with architecture ResNet1DConv (architectures.py:18-117): fit with the block / final Dropouts, save, reload, predict."""
+    from orcai_amd.io import load_orcai_model
+    from orcai_amd.train import train
+
+    d = _data(tmp_path, n_train=32, n_val=8)
+    out = tmp_path / "out"
+    out.mkdir()
+    p = _param(epochs=2, dropout_rate=0.3)
+    p["architecture"] = "ResNet1DConv"
+    train(d, out, p, verbosity=0)
+    mdir = out / "orcai-v1"
+    hist = json.loads((mdir / "training_history.json").read_text())
+    assert len(hist["loss"]) == 2 and np.isfinite(hist["loss"]).all() and np.isfinite(hist["val_loss"]).all()
+    model, p2, _ = load_orcai_model(mdir)
+    assert model.architecture == "ResNet1DConv" and p2["architecture"] == "ResNet1DConv"
+    x = np.random.default_rng(0).random((4, 32, 12, 1), dtype=np.float32)
+    probs = model.predict(x)
+    assert probs.shape == (4, 8, 3) and np.isfinite(probs).all()
