@@ -269,6 +269,12 @@ int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, float* dv, void* stream);
+/* orcai_bn_planes_bwd fused with the input gradient through the pointwise weights of the separable conv that produced v:
+ * dbeta / dgamma as above, dv (may alias dy) = BN input gradient, du = Wpw dv with wt = pointwise^T [C][Cin] (planes of Cin
+ * channels).  One pass over dy and v instead of bn apply + a pointwise conv pass that re-reads dv. */
+int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                           const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, const float* wt, int Cin, float* dv, float* du,
+                           void* stream);
 /* out[c] (=|+=) sum over snippets and pixels of x[c] (bias gradients); scratch: f64[4*ceil(C/4)] */
 int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratch, float* out, int accumulate, void* stream);
 /* gradient of MaxPooling2D((3,2), 2, "same"): dy[y][x] = sum of dout over the windows whose maximum is ybn[y][x] */

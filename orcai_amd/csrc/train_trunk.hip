@@ -160,6 +160,105 @@ __global__ __launch_bounds__(256) void bn_planes_bwd_apply_kernel(const float* _
   reinterpret_cast<float4*>(dv)[off] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---------------------------------------------------------------- BN backward apply fused with the transposed pointwise conv
+// dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N)  (as bn_planes_bwd_apply_kernel)  AND  du = Wpw dv  in one pass:
+// one wave = 64 consecutive flat pixels (1 KiB-aligned windows, no halo: both ops are per pixel), lane = pixel.  Per channel
+// quad of the conv OUTPUT side the lane loads dy and v (dwordx4 each), forms dv on the VALU with wave-uniform per-channel
+// constants, stores it (the pointwise weight gradient reads it next), transposes the 4 VGPRs into MFMA B fragments
+// (permlane swaps, as in sepconv_kernel) and multiplies by the transposed pointwise weights (A operand, row = conv INPUT
+// channel).  Replaces bn_planes_bwd_apply_kernel + the ktap = 1 sepconv pass: dv is no longer re-read for du.
+__device__ __forceinline__ void swap32t(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16t(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void bn_bwd_pw_kernel(const float* dy, const float* __restrict__ v, int C, int H, int W, int WP, int R,
+                                                         const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int relu, const double* __restrict__ dbeta,
+                                                         const double* __restrict__ dgamma, float inv_count, const float* __restrict__ wt /*[C][Cin]*/, int Cin,
+                                                         float* dv /*may alias dy*/, float* __restrict__ du /*[B][CQin][HP][WP][4]*/, int tasks,
+                                                         uint32_t magic_WP) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;
+  const int b = blockIdx.y;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int CQ = (C + 3) >> 2, CQi = (Cin + 3) >> 2;
+  const int plane = (H + 2 * R) * WP;
+  const int qbase = R * WP + task * 64;  // interior rows only; windows are 1 KiB aligned (plane and row pitch are multiples of 4 pixels... of 64 B)
+  const int q = qbase + lane;
+  const int row = (int)__umulhi((uint32_t)q, magic_WP);
+  const bool live = (q - row * WP) < W && row < R + H;
+  const int qc = q < plane ? q : plane - 1;
+  const float4* dyp = reinterpret_cast<const float4*>(dy) + (int64_t)b * CQ * plane + qc;
+  const float4* vp = reinterpret_cast<const float4*>(v) + (int64_t)b * CQ * plane + qc;
+  float4* dvp = reinterpret_cast<float4*>(dv) + (int64_t)b * CQ * plane + qc;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 nd = dyp[0], nv = vp[0];
+  for (int cq = 0; cq < CQ; ++cq) {
+    const float4 d4 = nd, v4 = nv;
+    if (cq + 1 < CQ) {
+      nd = dyp[(int64_t)(cq + 1) * plane];
+      nv = vp[(int64_t)(cq + 1) * plane];
+    }
+    float afrag[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = cq * 4 + lk, ci = m * 16 + lj;  // k = conv-output channel, row = conv-input channel
+      const bool ok = co < C && ci < Cin;
+      const float av = wt[ok ? co * Cin + ci : 0];
+      afrag[m] = ok ? av : 0.0f;
+    }
+    const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = cq * 4 + k;  // wave-uniform: the per-channel constants are scalar loads
+      if (c < C) {
+        const float inv = rsqrtf(var[c] + eps);
+        const float xh = (vv[k] - mean[c]) * inv;
+        float de = dd[k];
+        if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+        o[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
+      } else {
+        o[k] = 0.0f;
+      }
+    }
+    if (live) dvp[(int64_t)cq * plane] = make_float4(o[0], o[1], o[2], o[3]);
+    swap32t(o[0], o[2]);
+    swap32t(o[1], o[3]);
+    swap16t(o[0], o[1]);
+    swap16t(o[2], o[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], o[t], acc[m][t]);
+  }
+  float4* dup = reinterpret_cast<float4*>(du) + (int64_t)b * CQi * plane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int flat = qbase + 16 * t + lj;
+    const int r2 = (int)__umulhi((uint32_t)flat, magic_WP);
+    if (!((flat - r2 * WP) < W && r2 < R + H)) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      if (oq < CQi) dup[(int64_t)oq * plane + flat] = make_float4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]);
+    }
+  }
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ a, float* __restrict__ b, int n, int accumulate) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
@@ -551,6 +650,40 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
   const int64_t n = (int64_t)B * CQ * H * W;
   hipLaunchKernelGGL(bn_planes_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, v, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg,
                      (double)B * H * W, dv, B);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                           const float* beta, float eps, int relu, double* scratch2C, float* dbeta, float* dgamma, const float* wt, int Cin, float* dv, float* du,
+                           void* stream) {
+  if (!dy || !v || !dv || !du || !wt || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0 || Cin <= 0 || C > 64 || Cin > 64) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 128) gx = 128;
+  double* db = scratch2C;
+  double* dg = scratch2C + 4 * CQ;
+  hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  const int tasks = (H * WP + 63) / 64;
+  dim3 grid((tasks + 3) / 4, B);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+#define ORCAI_BBP(MT_)                                                                                                                                 \
+  hipLaunchKernelGGL((bn_bwd_pw_kernel<MT_>), grid, dim3(256), 0, st, dy, v, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg, inv_count, wt, Cin, \
+                     dv, du, tasks, magic_for(WP))
+  switch ((Cin + 15) / 16) {
+    case 1: ORCAI_BBP(1); break;
+    case 2: ORCAI_BBP(2); break;
+    case 3: ORCAI_BBP(3); break;
+    case 4: ORCAI_BBP(4); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_BBP
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
   return (int)hipGetLastError();

@@ -432,7 +432,18 @@ class TrunkTrainer:
             S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
 
     # ------------------------------------------------------------- backward
-    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr):
+    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr):
+        """BatchNorm backward (in place on dy -> dv) fused with the first step of the separable conv's backward (du = Wpw dv),
+        then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv."""
+        lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
+        mean, var = self.stats[bn]
+        wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
+        N.check(lib.orcai_bn_bwd_pointwise(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                           P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), P.G(bn + "/beta").data_ptr(),
+                                           P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
+        self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True)
+
+    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False):
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
@@ -441,9 +452,9 @@ class TrunkTrainer:
         # u = dw(relu?(x)) was stored by the forward pass.
         N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                        self.partials.numel(), st), "outer_reduce")
-        # du = Wpw dv   (pointwise conv with the transposed weights)
-        wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
-        self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
+        if not have_du:  # du = Wpw dv   (pointwise conv with the transposed weights)
+            wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
+            self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
         dwg = torch.zeros((4 * ((Cin + 3) // 4), k * k), dtype=torch.float32, device=self.dev)
         N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, dwg.data_ptr(), st), "dw_wgrad")
         P.G(name + "/depthwise").copy_(dwg[:Cin].reshape(Cin, k, k).permute(1, 2, 0).unsqueeze(3))
@@ -475,14 +486,10 @@ class TrunkTrainer:
             # max-pool branch
             dyb = b[f"dyb{i}"]
             N.check(lib.orcai_pool_bwd(dout.data_ptr(), b[f"yb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), st), "pool_bwd")
-            dvb = dyb  # in place
-            self._bn_bwd(dyb, b[f"vb{i}"], f"b{i}/bn_b", f, h, w, 0, dvb)
             dya = b[f"dya{i}"]
-            self._sep_backward(f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, dvb, b[f"u_b{i}"], b[f"du_b{i}"], dya)
-            dva = dya
-            self._bn_bwd(dya, b[f"va{i}"], f"b{i}/bn_a", f, h, w, 1, dva)
+            self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya)
             dr = b[f"dr{i}"]
-            self._sep_backward(f"b{i}/sep_a", x_in, 1, cprev, f, h, w, dva, b[f"u_a{i}"], b[f"du_a{i}"], dr)
+            self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
             N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
