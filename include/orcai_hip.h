@@ -269,6 +269,12 @@ int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, float* dv, void* stream);
+/* Training forward / backward of the pooling with the BatchNormalization in front of it applied on the fly (architectures.py:
+ * 189-196): `s` / `ybn` hold the PRE-BN tensor v; BN(v) = fma(v, gamma*rsqrt(var+eps), beta - mean*that) is monotone per channel,
+ * so the maximum (and its position) is taken on v and transformed once.  BN(v) is never materialised. */
+int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
+                          int xpooled, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* stream);
+int orcai_pool_bwd_bn(const float* dout, const float* v, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, void* stream);
 /* orcai_bn_planes_bwd fused with the input gradient through the pointwise weights of the separable conv that produced v:
  * dbeta / dgamma as above, dv (may alias dy) = BN input gradient, du = Wpw dv with wt = pointwise^T [C][Cin] (planes of Cin
  * channels).  One pass over dy and v instead of bn apply + a pointwise conv pass that re-reads dv. */

@@ -865,7 +865,11 @@ template <int MT>
 __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restrict__ s, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
                                                             int C, int Cp, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top,
                                                             int pad_left, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
-                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int xpooled, int tasks, uint32_t magic_WPo) {
+                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int xpooled, int tasks, uint32_t magic_WPo,
+                                                            const float* __restrict__ bn_mean, const float* __restrict__ bn_var,
+                                                            const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta, float bn_eps) {
+  // bn_mean != NULL (training forward): s holds the PRE-BatchNorm tensor v and the pooling runs on BN(v) = fma(v, sc, sh) without
+  // materialising it: fma with sc >= 0 is monotone, so max BN(v) = BN(max v) bit for bit; for sc < 0 it is BN(min v).
   const int lane = threadIdx.x & 63;
   int bx, b;
   xcd_remap(bx, b);
@@ -932,6 +936,7 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
       const int oq = m * 4 + lk;
       if (oq >= CQ) continue;
       float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
       if (xpooled) {  // s is [B][CQ][H][WPx][4], already reduced over the column pair (pad_left == 0)
         const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * (int64_t)H * WPx;
 #pragma unroll
@@ -952,8 +957,17 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
             if (y >= 0 && y < H && x >= 0 && x < W) {
               const float4 v = sp[(int64_t)(y + R) * WP + x];
               mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
+              if (bn_mean) { mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z); mn[3] = fminf(mn[3], v.w); }
             }
           }
+      }
+      if (bn_mean) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = oq * 4 + r, cc = c < C ? c : 0;
+          const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps);  // same expressions as bn_planes_apply_kernel
+          mx[r] = fmaf(sc >= 0.0f ? mx[r] : mn[r], sc, bn_beta[cc] - bn_mean[cc] * sc);
+        }
       }
       float o[4];
 #pragma unroll
@@ -1393,20 +1407,21 @@ int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const 
   return (int)hipGetLastError();
 }
 
-int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
-                       int xpooled, void* stream) {
+int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
+                          int xpooled, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* stream) {
   if (!s || !prev || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
   if (xpooled && tot_w / 2 != 0) return ORCAI_E_UNSUPPORTED;
+  if (bn_mean && (xpooled || !bn_var || !bn_gamma || !bn_beta)) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize), WPo = orcai_padded_width(Wo, ksize), R = ksize / 2;
   const int tasks = (Ho * WPo + 63) / 64;
   dim3 grid((tasks + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t mg = magic_for(WPo);
-#define ORCAI_POOL_LAUNCH(MT) hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg)
+#define ORCAI_POOL_LAUNCH(MT) hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps)
   switch ((C + 15) / 16) {
     case 1: ORCAI_POOL_LAUNCH(1); break;
     case 2: ORCAI_POOL_LAUNCH(2); break;
@@ -1416,6 +1431,11 @@ int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, 
   }
 #undef ORCAI_POOL_LAUNCH
   return (int)hipGetLastError();
+}
+
+int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
+                       int xpooled, void* stream) {
+  return orcai_pool_res_add_bn(s, prev, B, C, Cp, H, W, ksize, wr, br, out, xpooled, nullptr, nullptr, nullptr, nullptr, 0.0f, stream);
 }
 
 int orcai_sep_pool_res(const float* a, const float* prev, int B, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,

@@ -274,7 +274,9 @@ constexpr int PB_ROWS = 8;
 
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout /*[B][CQ][Ho+2R][WPo][4]*/, const float* __restrict__ ybn /*[B][CQ][HP][WP][4]*/,
                                                         int C, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, int pad_left,
-                                                        float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B) {
+                                                        float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B, const float* __restrict__ bn_gamma) {
+  // bn_gamma != NULL: ybn holds the PRE-BatchNorm tensor v; BN(v) = fma(v, gamma*inv, ..) is monotone, increasing for gamma >= 0
+  // and decreasing for gamma < 0, so the arg-max of BN(v) is the arg-max of sign(gamma) * v.
   const int CQ = (C + 3) >> 2;
   const int nchunk = (Ho + PB_ROWS - 1) / PB_ROWS;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -289,7 +291,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   const int x0 = 2 * j - pad_left, x1 = x0 + 1;
   const bool cx0 = x0 >= 0 && x0 < W, cx1 = x1 < W;  // x1 >= 0 always
   const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto ld = [&](int y, int x, bool cx) -> float4 { return (cx && y >= 0 && y < H) ? yp[(int64_t)(y + R) * WP + x] : ninf; };
+  float4 sgn = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (bn_gamma) {
+    const int c0 = (int)(bq % CQ) * 4;
+    sgn = make_float4(bn_gamma[c0 < C ? c0 : 0] < 0.f ? -1.f : 1.f, bn_gamma[c0 + 1 < C ? c0 + 1 : 0] < 0.f ? -1.f : 1.f,
+                      bn_gamma[c0 + 2 < C ? c0 + 2 : 0] < 0.f ? -1.f : 1.f, bn_gamma[c0 + 3 < C ? c0 + 3 : 0] < 0.f ? -1.f : 1.f);
+  }
+  auto ld = [&](int y, int x, bool cx) -> float4 {
+    if (!(cx && y >= 0 && y < H)) return ninf;
+    const float4 t = yp[(int64_t)(y + R) * WP + x];
+    return make_float4(t.x * sgn.x, t.y * sgn.y, t.z * sgn.z, t.w * sgn.w);
+  };
   auto mx4 = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
   auto sel = [](float4 v, float4 m, float4 d) { return make_float4(v.x == m.x ? d.x : 0.f, v.y == m.y ? d.y : 0.f, v.z == m.z ? d.z : 0.f, v.w == m.w ? d.w : 0.f); };
   auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
@@ -689,7 +701,7 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
   return (int)hipGetLastError();
 }
 
-int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream) {
+int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, void* stream) {
   if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
@@ -697,8 +709,12 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
   if (tot_w < 0) tot_w = 0;
   const int64_t n = (int64_t)B * ((C + 3) / 4) * ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
-                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B);
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B, bn_gamma);
   return (int)hipGetLastError();
+}
+
+int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream) {
+  return orcai_pool_bwd_bn(dout, ybn, B, C, H, W, ksize, dy, nullptr, stream);
 }
 
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,

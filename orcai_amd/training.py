@@ -341,10 +341,14 @@ class TrunkTrainer:
                                                 N.stream_ptr()), "orcai_sepconv_planes_u")
 
     def _bn_fwd(self, v, bn, C, H, W, relu, y):
+        """Batch statistics of v; y = [relu](BN(v)) is materialised unless y is None (the consumer applies BN on the fly)."""
         lib, P, st = self.lib, self.P, N.stream_ptr()
         mean = torch.empty(C, dtype=torch.float32, device=self.dev)
         var = torch.empty(C, dtype=torch.float32, device=self.dev)
         N.check(lib.orcai_bn_planes_stats(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
+        self.stats[bn] = (mean, var)
+        if y is None:
+            return
         N.check(lib.orcai_bn_planes_apply(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                           P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), st), "bn_planes_apply")
         self.stats[bn] = (mean, var)
@@ -367,7 +371,7 @@ class TrunkTrainer:
         b["v0"], b["y0"] = self._planes(B, 16, h, w), self._planes(B, 16, h, w)
         for i, f in enumerate(m.filters, start=1):
             h, w, cprev = shapes[i - 1]
-            for n in ("va", "ya", "vb", "yb"):
+            for n in ("va", "ya", "vb"):  # y_b = BN_b(v_b) is never materialised (the pooling kernels apply BN on the fly)
                 b[f"{n}{i}"] = self._planes(B, f, h, w)
             b[f"u_a{i}"], b[f"du_a{i}"] = self._planes(B, cprev, h, w), self._planes(B, cprev, h, w)  # depthwise output / its gradient (sep_a)
             b[f"u_b{i}"], b[f"du_b{i}"] = self._planes(B, f, h, w), self._planes(B, f, h, w)
@@ -403,14 +407,17 @@ class TrunkTrainer:
         for i, f in enumerate(m.filters, start=1):
             h, w, _ = shapes[i - 1]
             self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
-            for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], b[f"yb{i}"], 0)):
+            for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], None, 0)):
                 name = f"b{i}/sep_{tag}"
                 self.dwl[name] = self._dw_kernel_layout(name + "/depthwise")
                 self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
-                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y)
+                # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
+                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None)
             # the residual branch reads the block input BEFORE the previous block's Dropout (architectures.py:88-97)
-            N.check(lib.orcai_pool_res_add(b[f"yb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(), P.W(f"b{i}/res/bias").data_ptr(),
-                                           b[f"prev{i}"].data_ptr(), 0, st), "orcai_pool_res_add")
+            bmean, bvar = self.stats[f"b{i}/bn_b"]
+            N.check(lib.orcai_pool_res_add_bn(b[f"vb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(),
+                                              P.W(f"b{i}/res/bias").data_ptr(), b[f"prev{i}"].data_ptr(), 0, bmean.data_ptr(), bvar.data_ptr(),
+                                              P.W(f"b{i}/bn_b/gamma").data_ptr(), P.W(f"b{i}/bn_b/beta").data_ptr(), BN_EPS, st), "orcai_pool_res_add_bn")
             prev, c = b[f"prev{i}"], f
             res_in = prev
             if self.block_masks is not None:  # ResNet1DConv: Dropout after every block; the dropped tensor feeds the next separable conv only
@@ -485,7 +492,7 @@ class TrunkTrainer:
             N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
             # max-pool branch
             dyb = b[f"dyb{i}"]
-            N.check(lib.orcai_pool_bwd(dout.data_ptr(), b[f"yb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), st), "pool_bwd")
+            N.check(lib.orcai_pool_bwd_bn(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), st), "pool_bwd_bn")
             dya = b[f"dya{i}"]
             self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya)
             dr = b[f"dr{i}"]
