@@ -269,6 +269,12 @@ int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, float* dv, void* stream);
+/* Backward of the entry block Conv2D(16) -> BatchNormalization -> ReLU (architectures.py:162-168): dbeta / dgamma of bn0 and the
+ * conv weight gradient dW0[tap][16] (accumulated) from dy = gradient at the ReLU output and v = pre-BN conv output.  The BN input
+ * gradient is formed on the fly and never written (the entry conv has no input gradient). */
+int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy, const float* v, int B, int H, int W, int ksize, const float* mean,
+                       const float* var, const float* gamma, const float* beta, float eps, double* scratch, float* dbeta, float* dgamma, float* dW,
+                       void* stream);
 /* Training forward / backward of the pooling with the BatchNormalization in front of it applied on the fly (architectures.py:
  * 189-196): `s` / `ybn` hold the PRE-BN tensor v; BN(v) = fma(v, gamma*rsqrt(var+eps), beta - mean*that) is monotone per channel,
  * so the maximum (and its position) is taken on v and transformed once.  BN(v) is never materialised. */

@@ -580,6 +580,75 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   }
 }
 
+// Entry conv weight gradient with the BatchNorm (+ReLU) backward of bn0 applied on the fly: dv = gamma*inv*(dy_eff - dbeta/N -
+// xhat*dgamma/N) is formed per pixel from (dy, v, sums) and consumed at once -- the entry conv has no input gradient, so dv is
+// never written.  Same work distribution and block-level reduction as conv0_wgrad_kernel.
+template <int KS>
+__global__ __launch_bounds__(256) void conv0_bn_wgrad_kernel(const float* __restrict__ in, int64_t snippet_stride, const float* __restrict__ dy,
+                                                              const float* __restrict__ v /*[B][4][HP][WP][4]*/, int H, int W, int WP, int B,
+                                                              const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, const double* __restrict__ dbeta,
+                                                              const double* __restrict__ dgamma, float inv_count, float* __restrict__ dW /*[KS*KS][16]*/) {
+  constexpr int R = KS / 2, KK = KS * KS;
+  __shared__ float red[4][4 * KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = blockIdx.y;
+  const int plane = (H + 2 * R) * WP;
+  float mu[4], inv[4], g[4], bt[4], c1[4], c2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;  // the entry conv has exactly 16 filters: 4 full quads
+    mu[k] = mean[c]; inv[k] = rsqrtf(var[c] + eps); g[k] = gamma[c]; bt[k] = beta[c];
+    c1[k] = (float)dbeta[c] * inv_count; c2[k] = (float)dgamma[c] * inv_count;
+  }
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const int total = H * W;
+  for (int b = 0; b < B; ++b) {
+    const float* src = in + (int64_t)b * snippet_stride;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + ((int64_t)b * 4 + cq) * plane;
+    const float4* vp = reinterpret_cast<const float4*>(v) + ((int64_t)b * 4 + cq) * plane;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+      const int y = p / W, x = p - y * W;
+      const float4 d4 = dp[(y + R) * WP + x], v4 = vp[(y + R) * WP + x];
+      const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      float gq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (vv[k] - mu[k]) * inv[k];
+        const float de = (fmaf(xh, g[k], bt[k]) > 0.0f) ? dd[k] : 0.0f;  // bn0 is followed by a ReLU (architectures.py:167-168)
+        gq[k] = g[k] * inv[k] * (de - c1[k] - xh * c2[k]);
+      }
+#pragma unroll
+      for (int dyy = 0; dyy < KS; ++dyy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const int yy = y + dyy - R, xx = x + dx - R;
+          const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[yy * W + xx] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][dyy * KS + dx] = fmaf(a, gq[j], acc[j][dyy * KS + dx]);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float s2 = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+      if (lane == 0) red[wave][j * KK + t] = s2;
+    }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
+    atomicAdd(&dW[t * 16 + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // ---------------------------------------------------------------- Keras Reshape layout [B][H][W*C] -> planes (gradient of the final conv)
 __global__ __launch_bounds__(256) void feat_to_planes_kernel(const float* __restrict__ f, int C, int H, int W, int WP, int R, float* __restrict__ out, int B) {
   const int CQ = (C + 3) >> 2;
@@ -770,6 +839,34 @@ int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, 
     case 7: hipLaunchKernelGGL(conv0_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dv, H, W, WP, B, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy, const float* v, int B, int H, int W, int ksize, const float* mean,
+                       const float* var, const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW,
+                       void* stream) {
+  if (!in || !dy || !v || !dW || !scratch2C || !dbeta || !dgamma || B <= 0) return ORCAI_E_BADARG;
+  if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = 16, CQ = 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 128) gx = 128;
+  double* db = scratch2C;
+  double* dg = scratch2C + 4 * CQ;
+  hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, 1, db, dg);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+  dim3 grid(256, 4);
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_bn_wgrad_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, dy, v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 5: hipLaunchKernelGGL(conv0_bn_wgrad_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, dy, v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 7: hipLaunchKernelGGL(conv0_bn_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dy, v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, dg, dgamma, C, 0);
   return (int)hipGetLastError();
 }
 

@@ -498,16 +498,18 @@ class TrunkTrainer:
             dr = b[f"dr{i}"]
             self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
-            N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
+            if i > 1:  # for block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward applies anyway (mask*mask = mask)
+                N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
                 N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")
             wrt = P.W(f"b{i}/res/kernel")[0, 0].t().contiguous()  # [f][cprev]
             self._sep(dout, f, ho, wo, 1, 0, self._ones(4 * ((f + 3) // 4)), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
             dprev = dr
         H, W = m.input_hw
-        dv0 = dprev
-        self._bn_bwd(dprev, b["v0"], "bn0", 16, H, W, 1, dv0)
-        N.check(lib.orcai_conv0_wgrad(self.src.data_ptr(), self.snippet_stride, dv0.data_ptr(), B, H, W, k, P.G("conv0/kernel").data_ptr(), st), "conv0_wgrad")
+        mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
+        N.check(lib.orcai_conv0_bn_bwd(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
+                                       P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
+                                       P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
         # conv0/bias feeds bn0: zero gradient (see _sep_backward)
 
 
