@@ -280,13 +280,16 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
  * so the maximum (and its position) is taken on v and transformed once.  BN(v) is never materialised. */
 int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
                           int xpooled, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* stream);
-int orcai_pool_bwd_bn(const float* dout, const float* v, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, void* stream);
+/* bn_sums != NULL (device f64[8*ceil(C/4)], zeroed by the call): additionally accumulates sum dy and sum dy*xhat per channel, the two
+ * reductions of that BatchNorm's backward, so orcai_bn_bwd_pointwise(sums_ready = 1) need not read dy and v for them. */
+int orcai_pool_bwd_bn(const float* dout, const float* v, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                      const float* bn_var, float bn_eps, double* bn_sums, void* stream);
 /* orcai_bn_planes_bwd fused with the input gradient through the pointwise weights of the separable conv that produced v:
  * dbeta / dgamma as above, dv (may alias dy) = BN input gradient, du = Wpw dv with wt = pointwise^T [C][Cin] (planes of Cin
  * channels).  One pass over dy and v instead of bn apply + a pointwise conv pass that re-reads dv. */
 int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
-                           const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, const float* wt, int Cin, float* dv, float* du,
-                           void* stream);
+                           const float* beta, float eps, int relu, double* scratch, int sums_ready, float* dbeta, float* dgamma, const float* wt, int Cin,
+                           float* dv, float* du, void* stream);
 /* out[c] (=|+=) sum over snippets and pixels of x[c] (bias gradients); scratch: f64[4*ceil(C/4)] */
 int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratch, float* out, int accumulate, void* stream);
 /* gradient of MaxPooling2D((3,2), 2, "same"): dy[y][x] = sum of dout over the windows whose maximum is ybn[y][x] */

@@ -274,17 +274,29 @@ constexpr int PB_ROWS = 8;
 
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout /*[B][CQ][Ho+2R][WPo][4]*/, const float* __restrict__ ybn /*[B][CQ][HP][WP][4]*/,
                                                         int C, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, int pad_left,
-                                                        float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B, const float* __restrict__ bn_gamma) {
+                                                        float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B, const float* __restrict__ bn_gamma,
+                                                        const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float bn_eps,
+                                                        double* __restrict__ bn_sums /*[2][4*CQ]: sum dy, sum dy*xhat*/) {
   // bn_gamma != NULL: ybn holds the PRE-BatchNorm tensor v; BN(v) = fma(v, gamma*inv, ..) is monotone, increasing for gamma >= 0
   // and decreasing for gamma < 0, so the arg-max of BN(v) is the arg-max of sign(gamma) * v.
+  // bn_sums != NULL: the reductions of that BatchNorm's backward (sum of dy and of dy * xhat per channel) are accumulated here,
+  // where every gradient value and the v it belongs to are in registers anyway (one workgroup = one (snippet, quad): blockIdx.y).
   const int CQ = (C + 3) >> 2;
   const int nchunk = (Ho + PB_ROWS - 1) / PB_ROWS;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)B * CQ * nchunk * Wo) return;
-  const int j = (int)(idx % Wo);
-  const int64_t rest = idx / Wo;
-  const int chunk = (int)(rest % nchunk);
-  const int64_t bq = rest / nchunk;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool in_range = idx < nchunk * Wo;
+  const int j = in_range ? idx % Wo : 0;
+  const int chunk = in_range ? idx / Wo : 0;
+  const int64_t bq = blockIdx.y;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, bqs[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, binv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bn_sums) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = (int)(bq % CQ) * 4 + k, cc = c < C ? c : 0;
+      bmu[k] = bn_mean[cc];
+      binv[k] = rsqrtf(bn_var[cc] + bn_eps);
+    }
+  }
   const float4* yp = reinterpret_cast<const float4*>(ybn) + bq * ((int64_t)(H + 2 * R) * WP);
   const float4* dp = reinterpret_cast<const float4*>(dout) + bq * ((int64_t)(Ho + 2 * R) * WPo);
   float4* gp = reinterpret_cast<float4*>(dy) + bq * ((int64_t)(H + 2 * R) * WP);
@@ -305,7 +317,18 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   auto mx4 = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
   auto sel = [](float4 v, float4 m, float4 d) { return make_float4(v.x == m.x ? d.x : 0.f, v.y == m.y ? d.y : 0.f, v.z == m.z ? d.z : 0.f, v.w == m.w ? d.w : 0.f); };
   auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
-  const int i0 = chunk * PB_ROWS, i1 = (i0 + PB_ROWS < Ho) ? i0 + PB_ROWS : Ho;
+  auto emit = [&](int64_t pos, float4 g, float4 tv) {  // store one gradient pixel-quad; tv = sign(gamma) * v at that position
+    gp[pos] = g;
+    if (bn_sums) {
+      const float gg[4] = {g.x, g.y, g.z, g.w}, vv[4] = {tv.x * sgn.x, tv.y * sgn.y, tv.z * sgn.z, tv.w * sgn.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bs[k] += gg[k];
+        bqs[k] = fmaf(gg[k], (vv[k] - bmu[k]) * binv[k], bqs[k]);
+      }
+    }
+  };
+  const int i0 = chunk * PB_ROWS, i1 = in_range ? ((i0 + PB_ROWS < Ho) ? i0 + PB_ROWS : Ho) : i0;
   const int istart = i0 > 0 ? i0 - 1 : 0;  // halo window: only its contribution to the shared row is kept
   float4 t0 = ld(2 * istart - pad_top, x0, cx0), t1 = ld(2 * istart - pad_top, x1, cx1);  // first row of the current window
   float4 c0 = zero4, c1 = zero4;                                                            // gradient carried into that row
@@ -317,12 +340,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const float4 m = mx4(mx4(mx4(t0, t1), mx4(m0, m1)), mx4(b0, b1));
     if (i >= i0) {
       if (r0 >= 0) {
-        if (cx0) gp[(int64_t)(r0 + R) * WP + x0] = add4(c0, sel(t0, m, d));
-        if (cx1) gp[(int64_t)(r0 + R) * WP + x1] = add4(c1, sel(t1, m, d));
+        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add4(c0, sel(t0, m, d)), t0);
+        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add4(c1, sel(t1, m, d)), t1);
       }
       if (r0 + 1 < H) {  // r0 + 1 >= 0 always
-        if (cx0) gp[(int64_t)(r0 + 1 + R) * WP + x0] = sel(m0, m, d);
-        if (cx1) gp[(int64_t)(r0 + 1 + R) * WP + x1] = sel(m1, m, d);
+        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, sel(m0, m, d), m0);
+        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, sel(m1, m, d), m1);
       }
     }
     c0 = sel(b0, m, d);
@@ -331,9 +354,25 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     t1 = b1;
   }
   const int rl = 2 * i1 - pad_top;  // first row of window i1: written here only when there is no window i1 (else the next chunk owns it)
-  if (i1 == Ho && rl < H) {
-    if (cx0) gp[(int64_t)(rl + R) * WP + x0] = c0;
-    if (cx1) gp[(int64_t)(rl + R) * WP + x1] = c1;
+  if (in_range && i1 == Ho && rl < H) {
+    if (cx0) emit((int64_t)(rl + R) * WP + x0, c0, t0);
+    if (cx1) emit((int64_t)(rl + R) * WP + x1, c1, t1);
+  }
+  if (bn_sums) {  // block reduction (float64) and 8 atomics per workgroup
+    __shared__ double red[256][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = (double)bs[k]; red[threadIdx.x][4 + k] = (double)bqs[k]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+      __syncthreads();
+    }
+    if (threadIdx.x < 8) {
+      const int k = threadIdx.x & 3, c = (int)(bq % CQ) * 4 + k;
+      if (c < C) atomicAdd(&bn_sums[(threadIdx.x >> 2) * 4 * CQ + c], red[0][threadIdx.x]);
+    }
   }
 }
 
@@ -737,20 +776,22 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
 }
 
 int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
-                           const float* beta, float eps, int relu, double* scratch2C, float* dbeta, float* dgamma, const float* wt, int Cin, float* dv, float* du,
-                           void* stream) {
+                           const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma, const float* wt, int Cin,
+                           float* dv, float* du, void* stream) {
   if (!dy || !v || !dv || !du || !wt || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0 || Cin <= 0 || C > 64 || Cin > 64) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
-  if (e != hipSuccess) return (int)e;
-  int gx = (int)((B * plane + 255) / 256);
-  if (gx > 128) gx = 128;
   double* db = scratch2C;
   double* dg = scratch2C + 4 * CQ;
-  hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  if (!sums_ready) {  // sums_ready: the producer of dy (orcai_pool_bwd_bn) already accumulated sum dy / sum dy*xhat into scratch
+    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+    if (e != hipSuccess) return (int)e;
+    int gx = (int)((B * plane + 255) / 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gx, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  }
   const int tasks = (H * WP + 63) / 64;
   dim3 grid((tasks + 3) / 4, B);
   const float inv_count = (float)(1.0 / ((double)B * H * W));
@@ -770,20 +811,29 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
   return (int)hipGetLastError();
 }
 
-int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, void* stream) {
+int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                      const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
   if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (bn_sums && (!bn_gamma || !bn_mean || !bn_var)) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
-  const int64_t n = (int64_t)B * ((C + 3) / 4) * ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
-                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B, bn_gamma);
+  const int CQ = (C + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (bn_sums) {
+    hipError_t e = hipMemsetAsync(bn_sums, 0, sizeof(double) * 8 * CQ, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
+  dim3 grid((per_bq + 255) / 256, (unsigned)(B * CQ));
+  hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 0, st, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums);
   return (int)hipGetLastError();
 }
 
 int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream) {
-  return orcai_pool_bwd_bn(dout, ybn, B, C, H, W, ksize, dy, nullptr, stream);
+  return orcai_pool_bwd_bn(dout, ybn, B, C, H, W, ksize, dy, nullptr, nullptr, nullptr, 0.0f, nullptr, stream);
 }
 
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,

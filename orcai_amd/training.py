@@ -439,14 +439,14 @@ class TrunkTrainer:
             S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
 
     # ------------------------------------------------------------- backward
-    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr):
+    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr, sums_ready=0):
         """BatchNorm backward (in place on dy -> dv) fused with the first step of the separable conv's backward (du = Wpw dv),
         then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
         wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
         N.check(lib.orcai_bn_bwd_pointwise(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
-                                           P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), P.G(bn + "/beta").data_ptr(),
+                                           P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
         self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True)
 
@@ -492,9 +492,11 @@ class TrunkTrainer:
             N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
             # max-pool branch
             dyb = b[f"dyb{i}"]
-            N.check(lib.orcai_pool_bwd_bn(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), st), "pool_bwd_bn")
+            bmean, bvar = self.stats[f"b{i}/bn_b"]  # the pooling backward also accumulates bn_b's backward reductions (sum dy, sum dy*xhat)
+            N.check(lib.orcai_pool_bwd_bn(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
+                                          bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
             dya = b[f"dya{i}"]
-            self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya)
+            self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1)
             dr = b[f"dr{i}"]
             self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
