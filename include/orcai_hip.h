@@ -269,6 +269,10 @@ int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, int relu, double* scratch, float* dbeta, float* dgamma, float* dv, void* stream);
+/* Kernel-layout copies of trunk weights from the flat parameter buffer in one launch: desc = n_desc x {type, src offset, dst offset,
+ * C, aux} (device int32): type 0 depthwise (k,k,C,1) -> [ceil(C/4)][k*k][4] (aux = k*k), type 1 the same with reversed taps,
+ * type 2 pointwise (1,1,C,aux) -> transposed [aux][C]. */
+int orcai_pack_weights(const float* w, const int* desc, int n_desc, float* out, void* stream);
 /* Backward of the entry block Conv2D(16) -> BatchNormalization -> ReLU (architectures.py:162-168): dbeta / dgamma of bn0 and the
  * conv weight gradient dW0[tap][16] (accumulated) from dy = gradient at the ReLU output and v = pre-BN conv output.  The BN input
  * gradient is formed on the fly and never written (the entry conv has no input gradient). */
@@ -299,7 +303,8 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
  * partial products (up to 512 * Ca * Cb floats are used; fewer workgroups run if it is smaller). */
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
                        float* workspace, int64_t workspace_floats, void* stream);
-/* dW[c][tap] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient) */
+/* dW[tap][c] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient, written in the Keras
+ * kernel layout (k, k, C, 1), i.e. straight into the flat gradient buffer) */
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);

@@ -497,7 +497,7 @@ __device__ __forceinline__ float lsh(float v) {  // value of lane (l + SH): one 
 
 template <int KS>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int RP, int relu_in,
-                                                        float* __restrict__ dW /*[CQ*4][KS*KS]*/, int tasks, int tasks_per_wave) {
+                                                        float* __restrict__ dW /*[KS*KS][C], Keras (k,k,C,1)*/, int tasks, int tasks_per_wave) {
   constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
   const int lane = threadIdx.x & 63;
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   __syncthreads();
   if (threadIdx.x < 4 * KK) {
     const int j = threadIdx.x / KK;
-    if (cq * 4 + j < C) atomicAdd(&dW[cq * 4 * KK + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const int t = threadIdx.x - j * KK;  // Keras depthwise kernel layout (k, k, C, 1): element (tap, channel) at tap*C + channel
+    if (cq * 4 + j < C) atomicAdd(&dW[t * C + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
@@ -685,6 +686,31 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_kernel(const float* __rest
   if (threadIdx.x < 4 * KK) {
     const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
     atomicAdd(&dW[t * 16 + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------- kernel-layout copies of the trunk weights, one launch per step
+// desc[i] = {type, src offset, dst offset, C, aux}: type 0 = Keras depthwise (k,k,C,1) -> [ceil(C/4)][k*k][4] (aux = k*k; zero taps for
+// the padding channels), type 1 = the same with the taps reversed (input-gradient conv), type 2 = pointwise (1,1,Cin,Cout) ->
+// transposed [Cout][Cin] (C = Cin, aux = Cout).  One workgroup per descriptor; replaces ~80 tiny framework kernels per step.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, const int* __restrict__ desc, float* __restrict__ out) {
+  const int* d = desc + blockIdx.x * 5;
+  const int type = d[0], C = d[3], aux = d[4];
+  const float* src = w + d[1];
+  float* dst = out + d[2];
+  if (type <= 1) {
+    const int KK = aux, CQ = (C + 3) >> 2;
+    for (int i = threadIdx.x; i < CQ * KK * 4; i += 256) {
+      const int j = i & 3, tap = (i >> 2) % KK, cq = (i >> 2) / KK;
+      const int c = cq * 4 + j, ts = type ? KK - 1 - tap : tap;
+      dst[i] = c < C ? src[ts * C + c] : 0.0f;
+    }
+  } else {
+    const int Cin = C, Cout = aux;
+    for (int i = threadIdx.x; i < Cin * Cout; i += 256) {
+      const int co = i / Cin, ci = i - co * Cin;
+      dst[i] = src[ci * Cout + co];
+    }
   }
 }
 
@@ -917,6 +943,12 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
   }
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);
   hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, dg, dgamma, C, 0);
+  return (int)hipGetLastError();
+}
+
+int orcai_pack_weights(const float* w, const int* desc, int n_desc, float* out, void* stream) {
+  if (!w || !desc || !out || n_desc <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(n_desc), dim3(256), 0, (hipStream_t)stream, w, desc, out);
   return (int)hipGetLastError();
 }
 

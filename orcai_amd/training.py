@@ -324,17 +324,6 @@ class TrunkTrainer:
     def _eye(self, c):
         return self._const(("eye", c), lambda: torch.eye(c, dtype=torch.float32, device=self.dev).contiguous())
 
-    def _dw_kernel_layout(self, name, flip: bool = False):
-        """Keras depthwise (k,k,c,1) -> [ceil(c/4)][k*k][4] (zero taps for the padding channels); flip = taps of the input gradient."""
-        w = self.P.W(name)
-        if flip:
-            w = w.flip(0, 1)
-        c, kk = w.shape[2], self.k * self.k
-        cq = (c + 3) // 4
-        out = torch.zeros((cq * 4, kk), dtype=torch.float32, device=self.dev)
-        out[:c] = w[:, :, :, 0].permute(2, 0, 1).reshape(c, kk)
-        return out.reshape(cq, 4, kk).permute(0, 2, 1).contiguous()
-
     def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0, u_out=None):
         N.check(self.lib.orcai_sepconv_planes_u(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
                                                 shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), None if u_out is None else u_out.data_ptr(),
@@ -385,6 +374,38 @@ class TrunkTrainer:
         b["dvf"] = self._planes(B, FINAL_FILTERS, h, w)
         b["dprev_f"] = self._planes(B, c, h, w)
         self.buf = b
+        self._build_pack_table()
+
+    def _build_pack_table(self):
+        """Descriptor table for orcai_pack_weights: depthwise taps (forward and reversed) and transposed pointwise / residual
+        weights of every layer, as views into one packed buffer refreshed once per step."""
+        P, m, k = self.P, self.model, self.k
+        desc, self.packed_views, off = [], {}, 0
+
+        def add(kind, name, C, aux, numel):
+            nonlocal off
+            desc.append([kind, P.offsets[name][0], off, C, aux])
+            self.packed_views[(kind, name)] = (off, numel)
+            off += (numel + 3) & ~3  # keep every view 16-byte aligned
+
+        names = []
+        c = 16
+        for i, f in enumerate(m.filters, start=1):
+            names += [(f"b{i}/sep_a", c, f), (f"b{i}/sep_b", f, f)]
+            add(2, f"b{i}/res/kernel", c, f, c * f)
+            c = f
+        names.append(("sep_f", c, FINAL_FILTERS))
+        for name, cin, cout in names:
+            cq4 = 4 * ((cin + 3) // 4)
+            add(0, name + "/depthwise", cin, k * k, cq4 * k * k)
+            add(1, name + "/depthwise", cin, k * k, cq4 * k * k)
+            add(2, name + "/pointwise", cin, cout, cin * cout)
+        self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=self.dev).contiguous()
+        self.packed = torch.empty(off, dtype=torch.float32, device=self.dev)
+
+    def _packed(self, kind, name, shape):
+        o, n = self.packed_views[(kind, name)]
+        return self.packed[o : o + n].view(shape)
 
     # ------------------------------------------------------------- forward
     def forward(self, src: torch.Tensor, snippet_stride: int, B: int) -> torch.Tensor:
@@ -394,6 +415,7 @@ class TrunkTrainer:
         lib, P, m, b, st = self.lib, self.P, self.model, self.buf, N.stream_ptr()
         self.stats = {}
         self.src, self.snippet_stride = src, snippet_stride
+        N.check(lib.orcai_pack_weights(P.w.data_ptr(), self.pack_desc.data_ptr(), int(self.pack_desc.shape[0]), self.packed.data_ptr(), st), "pack_weights")
         H, W = m.input_hw
         k = self.k
         shapes = m.stage_shapes()
@@ -409,7 +431,7 @@ class TrunkTrainer:
             self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
             for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], None, 0)):
                 name = f"b{i}/sep_{tag}"
-                self.dwl[name] = self._dw_kernel_layout(name + "/depthwise")
+                self.dwl[name] = self._packed(0, name + "/depthwise", (-1,))
                 self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
                 # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
                 self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None)
@@ -426,7 +448,7 @@ class TrunkTrainer:
                         "mask_scale")
                 prev = dropped
         h, w, _ = shapes[-1]
-        self.dwl["sep_f"] = self._dw_kernel_layout("sep_f/depthwise")
+        self.dwl["sep_f"] = self._packed(0, "sep_f/depthwise", (-1,))
         featv = torch.empty((B, h, w * FINAL_FILTERS), dtype=torch.float32, device=self.dev)
         self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1, u_out=b["u_f"])
         self.final_in = prev
@@ -444,7 +466,7 @@ class TrunkTrainer:
         then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
-        wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
+        wt = self._packed(2, name + "/pointwise", (Cout, Cin))  # pointwise^T [Cout][Cin]
         N.check(lib.orcai_bn_bwd_pointwise(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
@@ -460,13 +482,12 @@ class TrunkTrainer:
         N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                        self.partials.numel(), st), "outer_reduce")
         if not have_du:  # du = Wpw dv   (pointwise conv with the transposed weights)
-            wt = P.W(name + "/pointwise")[0, 0].t().contiguous()  # [Cout][Cin]
+            wt = self._packed(2, name + "/pointwise", (Cout, Cin))
             self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
-        dwg = torch.zeros((4 * ((Cin + 3) // 4), k * k), dtype=torch.float32, device=self.dev)
-        N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, dwg.data_ptr(), st), "dw_wgrad")
-        P.G(name + "/depthwise").copy_(dwg[:Cin].reshape(Cin, k, k).permute(1, 2, 0).unsqueeze(3))
+        # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
+        N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
         # dr = depthwise conv of du with the flipped taps (identity pointwise)
-        self._sep(du, Cin, H, W, k, 0, self._dw_kernel_layout(name + "/depthwise", flip=True), self._eye(Cin), self._zeros(64), Cin, dr)
+        self._sep(du, Cin, H, W, k, 0, self._packed(1, name + "/depthwise", (-1,)), self._eye(Cin), self._zeros(64), Cin, dr)
 
     def backward(self, dfeatv: torch.Tensor) -> None:
         """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
@@ -504,7 +525,7 @@ class TrunkTrainer:
                 N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
                 N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")
-            wrt = P.W(f"b{i}/res/kernel")[0, 0].t().contiguous()  # [f][cprev]
+            wrt = self._packed(2, f"b{i}/res/kernel", (f, cprev))  # residual weights transposed [f][cprev]
             self._sep(dout, f, ho, wo, 1, 0, self._ones(4 * ((f + 3) // 4)), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
             dprev = dr
         H, W = m.input_hw
