@@ -195,3 +195,31 @@ def test_lstm_oracle_agrees_with_torch_nn_lstm():
         want = ref(torch.tensor(x, dtype=torch.float64))[0].numpy()
     assert got.shape == want.shape == (B, T, 2 * u)
     assert np.abs(got - want).max() <= 1e-12
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(input_shape=(16, 9, 1), filters=(5, 6), kernel_size=3, lstm_units=8, num_labels=3),
+    dict(input_shape=(8, 12, 1), filters=(7,), kernel_size=5, lstm_units=6, num_labels=2),
+    dict(input_shape=(24, 7, 1), filters=(4, 5, 6), kernel_size=7, lstm_units=4, num_labels=4),
+])
+def test_two_independent_model_restatements_agree(cfg):
+    """the torch-functional oracle (model_ref) and the explicit-loop numpy restatement (model_ref_loops, written from the
+    Keras / TF documentation without a convolution library) agree on ResNetLSTM and ResNet1DConv for odd widths (asymmetric "same"
+    pooling pads), kernel sizes 3 / 5 / 7 and 1-3 blocks, in float64."""
+    import torch
+
+    from oracle import model_ref as M
+    from oracle import model_ref_loops as Lp
+
+    p = M.random_params(seed=4, **cfg)
+    rng = np.random.default_rng(4)
+    x = rng.random((2, *cfg["input_shape"]), dtype=np.float32)
+    ref = M.forward_ref(p, x, dtype=torch.float64)
+    for b in range(2):
+        assert np.abs(Lp.forward_one(p, x[b]) - ref[b]).max() <= 1e-10
+    q = {k: v for k, v in p.items() if not k.startswith(("lstm", "dense", "bn_d"))}
+    q["conv1d/kernel"] = (0.2 * rng.standard_normal((36, 36, cfg["num_labels"]))).astype(np.float32)
+    q["conv1d/bias"] = (0.1 * rng.standard_normal(cfg["num_labels"])).astype(np.float32)
+    ref1 = M.forward_ref_1dconv(q, x, dtype=torch.float64)
+    for b in range(2):
+        assert np.abs(Lp.forward_one_1dconv(q, x[b]) - ref1[b]).max() <= 1e-10
