@@ -279,6 +279,11 @@ def predict(recording_path: str | Path, channel: int = 1, model_dir: str | Path 
         recording_table = recording_table.iloc[mine]
     msgr.part(f"Predicting annotations for {len(recording_table)} wav files" + (f" (rank {rank} of {size})" if size > 1 else ""))
     progressbar = tqdm(recording_table.index, desc="Starting ...", unit="file", disable=verbosity < 1)
+    from orcai_amd import wavio
+
+    # decode the next recordings on background threads while the GPU works on the current one (the GPU needs ~60 ms per hour of audio)
+    wavio.set_prefetcher(wavio.WavPrefetcher([Path(recording_table.loc[i, "base_dir_recording"]).joinpath(recording_table.loc[i, "rel_recording_path"])
+                                              for i in recording_table.index]))
     for i in progressbar:
         try:
             _predict_and_save(recording_path=Path(recording_table.loc[i, "base_dir_recording"]).joinpath(recording_table.loc[i, "rel_recording_path"]),
@@ -287,4 +292,5 @@ def predict(recording_path: str | Path, channel: int = 1, model_dir: str | Path 
                               call_duration_limits=call_duration_limits, label_suffix=label_suffix, msgr=Messenger(verbosity=0), progressbar=progressbar)
         except Exception as e:  # predict.py:752-755: log and continue with the next recording
             msgr.error(f"Error predicting {recording_table.loc[i, 'recording']}: {e.args[0] if e.args else e}")
+    wavio.set_prefetcher(None)
     msgr.success("Predictions finished.")

@@ -18,7 +18,7 @@ from tqdm import tqdm
 from orcai_amd import frontend as fe
 from orcai_amd.auxiliary import Messenger
 from orcai_amd.io import read_json, save_array, write_vector_to_json
-from orcai_amd.wavio import read_wav
+from orcai_amd.wavio import read_wav_prefetched
 
 DEFAULT_ORCAI_PARAMETER = files("orcai_amd.defaults").joinpath("default_orcai_parameter.json")
 
@@ -26,7 +26,7 @@ DEFAULT_ORCAI_PARAMETER = files("orcai_amd.defaults").joinpath("default_orcai_pa
 def load_wav(wav_file_path: Path | str, sampling_rate: int, channel: int, msgr: Messenger) -> torch.Tensor:
     """``librosa.load(path, sr=sampling_rate, mono=False)`` + channel pick (spectrogram.py:23-31),
     returning the mono signal as a float32 tensor on the GPU at `sampling_rate`."""
-    wav, native_sr = read_wav(wav_file_path)  # [channels, frames]
+    wav, native_sr = read_wav_prefetched(wav_file_path)  # [channels, frames]; decoded ahead of time in table mode
     if wav.shape[0] > 1:
         msgr.warning(f"Multiple channels found, using channel {channel}")
         mono = wav[channel - 1]

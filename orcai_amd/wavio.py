@@ -82,3 +82,57 @@ def write_wav_pcm16(path: str | Path, samples: np.ndarray, rate: int) -> None:
     header += b"fmt " + struct.pack("<IHHIIHH", 16, WAVE_FORMAT_PCM, channels, rate, rate * channels * 2, channels * 2, 16)
     header += b"data" + struct.pack("<I", len(payload))
     Path(path).write_bytes(header + payload)
+
+
+class WavPrefetcher:
+    """Decodes the next recordings of a table on background threads while the GPU works on the current one.  The reference's table
+    mode is strictly serial (predict.py:729-755); on MI355X one hour of audio is ~60 ms of GPU work but several hundred ms of file
+    read + PCM16 -> float32 conversion, so without this the host side bounds table-mode throughput.  Order of results and error
+    behaviour are unchanged: a decode error surfaces when THAT recording is requested (and is logged per recording by the caller)."""
+
+    def __init__(self, paths, depth: int = 2, workers: int = 2):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.paths = [str(p) for p in paths]
+        self.depth = max(1, int(depth))
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="orcai-wav")
+        self.futures: dict[int, object] = {}
+        self.next_to_schedule = 0
+        self.index = {}
+        for i, p in enumerate(self.paths):
+            self.index.setdefault(p, []).append(i)
+
+    def _schedule_up_to(self, i: int) -> None:
+        while self.next_to_schedule < len(self.paths) and self.next_to_schedule <= i:
+            k = self.next_to_schedule
+            self.futures[k] = self.pool.submit(read_wav, self.paths[k])
+            self.next_to_schedule += 1
+
+    def get(self, path) -> tuple[np.ndarray, int]:
+        """The decoded recording (as read_wav) -- from the prefetch queue when it is one of the scheduled paths."""
+        slots = self.index.get(str(path))
+        if not slots:
+            return read_wav(path)
+        i = slots.pop(0)
+        self._schedule_up_to(i + self.depth)
+        fut = self.futures.pop(i)
+        return fut.result()
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=False, cancel_futures=True)
+        self.futures.clear()
+
+
+_prefetcher: WavPrefetcher | None = None
+
+
+def set_prefetcher(p: WavPrefetcher | None) -> None:
+    global _prefetcher
+    if _prefetcher is not None and p is not _prefetcher:
+        _prefetcher.close()
+    _prefetcher = p
+
+
+def read_wav_prefetched(path: str | Path) -> tuple[np.ndarray, int]:
+    """read_wav through the active WavPrefetcher, if any."""
+    return _prefetcher.get(path) if _prefetcher is not None else read_wav(path)

@@ -206,3 +206,37 @@ def test_recording_shorter_than_one_snippet_raises():
     for T in (735, 500, 368, 10):
         with pytest.raises(ValueError, match="too short"):
             compute_aggregated_predictions(Path("x.wav"), np.zeros((T, 171), dtype=np.float32), Fake(), param, shape, msgr=Messenger(verbosity=0))
+
+
+def test_wav_prefetcher_order_errors_and_fallback(tmp_path):
+    """Table-mode decode-ahead: same arrays as read_wav, in request order, duplicates and unknown paths handled, a missing file only
+    fails when it is requested."""
+    from orcai_amd import wavio
+
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(4):
+        p = tmp_path / f"r{i}.wav"
+        wavio.write_wav_pcm16(p, (rng.standard_normal((1 + i % 2, 1000 + 10 * i)) * 3000).astype(np.int16), 22050 + i)
+        paths.append(p)
+    missing = tmp_path / "missing.wav"
+    order = [paths[0], paths[1], missing, paths[2], paths[1], paths[3]]
+    pf = wavio.WavPrefetcher(order, depth=2, workers=2)
+    wavio.set_prefetcher(pf)
+    try:
+        for p in order:
+            if p == missing:
+                import pytest
+
+                with pytest.raises(FileNotFoundError):
+                    wavio.read_wav_prefetched(p)
+                continue
+            a, sr = wavio.read_wav_prefetched(p)
+            b, sr2 = wavio.read_wav(p)
+            assert sr == sr2 and np.array_equal(a, b)
+        other = tmp_path / "other.wav"
+        wavio.write_wav_pcm16(other, np.zeros(10, dtype=np.int16), 8000)
+        assert wavio.read_wav_prefetched(other)[1] == 8000  # not in the schedule: read directly
+    finally:
+        wavio.set_prefetcher(None)
+    assert wavio.read_wav_prefetched(paths[0])[1] == 22050  # no prefetcher: plain read
