@@ -151,3 +151,45 @@ def test_resnet_1dconv_training_step_vs_autograd(rate):
     # Adam + moving statistics run for this architecture as well
     tr.apply()
     assert bool(torch.isfinite(tr.P.w).all())
+
+
+def test_multi_step_trajectory_matches_oracle():
+    """Four optimisation steps (forward in training mode, backward, Keras-3 Adam, BN moving statistics) on the GPU against the same
+    four steps done with the CPU oracle (autograd gradients + adam_step_ref): weights, Adam slots and moving statistics stay together.
+    Zero-mean bias gradients are float noise in the oracle and exactly 0 here; Adam turns noise into O(lr) steps, so those biases
+    (which BatchNorm makes irrelevant to the function) are excluded from the weight comparison."""
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    cfg = dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=64, num_labels=3)
+    p = M.calibrated_params(seed=3, **cfg)
+    rng = np.random.default_rng(3)
+    B, lr = 4, 1e-3
+    xs = [rng.random((B, 32, 12, 1), dtype=np.float32) for _ in range(4)]
+    ys = [(rng.random((B, 8, 3)) > 0.5).astype(np.float32) for _ in range(4)]
+    model = ResNetLSTM(cfg["input_shape"], 3, [10, 20], 3, 0.0, 64)
+    model.set_weights_dict(p)
+    tr = Trainer(model, learning_rate=lr)
+    w = {k: np.asarray(v, dtype=np.float64) for k, v in p.items()}
+    m = {k: np.zeros_like(v) for k, v in w.items() if T.is_trainable(k)}
+    v2 = {k: np.zeros_like(v) for k, v in w.items() if T.is_trainable(k)}
+    for step in range(4):
+        ref = T.loss_and_grads(w, xs[step], ys[step], None, 0.0)
+        for k, g in ref["grads"].items():
+            w[k], m[k], v2[k] = T.adam_step_ref(w[k], g, m[k], v2[k], step + 1, lr)
+        for k, s in ref["new_stats"].items():
+            w[k] = s
+        out = tr.train_step(torch.from_numpy(np.ascontiguousarray(xs[step][..., 0])).cuda().view(-1), 32 * 12, B, torch.from_numpy(ys[step]).cuda())
+        acc = out["acc"].cpu().numpy()
+        assert abs(acc[0] / acc[1] + acc[3] - ref["loss"]) <= 1e-4 * max(1.0, abs(ref["loss"])), (step, acc, ref["loss"])
+    tr.P.to_model(model)
+    worst = {}
+    for k, want in w.items():
+        zero_mean_bias = k.endswith("/bias") and not k.startswith(("dense2", "lstm", "dense1")) and "res" not in k
+        if zero_mean_bias:
+            continue
+        got = model.weights[k].astype(np.float64)
+        err = float(np.abs(got - want).max()) / max(1e-2, float(np.abs(want).max()))
+        if err > 2e-3:  # four Adam steps of size lr = 1e-3 each: a sign flip of a near-zero gradient moves a weight by up to 2 lr
+            worst[k] = err
+    assert not worst, worst
