@@ -87,6 +87,7 @@ class ResNetLSTM:
         # recording): the 1.5x recomputation of the shared pooling row makes the kernel issue-bound.
         self.fuse_pool_min_width = int(os.environ.get("ORCAI_FUSE_POOL_MIN_WIDTH", "0")) or 10**9
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
+        self.kernel_event_labels = None  # bench hook: restrict the event brackets to these labels (an event pair costs ~15 us of queue time)
         # Inference trunk in two phases: blocks < tail_from_block in chunks of `chunk` snippets (their planes are large), the
         # later blocks (planes of a few thousand pixels: a chunk of 128 snippets is < 2 waves per SIMD) over up to tail_chunk snippets.
         self.tail_from_block = int(os.environ.get("ORCAI_TAIL_FROM_BLOCK", "3"))
@@ -319,7 +320,7 @@ class ResNetLSTM:
     def _launch(self, label: str, what: str, fn, *args) -> None:
         """Call one C-ABI launcher; optionally bracket it with HIP events on the launch stream (bench.py)."""
         ev = self.kernel_events
-        if ev is None:
+        if ev is None or (self.kernel_event_labels is not None and label not in self.kernel_event_labels):
             N.check(fn(*args), what)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
