@@ -117,6 +117,12 @@ int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int h
  * never write the pads, so "same" zero padding costs no bounds checks and every tile halo is one contiguous run. */
 int orcai_padded_width(int W, int ksize);
 
+/* Tuning knob of the separable-conv launcher: windows per wave of the streaming variant (sepconv_stream_kernel, used for
+ * k = 3, Cout in 17..32, Cin a multiple of 16 up to 32, plane or x-pooled output, no depthwise-output store); 0 selects the
+ * one-window-per-wave kernel everywhere.  Both variants perform the same arithmetic in the same order (bit-identical
+ * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
+int orcai_sepconv_stream_windows(int windows_per_wave);
+
 /* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
  *   in              f32, UNPADDED: snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
  *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is

@@ -131,6 +131,19 @@ __device__ __forceinline__ float lane_shift(float v) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// max(x, 0) as ONE v_max_f32: fmaxf() is compiled to two (a canonicalising v_max x, x first), and the depthwise stage of the
+// separable convolutions is bound by VALU issue.  Activations are finite, so NaN handling is irrelevant.
+__device__ __forceinline__ float max2(float a, float b) {  // one v_max_f32, no canonicalisation
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // Depthwise stage for one channel quad, lane = pixel.  rows[dy] = the quad's dwordx4 of window row dy; wq = the quad's taps
 // [k*k][4] (channel innermost, wave-uniform -> scalar loads); relu_lo = 0 (ReLU on load) or -inf.
 // By linearity the horizontal taps are applied to per-column partial sums: p_dx = sum_dy w[dy][dx] * a_dy (lane-local,
@@ -138,14 +151,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KS, bool RELU>
 __device__ __forceinline__ void dw_quad_impl(const float4 (&rows)[KS], const float* __restrict__ wq, float (&d)[4]) {
   constexpr int R = KS / 2;
-  constexpr float relu_lo = 0.0f;
   f32x2 p01[KS], p23[KS];
 #pragma unroll
   for (int dx = 0; dx < KS; ++dx) { p01[dx] = (f32x2){0.f, 0.f}; p23[dx] = (f32x2){0.f, 0.f}; }
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) {
-    const f32x2 a01 = {RELU ? fmaxf(rows[dy].x, relu_lo) : rows[dy].x, RELU ? fmaxf(rows[dy].y, relu_lo) : rows[dy].y};
-    const f32x2 a23 = {RELU ? fmaxf(rows[dy].z, relu_lo) : rows[dy].z, RELU ? fmaxf(rows[dy].w, relu_lo) : rows[dy].w};
+    const f32x2 a01 = {RELU ? relu1(rows[dy].x) : rows[dy].x, RELU ? relu1(rows[dy].y) : rows[dy].y};
+    const f32x2 a23 = {RELU ? relu1(rows[dy].z) : rows[dy].z, RELU ? relu1(rows[dy].w) : rows[dy].w};
 #pragma unroll
     for (int dx = 0; dx < KS; ++dx) {
       const float* w = wq + (dy * KS + dx) * 4;
@@ -336,6 +348,159 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
           if (oq * 4 + r < Cout) o[r] = v[r];
       }
     }
+  }
+}
+
+// =========================================================================================
+// sepconv_stream: the same arithmetic as sepconv_kernel<3, MT> for the layers that dominate inference (k = 3, plane or
+// x-pooled output, CQ input quads with CQ % 4 == 0), organised so that a wave's output stores drain while it is already
+// computing its next window.  Measured on sepconv_kernel: a wave holds its slot until its stores are acknowledged, so kernel
+// time was (loads + arithmetic) + writes.  Here one wave walks NW consecutive windows as ONE linear
+// stream of (window, quad) elements with the rows of the next three elements always in flight in four rotating register sets
+// (CQ % 4 == 0 keeps the rotation phase equal at every window boundary, so no register copies of in-flight loads).  vmcnt
+// retires in order on gfx9, so the epilogue's stores sit between the next window's first three row loads and its fourth:
+// the waits for quads 0..2 of the next window leave the stores outstanding (vmcnt(9 + S)), only quad 3's wait drains them.
+// Every memory instruction of the steady state is unconditional -- dead lanes store zeros to a padding pixel, the stream
+// tail re-loads clamped rows, the prologue issues S dummy stores -- so that the compiler's wait-count bookkeeping sees one
+// straight-line body whose entry state equals its back-edge state and emits exact partial waits instead of vmcnt(0).
+// Pointwise weights and the folded BN scale/shift come from LDS (no global load behind the row prefetches).
+// =========================================================================================
+template <int MT, int CQ, bool XP, bool RELU>
+__global__ __launch_bounds__(256, 4) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                              float* __restrict__ out, int tasks, uint32_t magic_WP, int NW) {
+  static_assert(CQ % 4 == 0 && CQ >= 4, "four rotating row sets");
+  constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  __shared__ float pw_s[CQ * 4 * 16 * MT];  // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
+  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
+  const int lane = threadIdx.x & 63;
+  int bx, b;
+  xcd_remap(bx, b);
+  // window w of this wave is task t0 + 4w: the four waves of a workgroup advance side by side through 4*NW consecutive
+  // windows, so vertically adjacent windows are in flight at the same time on one CU (row re-reads hit L1/L2 while hot)
+  const int t0 = bx * 4 * NW + (threadIdx.x >> 6);
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int CQo = (Cout + 3) >> 2;
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
+  const int dump = XP ? WPx - 1 : 0;  // a padding pixel of the snippet's first output plane (zero before and after)
+
+  // byte offsets of the three window rows inside a quad plane (clamped: only lanes whose outputs are discarded can leave
+  // the plane); 32-bit, so a load is "uniform quad base + lane offset" and needs one address register
+  auto row_index = [&](int t, uint32_t (&ri)[3]) {
+    const int q = R * WP + t * VAL - lo + lane;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int i = q + (dy - 1) * WP;
+      ri[dy] = (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+    }
+  };
+  auto load_row = [&](int e, uint32_t off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)e * plane) + off);
+  };
+
+  // The first three stream elements are requested before the LDS fill: the fill's own loads are younger, so its wait
+  // retires these too and the loop is entered with nothing outstanding (the state the steady-state wait counts assume).
+  float4 rows[4][3];
+  uint32_t rc[3];
+  row_index(min(t0, tasks - 1), rc);
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) rows[e][dy] = load_row(e, rc[dy]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 256) {
+    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
+  }
+  if (threadIdx.x < MT * 16) {
+    const int co = threadIdx.x;
+    sc_s[co] = co < Cout ? scale[co] : 0.0f;
+    sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  __syncthreads();  // the only barrier; waves are independent from here on
+  if (t0 >= tasks) return;
+  const int nw = min(NW, (tasks - t0 + 3) >> 2);
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int w = 0; w < nw; ++w) {
+    const int t = t0 + 4 * w;
+    uint32_t rn[3];
+    row_index(min(t + 4, tasks - 1), rn);
+    // the depthwise taps are re-read through the scalar cache every window: hoisted out of this loop, the CQ*36 scalars do
+    // not fit the SGPR file and come back as one v_readlane per tap
+    int opaque_zero = 0;
+    asm volatile("" : "+s"(opaque_zero));
+    const float* dww = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq) {
+      {  // stream element cq + 3: this window's quad cq + 3, or the next window's quad cq + 3 - CQ
+        const int e = cq + 3;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+          rows[e & 3][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the row loads are issued before any of the quad's arithmetic
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
+      float d[4];
+      dw_quad_impl<3, RELU>(rows[cq & 3], dww + cq * 4 * KK, d);
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
+    }
+    // ---- epilogue (see sepconv_kernel): D[row = 4*lk + r -> cout][col = lj -> pixel 16*tt + lj of the window]
+    // Written for VALU issue: single-instruction max, the column pair through a DPP quad permute, folded BN from LDS.
+    const int qbase = R * WP + t * VAL - lo;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int wl = 16 * tt + lj;
+      const int flat = qbase + wl;
+      const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+      const int x = flat - row * WP;
+      const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H && (!XP || (x & 1) == 0);
+      const bool pair_ok = x + 1 < W;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
+        float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = max2(v[r], lo_out);
+          if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
+            const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+            v[r] = max2(v[r], pair_ok ? other : v[r]);
+          }
+        }
+        const int oq = m * 4 + lk;
+        const bool ok = live && oq < CQo;
+        const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
+        // dead lanes: zeros to the padding pixel (plane output) / anything to the never-read padding column (x-pooled output)
+        const float4 val = (XP || ok) ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(outb) + (uint32_t)(ok ? idx : dump) * 16u) = val;
+        acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) rc[dy] = rn[dy];
   }
 }
 
@@ -1252,12 +1417,39 @@ struct SepArgs {
   float* u_out = nullptr;
 };
 
+int g_stream_windows = 2;  // windows per wave of sepconv_stream_kernel; 0 = use sepconv_kernel everywhere
+
+template <int MT, int CQ>
+int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
+  const int NW = g_stream_windows;
+  dim3 grid((tasks + 4 * NW - 1) / (4 * NW), a.B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
+#define ORCAI_STREAM_LAUNCH(XP, RELU)                                                                                                 \
+  hipLaunchKernelGGL((sepconv_stream_kernel<MT, CQ, XP, RELU>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
+                     a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), NW)
+  if (a.out_layout == 2) {
+    if (a.relu_in) ORCAI_STREAM_LAUNCH(true, true); else ORCAI_STREAM_LAUNCH(true, false);
+  } else {
+    if (a.relu_in) ORCAI_STREAM_LAUNCH(false, true); else ORCAI_STREAM_LAUNCH(false, false);
+  }
+#undef ORCAI_STREAM_LAUNCH
+  return (int)hipGetLastError();
+}
+
 template <int KS, int MT>
 int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   const int lo = (a.out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
   const int VAL = 64 - 2 * lo;
   const int tasks = (a.H * a.WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  if constexpr (KS == 3 && MT == 2) {
+    const int CQ = (a.Cin + 3) / 4, CQo = (a.Cout + 3) / 4, Wx = (a.W + 1) / 2;
+    const bool shape_ok = a.RP == 1 && !a.u_out && ((uintptr_t)a.dw & 15) == 0 && (a.out_layout == 0 || (a.out_layout == 2 && ((Wx + 3) & ~3) > Wx)) &&
+                          (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 28);
+    if (g_stream_windows > 0 && shape_ok) {
+      if (CQ == 4) return launch_sepconv_stream<2, 4>(st, a, tasks);
+      if (CQ == 8) return launch_sepconv_stream<2, 8>(st, a, tasks);
+    }
+  }
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pw, a.scale, a.shift, a.Cout, a.relu_out,
                      a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);
@@ -1294,6 +1486,12 @@ int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int 
 }
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
+
+int orcai_sepconv_stream_windows(int windows_per_wave) {
+  const int prev = g_stream_windows;
+  if (windows_per_wave >= 0 && windows_per_wave <= 64) g_stream_windows = windows_per_wave;
+  return prev;
+}
 
 int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
                         const float* shift, float* out, void* stream) {

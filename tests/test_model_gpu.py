@@ -185,3 +185,51 @@ def test_resnet_1dconv_forward(input_shape, filters, k):
     assert np.abs(o - ref).max() <= 1e-5, np.abs(o - ref).max()
     assert np.abs(o - M.forward_ref_1dconv(p, x, dtype=torch.float64)).max() <= 1e-5
     assert np.abs(model.predict(x, batch_size=2) - ref).max() <= 1e-5  # the keras-shaped entry point
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,layout,relu_in,relu_out", [
+    (16, 30, 736, 171, 0, 1, 1),   # orcai-V1 b1/sep_a
+    (30, 30, 736, 171, 2, 0, 0),   # orcai-V1 b1/sep_b (x-pooled output, odd W)
+    (13, 17, 9, 70, 0, 0, 1),      # ragged channels, few rows (tail windows), window crossing rows
+    (32, 32, 5, 64, 2, 1, 0),      # even W; Wx % 4 == 0 -> no padding column -> must fall back to the one-window kernel
+    (29, 32, 33, 118, 2, 1, 1),
+    (32, 20, 2, 61, 0, 1, 0),
+])
+def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, relu_out):
+    """sepconv_stream_kernel (several windows per wave, rows prefetched three quads deep) performs the arithmetic of
+    sepconv_kernel in the same order: outputs are equal bit for bit, plane pads stay zero, for every windows-per-wave setting."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(Cin * 1000 + Cout * 10 + layout)
+    B, CQ, CQo, WP = 3, (Cin + 3) // 4, (Cout + 3) // 4, lib.orcai_padded_width(W, 3)
+    x = torch.zeros(B, CQ * 4, H + 2, WP)
+    x[:, :Cin, 1:H + 1, :W] = torch.randn(B, Cin, H, W, generator=g)
+    planes = x.view(B, CQ, 4, H + 2, WP).permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    dw = torch.randn(CQ, 9, 4, generator=g).to(dev)
+    pw = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    scale, shift = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    Wx = (W + 1) // 2
+    oshape = (B, CQo, H + 2, WP, 4) if layout == 0 else (B, CQo, H, (Wx + 3) // 4 * 4, 4)
+
+    def run(nw):
+        prev = lib.orcai_sepconv_stream_windows(nw)
+        try:
+            out = torch.zeros(oshape, device=dev)
+            rc = lib.orcai_sepconv_bn(N.ptr(planes), B, Cin, H, W, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, relu_out, layout,
+                                      N.ptr(out), N.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            return out
+        finally:
+            lib.orcai_sepconv_stream_windows(prev)
+
+    ref = run(0)
+    assert float(ref.abs().max()) > 0
+    for nw in (1, 2, 5):
+        out = run(nw)
+        if layout == 0:
+            assert torch.equal(out, ref), nw
+        else:  # padding columns of the x-pooled buffer are never read and may hold anything
+            assert torch.equal(out[:, :, :, :Wx], ref[:, :, :, :Wx]), nw
