@@ -40,6 +40,8 @@ def kernel_costs():
         # pool + residual: read s (all), read prev at stride 2 (counted as the sampled quarter), write out
         costs[f"b{b}/pool_res"] = (4.0 * (h * w * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
     costs["sep_f"] = _sep_cost(60, 36, 46, 11)
+    # fused entry (orcai_conv0_sepconv): read the 1-channel snippet, write a1 and the (2i, 2j) subsample of the entry activation
+    costs["conv0+b1/sep_a"] = (4.0 * (736 * 171 * (1 + 30) + 368 * 86 * 16), costs["conv0"][1] + costs["b1/sep_a"][1])
     return costs
 
 
@@ -98,19 +100,28 @@ class PredictWorkload:
     def kernel_symbol(label: str) -> str:
         """HIP kernel symbol a timed label runs as (the name rocprofv3 --kernel-trace --stats reports): the separable-conv and
         pool kernels are templated on the tap size and on ceil(Cout/16) output tiles, so several layers share one symbol."""
+        from orcai_amd import _native as N
+
         couts = {"b1": 30, "b2": 40, "b3": 50, "b4": 60}
         if label == "conv0":
             return "conv0_kernel<3>"
+        if label == "conv0+b1/sep_a":
+            return "conv0_sep_kernel<2>"
         if label == "sep_f":
             return "sepconv_kernel<3, 3>"
         blk, _, op = label.partition("/")
+        if blk == "b1" and op in ("sep_a", "sep_b") and N.lib().orcai_sepconv_stream_windows(-1) > 0:
+            # streaming variant <MT, input quads, x-pooled output, ReLU on load>
+            return "sepconv_stream_kernel<2, 4, false, true>" if op == "sep_a" else "sepconv_stream_kernel<2, 8, true, false>"
         if blk in couts and op in ("sep_a", "sep_b"):
             return f"sepconv_kernel<3, {(couts[blk] + 15) // 16}>"
         if blk in couts and op == "pool_res":
             return f"pool_res_add_kernel<{(couts[blk] + 15) // 16}>"
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
-    DOMINANT = ("b1/sep_a", "b1/sep_b")  # the layers that run as sepconv_kernel<3, 2>, the top symbol of rocprofv3 --stats for this workload
+    # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
+    # (sepconv_stream_kernel<2, 8, true, false>) is the top symbol of rocprofv3 --stats for this workload
+    DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
 
     def roofline(self):
         """Dominant kernel SYMBOL (as rocprofv3 names it): average launch duration from HIP events recorded on the launch stream
@@ -199,7 +210,11 @@ class _TimedLib:
 
     @staticmethod
     def is_dominant(name, args):
-        return name == "orcai_sepconv_planes_u" and args[6] == 3 and (args[12] + 15) // 16 == 2  # ktap 3, ceil(Cout/16) = 2
+        if not (name == "orcai_sepconv_planes_u" and args[6] == 3 and (args[12] + 15) // 16 == 2):  # ktap 3, ceil(Cout/16) = 2
+            return False
+        # ... and not one of the launches the launcher hands to sepconv_stream_kernel (no depthwise-output store, plane or x-pooled
+        # output, 4 or 8 input quads), which rocprofv3 lists under another symbol
+        return bool(args[18]) or args[14] not in (0, 2) or (args[2] + 3) // 4 not in (4, 8)
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -289,7 +304,7 @@ class TrainWorkload:
             t = sum(a.elapsed_time(b) for a, b, _ in calls)
             by = sum(_train_call_bytes("orcai_sepconv_planes_u", args) for _, _, args in calls)
             ach = by / (t * 1e-3) / 1e9
-            out = {"bound": "hbm", "kernel": "sepconv_kernel<3, 2>", "layers": "block-1 separable convs of the step: 2 forward (with the depthwise output kept), 2 backward (reversed taps)",
+            out = {"bound": "hbm", "kernel": "sepconv_kernel<3, 2>", "layers": "separable convs of the step with 17..32 output channels that keep the depthwise output or have 10 input quads: block 1 forward (2), block 2 input gradient (1)",
                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                    "kernel_ms": round(t / len(calls), 4), "launches_per_step": len(calls) // max(1, n_steps), "algorithmic_bytes_per_launch": round(by / len(calls))}
         flops = 3.0 * FWD_FLOP_PER_SNIPPET * self.B  # fwd + bwd ~ 3x forward

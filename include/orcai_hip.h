@@ -132,6 +132,17 @@ int orcai_sepconv_stream_windows(int windows_per_wave);
 int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale,
                         const float* shift, float* out, void* stream);
 
+/* Entry convolution fused into the first separable convolution, k = 3, inference (architectures.py:164-179):
+ *   Conv2D(16, 3, same) + BN + ReLU  ->  ReLU -> SeparableConv2D(Cout, 3, same) -> BN -> [ReLU]
+ * = orcai_conv0_bn_relu followed by orcai_sepconv_bn(relu_in = 1, out_layout = 0), bit for bit, without the 16-channel entry
+ * activation ever reaching HBM.  in / snippet_stride / w0 / scale0 / shift0 as for orcai_conv0_bn_relu; dw f32[4][9][4],
+ * pw f32[16][Cout], scale / shift f32[Cout] as for orcai_sepconv_bn; out: padded channel-quad planes of Cout channels.
+ *   prev_sub (may be NULL)  f32[B][4][ceil(H/2)][ceil(W/2)][4]: the entry activation at pixels (2i, 2j) only -- all that the
+ *                           strided 1x1 residual convolution of block 1 reads (orcai_pool_res_add with flag 2). */
+int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w0, const float* scale0, const float* shift0,
+                        const float* dw, const float* pw, const float* scale, const float* shift, int Cout, int relu_out, float* out, float* prev_sub,
+                        void* stream);
+
 /* [ReLU] -> SeparableConv2D(Cout, k, same) -> BN -> [ReLU]   (architectures.py:174-189, :198-206)
  *   in   f32[B][Cin][HP][WP] padded planes
  *   dw   f32[Cin][k*k]   (Keras depthwise kernel (k,k,Cin,1) transposed)
@@ -156,8 +167,9 @@ int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const 
                      const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
 
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
- *   s: padded channel-quad planes of C channels (xpooled = 0) or the x-pooled tensor written by
- *   orcai_sepconv_bn(out_layout = 2) (xpooled = 1); prev: padded channel-quad planes of Cp channels; wr f32[Cp][C], br f32[C]
+ *   xpooled is a flag word.  Bit 0: s is the x-pooled tensor written by orcai_sepconv_bn(out_layout = 2) instead of padded
+ *   channel-quad planes of C channels.  Bit 1: prev is the compact subsample f32[B][ceil(Cp/4)][ceil(H/2)][ceil(W/2)][4] of
+ *   pixels (2i, 2j) written by orcai_conv0_sepconv instead of padded channel-quad planes of Cp channels.  wr f32[Cp][C], br f32[C]
  *   -> out f32[B][C][ceil(H/2) + 2*(k/2)][orcai_padded_width(ceil(W/2), k)] padded planes */
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br,
                        float* out, int xpooled, void* stream);

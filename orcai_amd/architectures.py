@@ -86,6 +86,9 @@ class ResNetLSTM:
         # residual (orcai_sep_pool_res).  Measured slower than the unfused pair on every block (b1 22.2 vs 19.8 ms per 1 h
         # recording): the 1.5x recomputation of the shared pooling row makes the kernel issue-bound.
         self.fuse_pool_min_width = int(os.environ.get("ORCAI_FUSE_POOL_MIN_WIDTH", "0")) or 10**9
+        # inference, k = 3: the entry convolution is computed inside the first separable convolution (orcai_conv0_sepconv); the
+        # 16-channel entry activation never reaches HBM, block 1's residual branch reads a quarter-size subsample of it
+        self.fuse_entry = os.environ.get("ORCAI_FUSE_ENTRY", "1") != "0"
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
         self.kernel_event_labels = None  # bench hook: restrict the event brackets to these labels (an event pair costs ~15 us of queue time)
         # Inference trunk in two phases: blocks < tail_from_block in chunks of `chunk` snippets (their planes are large), the
@@ -291,6 +294,9 @@ class ResNetLSTM:
         ws = {}
         if need_input:
             ws[f"prev{first - 1}"] = planes(shapes[first - 1][2], shapes[first - 1][0], shapes[first - 1][1])
+            if first == 1:  # compact (2i, 2j) subsample of the entry activation for the fused entry path
+                h0, w0, c0 = shapes[0]
+                ws["prev0s"] = torch.zeros((B, (c0 + 3) // 4, (h0 + 1) // 2, (w0 + 1) // 2, 4), dtype=torch.float32, device=dev)
         for b in range(first, last + 1):
             f = self.filters[b - 1]
             h, wd, _ = shapes[b - 1]
@@ -344,7 +350,8 @@ class ResNetLSTM:
         H, W = self.input_hw
         k = self.kernel_size
         shapes = self.stage_shapes()
-        if first == 0:
+        fuse_entry = first == 0 and last >= 1 and k == 3 and self.fuse_entry and keep is None and self.filters[0] <= 64
+        if first == 0 and not fuse_entry:
             self._launch("conv0", "orcai_conv0_bn_relu", lib.orcai_conv0_bn_relu, src.data_ptr(), snippet_stride, B, H, W, k, N.ptr(d["conv0/w"]),
                          N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(ws["prev0"]), st)
         for b in range(max(first, 1), min(last, nb) + 1):
@@ -353,7 +360,15 @@ class ResNetLSTM:
             h, wd, _ = shapes[b - 1]
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
-            if k == 3 and wd >= self.fuse_min_width and f <= 40 and keep is None:
+            entry = fuse_entry and b == 1
+            if entry:
+                prev = ws["prev0s"]
+                self._launch("conv0+b1/sep_a", "orcai_conv0_sepconv", lib.orcai_conv0_sepconv, src.data_ptr(), snippet_stride, B, H, W, N.ptr(d["conv0/w"]),
+                             N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
+                             N.ptr(d[pa + "/shift"]), f, 1, N.ptr(a), N.ptr(prev), st)
+                self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
+                             N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
+            elif k == 3 and wd >= self.fuse_min_width and f <= 40 and keep is None:
                 # both separable convs in one kernel: the intermediate activation never leaves the registers
                 fused = lib.orcai_block_sep2 if self.fuse_variant == "lds" else lib.orcai_block_rows
                 self._launch(f"b{b}/sep_ab", "orcai_block_rows", fused, N.ptr(prev), B, c, f, h, wd, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
@@ -371,7 +386,7 @@ class ResNetLSTM:
                 self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
                              N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
-                         N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 1, st)
+                         N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 3 if entry else 1, st)
         if last == nb + 1:
             h, wd, c = shapes[-1]
             self._launch("sep_f", "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(ws[f"prev{nb}"]), B, c, h, wd, k, 0, N.ptr(d["sep_f/dw"]), N.ptr(d["sep_f/pw"]),
@@ -384,6 +399,8 @@ class ResNetLSTM:
                 chans.update({f"a{i}": f, f"b{i}": f, f"prev{i}": f})
                 widths.update({f"a{i}": shapes[i - 1][1], f"b{i}": shapes[i - 1][1], f"prev{i}": shapes[i][1]})
             for name, t in ws.items():
+                if name == "prev0s":  # only written by the fused entry path, which the keep hook does not use
+                    continue
                 if name.startswith("b"):  # x-pooled (unpadded rows): [B][CQ][H][WPx][4] -> [B][C][H][ceil(W/2)]
                     t = t[:B]  # the workspace may be larger than this chunk
                     Bq, CQ, hh, WPx, _ = t.shape

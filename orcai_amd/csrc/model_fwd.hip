@@ -352,6 +352,145 @@ __global__ __launch_bounds__(256) void sepconv_kernel(const float* __restrict__ 
 }
 
 // =========================================================================================
+// conv0_sep: the entry convolution fused into the first separable convolution (inference only):
+//   Conv2D(16, 3x3, same) + BN + ReLU  ->  [ReLU] -> depthwise 3x3 -> pointwise + bias -> BN -> [ReLU]   (architectures.py:164-179)
+// The 16-channel entry activation (15 GB per hour of audio) is never written to nor read back from HBM: a wave computes it
+// for its 64-pixel window at the three rows the depthwise stage needs, straight from the 1-channel spectrogram, one channel
+// quad at a time, and hands the quad to the same depthwise / transpose / MFMA pipeline as sepconv_kernel.  The recomputation
+// (three rows) is VALU work on a kernel that was bound by its loads; results are bit-identical to conv0_kernel followed by
+// sepconv_kernel (same fma chains in the same order).
+//   * input: 15 dwords per lane (5 rows x 3 columns) through a raw buffer resource over the snippet's H*W floats: rows outside
+//     the snippet and columns outside the image (offset sentinel) are out of range and read as 0 = the "same" zero padding;
+//   * the entry activation must itself be zero outside the image (it is the depthwise stage's padding): v_med3(x, 0, hi) with
+//     hi = +inf inside / 0 outside is ReLU and mask in one instruction;
+//   * the residual branch of block 1 (1x1 conv, stride 2) only ever samples pixels (2i, 2j): those are written to a compact
+//     [B][4][ceil(H/2)][ceil(W/2)][4] tensor (1/4 of the activation) that orcai_pool_res_add reads with flag 2.
+// =========================================================================================
+__device__ __forceinline__ float relu_mask(float x, float hi) {  // min(max(x, 0), hi), hi in {0, +inf}
+  float r;
+  asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+  return r;
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
+                                                         const float* __restrict__ w0 /*[9][16]*/, const float* __restrict__ sc0, const float* __restrict__ sh0,
+                                                         const float* __restrict__ dw /*[4][9][4]*/, const float* __restrict__ pw /*[16][Cout]*/,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                         float* __restrict__ out /*[B][CQo][H+2][WP][4]*/, float* __restrict__ prev_sub, int tasks, uint32_t magic_WP) {
+  constexpr int R = 1, lo = 1, VAL = 62, C0 = 16;
+  const int lane = threadIdx.x & 63;
+  int bx, b;
+  xcd_remap(bx, b);
+  const int task = bx * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;  // whole wave; no barriers
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int CQo = (Cout + 3) >> 2;
+  const int qbase = R * WP + task * VAL - lo;
+  const int q = qbase + lane;
+  const int prow = (int)__umulhi((uint32_t)q, magic_WP);
+  const int x = q - prow * WP, iy = prow - R;  // image coordinates of this lane's pixel (iy >= -1; x >= W: padding column)
+
+  // ---- the 5 x 3 input neighbourhood
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a few row pitches
+  const uint32_t center = (uint32_t)((iy * W + x) * 4);
+  const uint32_t off[3] = {(x >= 1 && x <= W) ? center - 4u : OOB, x < W ? center : OOB, x + 1 < W ? center + 4u : OOB};
+  float inp[5][3];
+#pragma unroll
+  for (int d = 0; d < 5; ++d)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      inp[d][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 2) * W * 4), 0, 0));
+  float hi[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) hi[r] = (x < W && iy + r - 1 >= 0 && iy + r - 1 < H) ? INFINITY : 0.0f;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+  const bool sub_lane = prev_sub && lane >= lo && lane < 64 - lo && x < W && iy >= 0 && iy < H && ((x | iy) & 1) == 0;
+
+#pragma unroll
+  for (int cq = 0; cq < C0 / 4; ++cq) {
+    float afrag[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int ci = cq * 4 + lk, co = m * 16 + lj;
+      const float av = pw[co < Cout ? ci * Cout + co : 0];
+      afrag[m] = co < Cout ? av : 0.0f;
+    }
+    // entry convolution of channels 4cq..4cq+3 at rows iy-1, iy, iy+1: the fma chain of conv0_kernel (taps in dy, dx order)
+    const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
+    const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
+    float4 c0[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
+          const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
+          const f32x2 v = {inp[r + dy][dx], inp[r + dy][dx]};
+          a01 = v * w01 + a01;
+          a23 = v * w23 + a23;
+        }
+      a01 = a01 * s01 + h01;
+      a23 = a23 * s23 + h23;
+      c0[r] = make_float4(relu_mask(a01.x, hi[r]), relu_mask(a01.y, hi[r]), relu_mask(a23.x, hi[r]), relu_mask(a23.y, hi[r]));
+    }
+    if (sub_lane) reinterpret_cast<float4*>(prev_sub)[(((int64_t)b * (C0 / 4) + cq) * Ho + (iy >> 1)) * Wo + (x >> 1)] = c0[1];
+    float d[4];
+    dw_quad_impl<3, false>(c0, dw + cq * 36, d);  // the entry activation is already >= 0: the separable conv's ReLU is the identity
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+  }
+
+  // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> pixel 16t + lj of the window]
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+  float sc_r[MT][4], sh_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      sc_r[m][r] = co < Cout ? scale[co] : 0.0f;
+      sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
+    }
+  float4* outq = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int wl = 16 * t + lj;
+    const int flat = qbase + wl;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+    const int xx = flat - row * WP;
+    const bool live = wl >= lo && wl < 64 - lo && xx < W && row < R + H;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      if (!live || oq >= CQo) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = max2(fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]), lo_out);  // channels past Cout: max(0*0+0, lo)
+      outq[(int64_t)oq * plane + flat] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// =========================================================================================
 // sepconv_stream: the same arithmetic as sepconv_kernel<3, MT> for the layers that dominate inference (k = 3, plane or
 // x-pooled output, CQ input quads with CQ % 4 == 0), organised so that a wave's output stores drain while it is already
 // computing its next window.  Measured on sepconv_kernel: a wave holds its slot until its stores are acknowledged, so kernel
@@ -1042,13 +1181,15 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
   if (task >= tasks) return;
   const int lk = lane >> 4, lj = lane & 15;
   const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const int plane = (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
+  const bool prev_compact = (xpooled & 2) != 0;  // prev = [B][CQp][Ho][Wo][4]: only the pixels (2i, 2j) the strided 1x1 conv samples
+  xpooled &= 1;
+  const int plane = prev_compact ? Ho * Wo : (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
   const int qbase = R * WPo + task * 64;
   const int q = qbase + lane;
   const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
   const int pj = q - prow * WPo, pi = prow - R;
   const bool pvalid = pj < Wo && pi < Ho;
-  const int srcpix = pvalid ? (2 * pi + R) * WP + 2 * pj : 0;
+  const int srcpix = pvalid ? (prev_compact ? pi * Wo + pj : (2 * pi + R) * WP + 2 * pj) : 0;
   const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + srcpix;
 
   f32x4 acc[MT][4];
@@ -1513,6 +1654,28 @@ int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, in
   return (int)hipGetLastError();
 }
 
+int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w0, const float* scale0, const float* shift0,
+                        const float* dw, const float* pw, const float* scale, const float* shift, int Cout, int relu_out, float* out, float* prev_sub,
+                        void* stream) {
+  if (!in || !w0 || !scale0 || !shift0 || !dw || !pw || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
+  if (Cout > 64 || (int64_t)H * W >= (1ll << 28) || (((uintptr_t)w0 | (uintptr_t)dw) & 15)) return ORCAI_E_UNSUPPORTED;
+  const int WP = orcai_padded_width(W, 3);
+  if ((int64_t)(H + 2) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  const int tasks = (H * WP + 61) / 62;
+  dim3 grid((tasks + 3) / 4, B);
+  hipStream_t st = (hipStream_t)stream;
+#define ORCAI_C0S(MT) hipLaunchKernelGGL(conv0_sep_kernel<MT>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, \
+                                         Cout, relu_out, out, prev_sub, tasks, magic_for(WP))
+  switch ((Cout + 15) / 16) {
+    case 1: ORCAI_C0S(1); break;
+    case 2: ORCAI_C0S(2); break;
+    case 3: ORCAI_C0S(3); break;
+    case 4: ORCAI_C0S(4); break;
+  }
+#undef ORCAI_C0S
+  return (int)hipGetLastError();
+}
+
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream) {
   return orcai_sepconv_planes(in, B, Cin, H, W, ksize, ksize, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, 0, 0, out, stream);
@@ -1612,7 +1775,8 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
   if (tot_w < 0) tot_w = 0;
-  if (xpooled && tot_w / 2 != 0) return ORCAI_E_UNSUPPORTED;
+  if ((xpooled & 1) && tot_w / 2 != 0) return ORCAI_E_UNSUPPORTED;
+  if (xpooled & ~3) return ORCAI_E_BADARG;
   if (bn_mean && (xpooled || !bn_var || !bn_gamma || !bn_beta)) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize), WPo = orcai_padded_width(Wo, ksize), R = ksize / 2;
   const int tasks = (Ho * WPo + 63) / 64;

@@ -233,3 +233,41 @@ def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, re
             assert torch.equal(out, ref), nw
         else:  # padding columns of the x-pooled buffer are never read and may hold anything
             assert torch.equal(out[:, :, :, :Wx], ref[:, :, :, :Wx]), nw
+
+
+@pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])
+def test_fused_entry_convolution_is_bit_identical(shape, filters):
+    """orcai_conv0_sepconv (entry convolution computed inside block 1's first separable convolution, compact (2i, 2j) subsample for
+    the residual branch) against orcai_conv0_bn_relu + orcai_sepconv_bn: the same fma chains in the same order, so the block-1
+    activation, the subsample and the model output are equal bit for bit; odd and even H / W, rows shorter than a window."""
+    from orcai_amd import _native as N
+
+    model, p = make_model(21, input_shape=shape, filters=filters, kernel_size=3, lstm_units=64, num_labels=3)
+    x = np.random.default_rng(6).random((3, *shape), dtype=np.float32)
+    model.fuse_entry = False
+    unfused = model.predict(x, batch_size=3)
+    model.fuse_entry = True
+    fused = model.predict(x, batch_size=3)
+    assert np.array_equal(fused, unfused), np.abs(fused - unfused).max()
+    assert np.abs(fused - M.forward_ref(p, x)).max() <= 1e-5
+
+    # the two outputs of the fused kernel themselves
+    lib, d = N.lib(), model.prepare()
+    dev = torch.device("cuda", 0)
+    H, W = shape[:2]
+    f, B = filters[0], 3
+    WP, CQo = lib.orcai_padded_width(W, 3), (f + 3) // 4
+    xs = torch.from_numpy(x).to(dev).contiguous()
+    prev0 = torch.zeros((B, 4, H + 2, WP, 4), device=dev)
+    a_ref, a_fused = torch.zeros((B, CQo, H + 2, WP, 4), device=dev), torch.zeros((B, CQo, H + 2, WP, 4), device=dev)
+    sub = torch.zeros((B, 4, (H + 1) // 2, (W + 1) // 2, 4), device=dev)
+    st = N.stream_ptr()
+    w = lambda k: N.ptr(d[k])  # noqa: E731
+    assert lib.orcai_conv0_bn_relu(xs.data_ptr(), H * W, B, H, W, 3, w("conv0/w"), w("conv0/scale"), w("conv0/shift"), N.ptr(prev0), st) == 0
+    assert lib.orcai_sepconv_bn(N.ptr(prev0), B, 16, H, W, 3, 1, w("b1/sep_a/dw"), w("b1/sep_a/pw"), w("b1/sep_a/scale"), w("b1/sep_a/shift"), f, 1, 0,
+                                N.ptr(a_ref), st) == 0
+    assert lib.orcai_conv0_sepconv(xs.data_ptr(), H * W, B, H, W, w("conv0/w"), w("conv0/scale"), w("conv0/shift"), w("b1/sep_a/dw"), w("b1/sep_a/pw"),
+                                   w("b1/sep_a/scale"), w("b1/sep_a/shift"), f, 1, N.ptr(a_fused), N.ptr(sub), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a_fused, a_ref)  # pads included
+    assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :])
