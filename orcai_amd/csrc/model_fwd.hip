@@ -1283,6 +1283,131 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
   }
 }
 
+// pool_res_add for the inference path (s x-pooled, no BatchNorm on the fly): the same arithmetic as pool_res_add_kernel, with
+// the pooling loads made unconditional (row index clamped into the image: a duplicated row leaves a maximum unchanged) so that
+// they can be issued ahead of their use -- the loads of two 16-pixel tiles are in flight while the residual 1x1 convolution's
+// MFMAs run, instead of 24 load -> wait -> max round trips per wave.
+template <int MT>
+__global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(const float* __restrict__ s /*[B][CQ][H][WPx][4]*/, const float* __restrict__ prev, int C, int Cp, int H,
+                                                              int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, const float* __restrict__ wr /*[Cp][C]*/,
+                                                              const float* __restrict__ br, float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int prev_compact,
+                                                              int tasks, uint32_t magic_WPo) {
+  const int lane = threadIdx.x & 63;
+  int bx, b;
+  xcd_remap(bx, b);
+  const int task = bx * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
+  const int plane = prev_compact ? Ho * Wo : (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
+  const int WPx = (Wo + 3) & ~3;
+  const int qbase = R * WPo + task * 64;
+
+  // pooling operands: output pixel 16t + lj of the window, output quad m*4 + lk, rows 2i - pad_top + {0, 1, 2}
+  int soff[4][3], oidx[4];  // float4 index inside one quad plane of s; output pixel index (or -1)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int flat = qbase + 16 * t + lj;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);
+    const int j = flat - row * WPo, i = row - R;
+    const bool valid = j < Wo && i < Ho;
+    oidx[t] = valid ? flat : -1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      int y = 2 * i - pad_top + dy;
+      y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      soff[t][dy] = valid ? y * WPx + j : 0;
+    }
+  }
+  // uniform base of the snippet's planes + 32-bit byte offset per lane: one address register per load
+  const char* sbase = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(s) + (int64_t)b * CQ * H * WPx);
+  uint32_t qoff[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int oq = m * 4 + lk;
+    qoff[m] = (uint32_t)((oq < CQ ? oq : 0) * H * WPx);
+  }
+  float4 v[4][MT][3];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) v[t][m][dy] = *reinterpret_cast<const float4*>(sbase + (qoff[m] + (uint32_t)soff[t][dy]) * 16u);
+  };
+  float br_r[MT][4];  // residual bias of this lane's output channels
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      const float bv = br[co < C ? co : 0];
+      br_r[m][r] = co < C ? bv : 0.0f;
+    }
+  constexpr int DEPTH = MT <= 2 ? 2 : 1;  // 16-pixel tiles of pooling operands in flight (12 * MT VGPRs each)
+  load_tile(0);
+  if (DEPTH > 1) load_tile(1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // residual branch: Conv2D(C, 1, strides 2)(prev) at this window's 64 output pixels (lane = pixel)
+  const int q = qbase + lane;
+  const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
+  const int pj = q - prow * WPo, pi = prow - R;
+  const bool pvalid = pj < Wo && pi < Ho;
+  const int srcpix = pvalid ? (prev_compact ? pi * Wo + pj : (2 * pi + R) * WP + 2 * pj) : 0;
+  const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + srcpix;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 nxt = pp[0];
+  for (int cq = 0; cq < CQp; ++cq) {
+    const float4 cur = nxt;
+    if (cq + 1 < CQp) nxt = pp[(int64_t)(cq + 1) * plane];
+    float afrag[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int ci = cq * 4 + lk, co = m * 16 + lj;
+      const bool ok = ci < Cp && co < C;
+      const float av = wr[ok ? ci * C + co : 0];
+      afrag[m] = ok ? av : 0.0f;
+    }
+    float d[4] = {cur.x, cur.y, cur.z, cur.w};
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
+  }
+
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oq = m * 4 + lk;
+      float mx[4] = {v[t][m][0].x, v[t][m][0].y, v[t][m][0].z, v[t][m][0].w};
+#pragma unroll
+      for (int dy = 1; dy < 3; ++dy) {
+        mx[0] = fmaxf(mx[0], v[t][m][dy].x); mx[1] = fmaxf(mx[1], v[t][m][dy].y);
+        mx[2] = fmaxf(mx[2], v[t][m][dy].z); mx[3] = fmaxf(mx[3], v[t][m][dy].w);
+      }
+      if (oidx[t] >= 0 && oq < CQ) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f;
+        reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + oidx[t]] = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    if (t + DEPTH < 4) {
+      load_tile(t + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // =========================================================================================
 // gemm: C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]     (LSTM input projections, Dense-128)
 // 128 x 128 block tile, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (4 x 4 MFMA 16x16x4 tiles).
@@ -1783,7 +1908,12 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   dim3 grid((tasks + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t mg = magic_for(WPo);
-#define ORCAI_POOL_LAUNCH(MT) hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps)
+#define ORCAI_POOL_LAUNCH(MT)                                                                                                                        \
+  if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                     \
+    hipLaunchKernelGGL(pool_res_add_x_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out, (xpooled >> 1) & 1, \
+                       tasks, mg);                                                                                                                   \
+  else                                                                                                                                               \
+    hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps)
   switch ((C + 15) / 16) {
     case 1: ORCAI_POOL_LAUNCH(1); break;
     case 2: ORCAI_POOL_LAUNCH(2); break;

@@ -15,7 +15,7 @@ spec = FrontEnd(dev).make_spectrogram(pcm, SPEC_PARAM)
 model = ResNetLSTM((736, 171, 1), 7, [30, 40, 50, 60], 3, 0.0, 128, seed=1)
 model.prepare()
 ref = None
-for fuse in (False, True, False, True):
+for fuse in (False, True):
     model.fuse_entry = fuse
     for it in range(3):
         model.kernel_events = {}
