@@ -123,6 +123,10 @@ int orcai_padded_width(int W, int ksize);
  * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_stream_windows(int windows_per_wave);
 
+/* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current
+ * one is computed).  Returns the previous value; values outside [1, 64] only query. */
+int orcai_entry_windows(int windows_per_wave);
+
 /* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
  *   in              f32, UNPADDED: snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
  *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is

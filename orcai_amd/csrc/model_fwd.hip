@@ -374,119 +374,162 @@ __device__ __forceinline__ float relu_mask(float x, float hi) {  // min(max(x, 0
 
 template <int MT>
 __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
-                                                         const float* __restrict__ w0 /*[9][16]*/, const float* __restrict__ sc0, const float* __restrict__ sh0,
-                                                         const float* __restrict__ dw /*[4][9][4]*/, const float* __restrict__ pw /*[16][Cout]*/,
+                                                         const float* __restrict__ w0_ /*[9][16]*/, const float* __restrict__ sc0_, const float* __restrict__ sh0_,
+                                                         const float* __restrict__ dw_ /*[4][9][4]*/, const float* __restrict__ pw /*[16][Cout]*/,
                                                          const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                         float* __restrict__ out /*[B][CQo][H+2][WP][4]*/, float* __restrict__ prev_sub, int tasks, uint32_t magic_WP) {
+                                                         float* __restrict__ out /*[B][CQo][H+2][WP][4]*/, float* __restrict__ prev_sub, int tasks, uint32_t magic_WP,
+                                                         int NW) {
+  // A wave walks NW windows (task t0 + 4w: the four waves of a workgroup side by side) with the NEXT window's 15 input dwords
+  // in flight while it computes the current one -- a one-window wave spent a quarter of its life waiting for its inputs.
+  // Two register sets in a loop unrolled by two (no copies of in-flight registers); the epilogue's stores are unconditional
+  // (dead lanes: zeros to a padding pixel), so that the compiler's wait counts are exact and the stores drain behind the
+  // next window's arithmetic.
   constexpr int R = 1, lo = 1, VAL = 62, C0 = 16;
+  __shared__ float pw_s[C0 * 16 * MT];  // [(ci * 16 + lj)][m]
+  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
   const int lane = threadIdx.x & 63;
   int bx, b;
   xcd_remap(bx, b);
-  const int task = bx * 4 + (threadIdx.x >> 6);
-  if (task >= tasks) return;  // whole wave; no barriers
+  const int t0 = bx * 4 * NW + (threadIdx.x >> 6);
+  const int nw = min(NW, (tasks - t0 + 3) >> 2);
   const int lk = lane >> 4, lj = lane & 15;
   const int plane = (H + 2 * R) * WP;
   const int CQo = (Cout + 3) >> 2;
-  const int qbase = R * WP + task * VAL - lo;
-  const int q = qbase + lane;
-  const int prow = (int)__umulhi((uint32_t)q, magic_WP);
-  const int x = q - prow * WP, iy = prow - R;  // image coordinates of this lane's pixel (iy >= -1; x >= W: padding column)
-
-  // ---- the 5 x 3 input neighbourhood
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
-  constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a few row pitches
-  const uint32_t center = (uint32_t)((iy * W + x) * 4);
-  const uint32_t off[3] = {(x >= 1 && x <= W) ? center - 4u : OOB, x < W ? center : OOB, x + 1 < W ? center + 4u : OOB};
-  float inp[5][3];
-#pragma unroll
-  for (int d = 0; d < 5; ++d)
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      inp[d][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 2) * W * 4), 0, 0));
-  float hi[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) hi[r] = (x < W && iy + r - 1 >= 0 && iy + r - 1 < H) ? INFINITY : 0.0f;
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-  const bool sub_lane = prev_sub && lane >= lo && lane < 64 - lo && x < W && iy >= 0 && iy < H && ((x | iy) & 1) == 0;
-
-#pragma unroll
-  for (int cq = 0; cq < C0 / 4; ++cq) {
-    float afrag[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int ci = cq * 4 + lk, co = m * 16 + lj;
-      const float av = pw[co < Cout ? ci * Cout + co : 0];
-      afrag[m] = co < Cout ? av : 0.0f;
-    }
-    // entry convolution of channels 4cq..4cq+3 at rows iy-1, iy, iy+1: the fma chain of conv0_kernel (taps in dy, dx order)
-    const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
-    const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
-    float4 c0[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
-          const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
-          const f32x2 v = {inp[r + dy][dx], inp[r + dy][dx]};
-          a01 = v * w01 + a01;
-          a23 = v * w23 + a23;
-        }
-      a01 = a01 * s01 + h01;
-      a23 = a23 * s23 + h23;
-      c0[r] = make_float4(relu_mask(a01.x, hi[r]), relu_mask(a01.y, hi[r]), relu_mask(a23.x, hi[r]), relu_mask(a23.y, hi[r]));
-    }
-    if (sub_lane) reinterpret_cast<float4*>(prev_sub)[(((int64_t)b * (C0 / 4) + cq) * Ho + (iy >> 1)) * Wo + (x >> 1)] = c0[1];
-    float d[4];
-    dw_quad_impl<3, false>(c0, dw + cq * 36, d);  // the entry activation is already >= 0: the separable conv's ReLU is the identity
-    swap32(d[0], d[2]);
-    swap32(d[1], d[3]);
-    swap16(d[0], d[1]);
-    swap16(d[2], d[3]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-  }
-
-  // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> pixel 16t + lj of the window]
   const float lo_out = relu_out ? 0.0f : -INFINITY;
-  float sc_r[MT][4], sh_r[MT][4];
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
+  // 32-bit byte offsets from wave-uniform bases: no 64-bit (quarter-rate) multiplies per store
+  char* sub_base = reinterpret_cast<char*>(prev_sub) + (int64_t)b * (C0 / 4) * Ho * Wo * 16;
+  char* outq = reinterpret_cast<char*>(reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane);
+
+  // the 5 x 3 input neighbourhood of window t (clamped to the last window: the stream's tail prefetch)
+  auto load_inputs = [&](int t, float (&inp)[5][3]) {
+    const int q = R * WP + min(t, tasks - 1) * VAL - lo + lane;
+    const int prow = (int)__umulhi((uint32_t)q, magic_WP);
+    const int x = q - prow * WP, iy = prow - R;
+    constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a few row pitches
+    const uint32_t center = (uint32_t)((iy * W + x) * 4);
+    const uint32_t off[3] = {(x >= 1 && x <= W) ? center - 4u : OOB, x < W ? center : OOB, x + 1 < W ? center + 4u : OOB};
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int d = 0; d < 5; ++d)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = m * 16 + lk * 4 + r;
-      sc_r[m][r] = co < Cout ? scale[co] : 0.0f;
-      sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
+      for (int j = 0; j < 3; ++j)
+        inp[d][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 2) * W * 4), 0, 0));
+  };
+
+  auto window = [&](int t, const float (&inp)[5][3]) {
+    const int qbase = R * WP + t * VAL - lo;
+    const int q = qbase + lane;
+    const int prow = (int)__umulhi((uint32_t)q, magic_WP);
+    const int x = q - prow * WP, iy = prow - R;  // image coordinates of this lane's pixel (iy >= -1; x >= W: padding column)
+    float hi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) hi[r] = (x < W && iy + r - 1 >= 0 && iy + r - 1 < H) ? INFINITY : 0.0f;
+    const bool sub_lane = prev_sub && lane >= lo && lane < 64 - lo && x < W && iy >= 0 && iy < H && ((x | iy) & 1) == 0;
+    const uint32_t sub_off = (uint32_t)((iy >> 1) * Wo + (x >> 1)) * 16u;
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // the weights are re-read through the scalar cache every window: hoisted out of the window loop, the ~230 scalars do not
+    // fit the SGPR file and come back as v_readlane / unpacked fmas
+    int opaque_zero = 0;
+    asm volatile("" : "+s"(opaque_zero));
+    const float* w0 = static_cast<const float*>(__builtin_assume_aligned(w0_ + opaque_zero, 16));
+    const float* sc0 = static_cast<const float*>(__builtin_assume_aligned(sc0_ + opaque_zero, 16));
+    const float* sh0 = static_cast<const float*>(__builtin_assume_aligned(sh0_ + opaque_zero, 16));
+    const float* dw = static_cast<const float*>(__builtin_assume_aligned(dw_ + opaque_zero, 16));
+
+#pragma unroll
+    for (int cq = 0; cq < C0 / 4; ++cq) {
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
+      // entry convolution of channels 4cq..4cq+3 at rows iy-1, iy, iy+1: the fma chain of conv0_kernel (taps in dy, dx order)
+      const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
+      const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
+      float4 c0[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
+            const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
+            const f32x2 v = {inp[r + dy][dx], inp[r + dy][dx]};
+            a01 = v * w01 + a01;
+            a23 = v * w23 + a23;
+          }
+        a01 = a01 * s01 + h01;
+        a23 = a23 * s23 + h23;
+        c0[r] = make_float4(relu_mask(a01.x, hi[r]), relu_mask(a01.y, hi[r]), relu_mask(a23.x, hi[r]), relu_mask(a23.y, hi[r]));
+      }
+      if (sub_lane) *reinterpret_cast<float4*>(sub_base + (sub_off + (uint32_t)(cq * Ho * Wo) * 16u)) = c0[1];
+      float d[4];
+      dw_quad_impl<3, false>(c0, dw + cq * 36, d);  // the entry activation is already >= 0: the separable conv's ReLU is the identity
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
     }
-  float4* outq = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane;
+
+    // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> pixel 16tt + lj of the window]; always 4*MT stores
+    const uint32_t lk_off = (uint32_t)(lk * plane + qbase + lj);  // quad lk, pixel lj of the window
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int wl = 16 * t + lj;
-    const int flat = qbase + wl;
-    const int row = (int)__umulhi((uint32_t)flat, magic_WP);
-    const int xx = flat - row * WP;
-    const bool live = wl >= lo && wl < 64 - lo && xx < W && row < R + H;
+    for (int tt = 0; tt < 4; ++tt) {
+      const int wl = 16 * tt + lj;
+      const int flat = qbase + wl;
+      const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+      const int xx = flat - row * WP;
+      const bool live = wl >= lo && wl < 64 - lo && xx < W && row < R + H;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-      if (!live || oq >= CQo) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = max2(fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]), lo_out);  // channels past Cout: max(0*0+0, lo)
-      outq[(int64_t)oq * plane + flat] = make_float4(v[0], v[1], v[2], v[3]);
+      for (int m = 0; m < MT; ++m) {
+        const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
+        const bool ok = live && m * 4 + lk < CQo;
+        const float4 val = make_float4(max2(fmaf(acc[m][tt][0], sc.x, sh.x), lo_out), max2(fmaf(acc[m][tt][1], sc.y, sh.y), lo_out),
+                                       max2(fmaf(acc[m][tt][2], sc.z, sh.z), lo_out), max2(fmaf(acc[m][tt][3], sc.w, sh.w), lo_out));
+        *reinterpret_cast<float4*>(outq + (ok ? lk_off + (uint32_t)(m * 4 * plane + 16 * tt) : 0u) * 16u) = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
+  };
+
+  // The first window's inputs are requested before the LDS fill: the fill's own loads are younger, so its wait retires these
+  // too and the loop is entered with nothing outstanding (the state the steady-state wait counts assume).
+  float ia[5][3], ib[5][3];
+  load_inputs(t0, ia);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int i = threadIdx.x; i < C0 * 16 * MT; i += 256) {
+    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+    pw_s[i] = co < Cout ? pw[ci * Cout + co] : 0.0f;
+  }
+  if (threadIdx.x < MT * 16) {
+    const int co = threadIdx.x;
+    sc_s[co] = co < Cout ? scale[co] : 0.0f;
+    sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  __syncthreads();  // the only barrier
+
+  if (t0 >= tasks) return;
+#pragma unroll 1
+  for (int w = 0; w < nw; w += 2) {
+    load_inputs(t0 + 4 * (w + 1), ib);
+    __builtin_amdgcn_sched_barrier(0);
+    window(t0 + 4 * w, ia);
+    __builtin_amdgcn_sched_barrier(0);
+    if (w + 1 >= nw) break;
+    load_inputs(t0 + 4 * (w + 2), ia);
+    __builtin_amdgcn_sched_barrier(0);
+    window(t0 + 4 * (w + 1), ib);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -1683,6 +1726,7 @@ struct SepArgs {
   float* u_out = nullptr;
 };
 
+int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_stream_windows = 2;  // windows per wave of sepconv_stream_kernel; 0 = use sepconv_kernel everywhere
 
 template <int MT, int CQ>
@@ -1753,6 +1797,12 @@ int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int 
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 
+int orcai_entry_windows(int windows_per_wave) {
+  const int prev = g_entry_windows;
+  if (windows_per_wave >= 1 && windows_per_wave <= 64) g_entry_windows = windows_per_wave;
+  return prev;
+}
+
 int orcai_sepconv_stream_windows(int windows_per_wave) {
   const int prev = g_stream_windows;
   if (windows_per_wave >= 0 && windows_per_wave <= 64) g_stream_windows = windows_per_wave;
@@ -1783,14 +1833,15 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
                         const float* dw, const float* pw, const float* scale, const float* shift, int Cout, int relu_out, float* out, float* prev_sub,
                         void* stream) {
   if (!in || !w0 || !scale0 || !shift0 || !dw || !pw || !scale || !shift || !out || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
-  if (Cout > 64 || (int64_t)H * W >= (1ll << 28) || (((uintptr_t)w0 | (uintptr_t)dw) & 15)) return ORCAI_E_UNSUPPORTED;
+  if (Cout > 64 || (int64_t)H * W >= (1ll << 26) || (((uintptr_t)w0 | (uintptr_t)dw | (uintptr_t)scale0 | (uintptr_t)shift0) & 15)) return ORCAI_E_UNSUPPORTED;
   const int WP = orcai_padded_width(W, 3);
-  if ((int64_t)(H + 2) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  if ((int64_t)((Cout + 3) / 4) * (H + 2) * WP >= (1ll << 28)) return ORCAI_E_UNSUPPORTED;  // 32-bit byte offsets inside a snippet's planes
   const int tasks = (H * WP + 61) / 62;
-  dim3 grid((tasks + 3) / 4, B);
+  const int NW = g_entry_windows;
+  dim3 grid((tasks + 4 * NW - 1) / (4 * NW), B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
   hipStream_t st = (hipStream_t)stream;
 #define ORCAI_C0S(MT) hipLaunchKernelGGL(conv0_sep_kernel<MT>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, \
-                                         Cout, relu_out, out, prev_sub, tasks, magic_for(WP))
+                                         Cout, relu_out, out, prev_sub, tasks, magic_for(WP), NW)
   switch ((Cout + 15) / 16) {
     case 1: ORCAI_C0S(1); break;
     case 2: ORCAI_C0S(2); break;
