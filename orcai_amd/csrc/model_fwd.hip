@@ -1727,7 +1727,10 @@ struct SepArgs {
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
-int g_stream_windows = 2;  // windows per wave of sepconv_stream_kernel; 0 = use sepconv_kernel everywhere
+int g_stream_windows = 1;  // windows per wave of sepconv_stream_kernel; 0 = use sepconv_kernel everywhere.  1: rows re-read by vertically
+                           // adjacent windows are requested at the same time by neighbouring waves and hit L2 (PMC: FETCH_SIZE = input
+                           // bytes); with 2 the second window re-reads them one window-time later, after the XCD has streamed three times
+                           // its L2 through, and FETCH_SIZE doubles at equal speed
 
 template <int MT, int CQ>
 int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
