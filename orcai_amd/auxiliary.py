@@ -104,6 +104,14 @@ class Messenger:
             pass
 
 
+def resolve_recording_data_dir(recording: str, recording_data_dir):
+    """auxiliary.py:347-365: ``<recording_data_dir>/<recording>`` if it exists, else None."""
+    from pathlib import Path
+
+    p = Path(recording_data_dir, recording)
+    return p if p.exists() else None
+
+
 def seconds_to_hms(seconds: int) -> str:
     hours, remainder = divmod(seconds, 3600)
     minutes, seconds = divmod(remainder, 60)

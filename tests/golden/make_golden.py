@@ -295,6 +295,86 @@ def gen_label_raster():
     print("label raster", arr.shape, arr.sum().to_dict())
 
 
+def snippet_fixture_inputs(root: Path):
+    """Deterministic recording data directories for the snippet-table fixtures (also rebuilt by the test): three recordings
+    (640 s, 450 s, 150 s -- the last one shorter than a segment), per-frame labels with random call intervals, one masked label
+    column, one recording without labels.  Label arrays go to labels.npy (the test reads these) AND are what the patched
+    ``zarr.open`` hands to the reference."""
+    calls = CALLS
+    rng = np.random.default_rng(20250620)
+    dirs = []
+    for name, n_rows, with_labels in (("recA", 120000, True), ("recB", 84375, True), ("recC", 28125, True), ("recD", 60000, False)):
+        d = root / name
+        (d / "spectrogram").mkdir(parents=True)
+        (d / "labels").mkdir(parents=True)
+        times = {"min": 0.0, "max": (n_rows - 1) * 256 / 48000, "length": n_rows}
+        (d / "spectrogram" / "times.json").write_text(json.dumps(times))
+        if with_labels:
+            lab = np.zeros((n_rows, len(calls)), dtype=np.int16)
+            for c in range(len(calls)):
+                for _ in range(int(rng.integers(3, 12))):
+                    a = int(rng.integers(0, n_rows - 2000))
+                    lab[a : a + int(rng.integers(50, 1500)), c] = 1
+            if name == "recB":
+                lab[:, 2] = -1  # HERDING cannot be annotated in this recording
+            np.save(d / "labels" / "labels.npy", lab)
+            (d / "labels" / "label_list.json").write_text(json.dumps({c: i for i, c in enumerate(calls)}))
+        dirs.append(d)
+    return dirs
+
+
+SNIPPET_PARAM = {"name": "t", "seed": 42, "calls": CALLS,
+                 "model": {"filters": [30, 40, 50, 60], "batch_size": 4, "n_batch_train": 6, "n_batch_val": 2, "n_batch_test": 2, "call_weights": None},
+                 "snippets": {"segment_duration": 200, "snippets_per_sec": 0.25, "snippet_duration": 4, "fraction_removal": 0.5, "train": 0.8, "val": 0.1, "test": 0.1}}
+
+
+def gen_snippet_tables():
+    """snippets.py:26-556 -- _make_snippet_table, _compute_snippet_stats, _filter_snippet_table and the files written by
+    create_snippet_table / create_tvt_snippet_tables, run by the reference itself with ``zarr.open`` patched to return the
+    numpy label array (zarr and tensorflow are absent from this image)."""
+    import gzip
+    import tempfile
+    import types as _types
+
+    import orcAI.snippets as Sn
+    from orcAI.auxiliary import Messenger
+
+    Sn.zarr = _types.SimpleNamespace(open=lambda path, mode="r": np.load(Path(path).with_suffix(".npy"), mmap_mode="r") if Path(path).with_suffix(".npy").exists()
+                                     else (_ for _ in ()).throw(FileNotFoundError(path)))
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        root = Path(d) / "data"
+        dirs = snippet_fixture_inputs(root)
+        rng = np.random.default_rng(seed=[1, SNIPPET_PARAM["seed"]])
+        tables = []
+        for rd in dirs:
+            table, dur, nseg, rec, status = Sn._make_snippet_table(rd, SNIPPET_PARAM, rng=rng, msgr=Messenger(verbosity=0))
+            out[f"status_{rec}"] = [float(dur), int(nseg), status]
+            if table is not None:
+                tables.append(table)
+        allt = pd.concat(tables).reset_index(drop=True)
+        stats = Sn._compute_snippet_stats(allt, for_calls=CALLS)
+        filt = Sn._filter_snippet_table(allt, SNIPPET_PARAM, rng=np.random.default_rng(seed=[2, SNIPPET_PARAM["seed"]]), msgr=Messenger(verbosity=0))
+        # the two public entry points, writing files
+        rt = Path(d) / "recording_table.csv"
+        pd.DataFrame({"recording": [x.name for x in dirs] + ["recE"], "base_dir_annotation": ["a", "a", "a", "a", np.nan]}).to_csv(rt, index=False)
+        tv = Path(d) / "tvt"
+        Sn.create_snippet_table(rt, root, tv, SNIPPET_PARAM, verbosity=0, msgr=Messenger(verbosity=0))
+        Sn.create_tvt_snippet_tables(tv, None, SNIPPET_PARAM, create_unfiltered_test_snippets=True, n_unfiltered_test_snippets=5, verbosity=0, msgr=Messenger(verbosity=0))
+        files_out = {}
+        for f in sorted(tv.iterdir()):
+            raw = gzip.decompress(f.read_bytes()).decode() if f.suffix == ".gz" else f.read_text()
+            files_out[f.name] = raw.replace(str(root), "<ROOT>")
+    num = ["row_start", "row_stop"] + CALLS
+    np.savez_compressed(HERE / "snippet_tables.npz", all_numeric=allt[num].to_numpy(dtype=np.float64), filtered_numeric=filt[num].to_numpy(dtype=np.float64),
+                        stats=stats.to_numpy(dtype=np.float64))
+    (HERE / "snippet_tables.json").write_text(json.dumps({
+        "param": SNIPPET_PARAM, "status": out, "all_recording": list(allt["recording"]), "all_data_type": list(allt["data_type"]),
+        "filtered_recording": list(filt["recording"]), "filtered_data_type": list(filt["data_type"]), "stats_index": list(stats.index),
+        "stats_columns": list(stats.columns), "files": files_out}, indent=1))
+    print("snippet tables", allt.shape, filt.shape, {k: len(v) for k, v in files_out.items()})
+
+
 def main():
     S, P, A = import_reference()
     gen_preprocess(S)
@@ -304,6 +384,7 @@ def main():
     gen_consecutive(A)
     gen_test_tables()
     gen_label_raster()
+    gen_snippet_tables()
 
 
 if __name__ == "__main__":

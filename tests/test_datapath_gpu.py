@@ -101,3 +101,62 @@ def test_table_dataset_equals_materialised_dataset_and_trains(tmp_path):
     bad.loc[0, "row_start"] = 10**6 - rows
     with pytest.raises(IndexError):
         SnippetTableDataset(bad, nf, 8)
+
+
+def test_data_preparation_commands_feed_training(tmp_path):
+    """The reference's data-preparation chain on synthetic recordings, through the CLI where it has one: label arrays ->
+    create-snippet-table -> create-tvt-snippet-tables -> create-tvt-data -> orcai train.  create-tvt-data materialises nothing;
+    train reads the descriptors and gathers its batches on the GPU from the recordings' arrays."""
+    import json
+
+    from click.testing import CliRunner
+
+    from orcai_amd.cli import cli
+    from orcai_amd.datasets import SnippetTableDataset, load_dataset
+    from orcai_amd.io import read_json
+
+    rng = np.random.default_rng(5)
+    calls = ["A", "B", "C"]
+    W, hop_s = 16, 0.05  # 20 frames per second
+    root = tmp_path / "recording_data"
+    for r, seconds in enumerate((130, 90)):
+        T = int(seconds / hop_s)
+        d = root / f"rec{r}"
+        (d / "spectrogram").mkdir(parents=True)
+        (d / "labels").mkdir()
+        np.save(d / "spectrogram" / "spectrogram.npy", rng.random((T, W), dtype=np.float32))
+        (d / "spectrogram" / "times.json").write_text(json.dumps({"min": 0.0, "max": (T - 1) * hop_s, "length": T}))
+        lab = (rng.random((T, len(calls))) < 0.3).astype(np.int16)
+        if r == 1:
+            lab[:, 2] = -1
+        np.save(d / "labels" / "labels.npy", lab)
+        (d / "labels" / "label_list.json").write_text(json.dumps({c: i for i, c in enumerate(calls)}))
+    table = tmp_path / "recordings.csv"
+    pd.DataFrame({"recording": ["rec0", "rec1", "rec2"], "base_dir_annotation": ["x", "x", "x"]}).to_csv(table, index=False)  # rec2 has no data directory
+    param = read_json(__import__("orcai_amd.snippets", fromlist=["x"]).DEFAULT_ORCAI_PARAMETER)
+    param.update({"name": "tiny", "seed": 3, "calls": calls})
+    param["model"].update({"filters": [8, 12], "lstm_units": 64, "batch_size": 4, "n_batch_train": 5, "n_batch_val": 2, "n_batch_test": 2, "epochs": 1,
+                           "call_weights": None})
+    param["snippets"].update({"segment_duration": 40, "snippets_per_sec": 1, "snippet_duration": 1.7, "fraction_removal": 0.5})
+    pfile = tmp_path / "param.json"
+    pfile.write_text(json.dumps(param))
+    tvt = tmp_path / "tvt"
+    run = CliRunner()
+    for args in (["create-snippet-table", str(table), str(root), "-o", str(tvt), "-p", str(pfile), "-v", "0"],
+                 ["create-tvt-snippet-tables", str(tvt), "-p", str(pfile), "-uts", "-n_uts", "6", "-v", "0"],
+                 ["create-tvt-data", str(tvt), "-p", str(pfile), "-v", "0"]):
+        res = run.invoke(cli, args, catch_exceptions=False)
+        assert res.exit_code == 0, (args, res.output)
+    assert read_json(tvt / "dataset_shapes.json") == {"spectrogram": [32, W, 1], "labels": [8, len(calls)]}  # 1.7 s = 34 frames -> 32 (a multiple of 2**2 blocks)
+    assert sorted(p.name for p in tvt.iterdir() if p.is_dir()) == ["test_dataset", "test_unfiltered_dataset", "train_dataset", "val_dataset"]
+    assert sum(f.stat().st_size for f in tvt.rglob("*") if f.is_file()) < 200_000  # tables and descriptors only
+    ds = load_dataset(tvt / "train_dataset", 4, seed=[7, 3])
+    assert isinstance(ds, SnippetTableDataset) and len(ds) == 5
+    x, y = next(iter(ds))
+    assert tuple(x.shape) == (4, 32, W) and tuple(y.shape) == (4, 8, len(calls))
+    out = tmp_path / "out"
+    out.mkdir()
+    res = run.invoke(cli, ["train", str(tvt), str(out), "-p", str(pfile), "-v", "0"], catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    hist = read_json(out / "tiny" / "training_history.json")
+    assert len(hist["loss"]) == 1 and np.isfinite(hist["loss"][0]) and np.isfinite(hist["val_MBA"][0])

@@ -128,12 +128,16 @@ def test_predict_rejects_bad_suffix_and_existing_output(tmp_path):
 
 
 def test_cli_surface_matches_reference_options():
-    """Option flags of the in-scope subcommands (reference cli.py:93-184, 359-416, 630-677, 680-729, 732-788)."""
+    """Option flags of the in-scope subcommands (reference cli.py:93-184, 359-627, 630-677, 680-729, 732-788)."""
     from orcai_amd.cli import cli
 
     expect = {
         "predict": {"-c", "-m", "-md", "-o", "-ow", "-sp", "-bdr", "-cdl", "-ls", "-v"},
         "create-spectrograms": {"-bdr", "-p", "-en", "-enp", "-ow", "-v"},
+        "create-label-arrays": {"-bda", "-p", "-ce", "-ow", "-v"},
+        "create-snippet-table": {"-o", "-p", "-v"},
+        "create-tvt-snippet-tables": {"-st", "-p", "-uts", "-n_uts", "-ow", "-v"},
+        "create-tvt-data": {"-p", "-ow", "-dc", "-v"},
         "train": {"-p", "-dc", "-lm", "-v"},
         "hpsearch": {"-p", "-hp", "-pl", "-dc", "-v"},
         "test": {"-tu", "-o", "-dc", "-v"},

@@ -223,3 +223,72 @@ def test_two_independent_model_restatements_agree(cfg):
     ref1 = M.forward_ref_1dconv(q, x, dtype=torch.float64)
     for b in range(2):
         assert np.abs(Lp.forward_one_1dconv(q, x[b]) - ref1[b]).max() <= 1e-10
+
+
+def _golden_generator_module(golden_dir):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", golden_dir / "make_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # defines helpers only; the reference is not touched at import
+    return mod
+
+
+def test_snippet_tables_match_reference(golden_dir, tmp_path):
+    """orcai_amd.snippets against the reference's own snippets.py run on the same recording directories with the same seeds
+    (tests/golden/snippet_tables.*): row indices, per-call label seconds (NaN for masked labels), the random filtering, the
+    statistics table and every file create_snippet_table / create_tvt_snippet_tables write -- bit for bit / byte for byte."""
+    import gzip
+    import json
+
+    import pandas as pd
+
+    from orcai_amd import snippets as Sn
+    from orcai_amd.auxiliary import Messenger
+
+    G = _golden_generator_module(golden_dir)
+    gold = json.loads((golden_dir / "snippet_tables.json").read_text())
+    arrs = np.load(golden_dir / "snippet_tables.npz")
+    param = gold["param"]
+    calls = param["calls"]
+    root = tmp_path / "data"
+    dirs = G.snippet_fixture_inputs(root)
+    quiet = Messenger(verbosity=0)
+
+    rng = np.random.default_rng(seed=[1, param["seed"]])
+    tables = []
+    for rd in dirs:
+        table, dur, nseg, rec, status = Sn._make_snippet_table(rd, param, rng=rng, msgr=quiet)
+        assert [float(dur), int(nseg), status] == gold["status"][f"status_{rec}"]
+        if table is not None:
+            tables.append(table)
+    allt = pd.concat(tables).reset_index(drop=True)
+    num = ["row_start", "row_stop"] + calls
+    assert list(allt["recording"]) == gold["all_recording"] and list(allt["data_type"]) == gold["all_data_type"]
+    assert np.array_equal(allt[num].to_numpy(dtype=np.float64), arrs["all_numeric"], equal_nan=True)
+    assert np.isnan(arrs["all_numeric"]).any()  # the masked label column of recB
+
+    stats = Sn._compute_snippet_stats(allt, for_calls=calls)
+    assert list(stats.index) == gold["stats_index"] and list(stats.columns) == gold["stats_columns"]
+    assert np.array_equal(stats.to_numpy(dtype=np.float64), arrs["stats"], equal_nan=True)
+
+    filt = Sn._filter_snippet_table(allt, param, rng=np.random.default_rng(seed=[2, param["seed"]]), msgr=quiet)
+    assert list(filt["recording"]) == gold["filtered_recording"] and list(filt["data_type"]) == gold["filtered_data_type"]
+    assert np.array_equal(filt[num].to_numpy(dtype=np.float64), arrs["filtered_numeric"], equal_nan=True)
+
+    rt = tmp_path / "recording_table.csv"
+    pd.DataFrame({"recording": [x.name for x in dirs] + ["recE"], "base_dir_annotation": ["a", "a", "a", "a", np.nan]}).to_csv(rt, index=False)
+    tv = tmp_path / "tvt"
+    Sn.create_snippet_table(rt, root, tv, param, verbosity=0, msgr=quiet)
+    Sn.create_tvt_snippet_tables(tv, None, param, create_unfiltered_test_snippets=True, n_unfiltered_test_snippets=5, verbosity=0, msgr=quiet)
+    got = {}
+    for f in sorted(tv.iterdir()):
+        raw = gzip.decompress(f.read_bytes()).decode() if f.suffix == ".gz" else f.read_text()
+        got[f.name] = raw.replace(str(root), "<ROOT>")
+    assert sorted(got) == sorted(gold["files"])
+    for name, text in gold["files"].items():
+        assert got[name] == text, name
+
+    with pytest.raises(ValueError, match="larger than available snippets"):  # snippets.py:474-477
+        Sn.create_tvt_snippet_tables(tmp_path / "tvt2", tv / "all_snippets.csv.gz", {**param, "model": {**param["model"], "n_batch_val": 1000}}, verbosity=0,
+                                     msgr=quiet)
