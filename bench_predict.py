@@ -103,18 +103,23 @@ class PredictWorkload:
         from orcai_amd import _native as N
 
         couts = {"b1": 30, "b2": 40, "b3": 50, "b4": 60}
+        cins = {"b1": 16, "b2": 30, "b3": 40, "b4": 50}
+        widths = {"b1": 171, "b2": 86, "b3": 43, "b4": 22}
         if label == "conv0":
             return "conv0_kernel<3>"
         if label == "conv0+b1/sep_a":
             return "conv0_sep_kernel<2>"
         if label == "sep_f":
-            return "sepconv_kernel<3, 3>"
+            return "sepconv_kernel<3, 3>"  # Keras-reshape output layout: not a streaming shape
         blk, _, op = label.partition("/")
-        if blk == "b1" and op in ("sep_a", "sep_b") and N.lib().orcai_sepconv_stream_windows(-1) > 0:
-            # streaming variant <MT, input quads, x-pooled output, ReLU on load>
-            return "sepconv_stream_kernel<2, 4, false, true>" if op == "sep_a" else "sepconv_stream_kernel<2, 8, true, false>"
         if blk in couts and op in ("sep_a", "sep_b"):
-            return f"sepconv_kernel<3, {(couts[blk] + 15) // 16}>"
+            cin, cout = (cins[blk] if op == "sep_a" else couts[blk]), couts[blk]
+            mt, cq = (cout + 15) // 16, ((cin + 3) // 4 + 3) // 4 * 4
+            wx = (widths[blk] + 1) // 2
+            streams = N.lib().orcai_sepconv_stream_windows(-1) > 0 and mt >= 2 and cq <= {2: 8, 3: 12, 4: 16}[mt] and (op == "sep_a" or (wx + 3) // 4 * 4 > wx)
+            if streams:  # streaming variant <MT, input quads rounded up to 4, x-pooled output, ReLU on load>
+                return f"sepconv_stream_kernel<{mt}, {cq}, {'true' if op == 'sep_b' else 'false'}, {'true' if op == 'sep_a' else 'false'}>"
+            return f"sepconv_kernel<3, {mt}>"
         if blk in couts and op == "pool_res":
             return f"pool_res_add_kernel<{(couts[blk] + 15) // 16}>"
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")

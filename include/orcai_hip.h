@@ -118,7 +118,7 @@ int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int h
 int orcai_padded_width(int W, int ksize);
 
 /* Tuning knob of the separable-conv launcher: windows per wave of the streaming variant (sepconv_stream_kernel, used for
- * k = 3, Cout in 17..32, Cin a multiple of 16 up to 32, plane or x-pooled output, no depthwise-output store); 0 selects the
+ * k = 3, Cout in 17..64, Cin <= 16*ceil(Cout/16), plane or x-pooled output, no depthwise-output store); 0 selects the
  * one-window-per-wave kernel everywhere.  Both variants perform the same arithmetic in the same order (bit-identical
  * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_stream_windows(int windows_per_wave);

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 // Pointwise weights and the folded BN scale/shift come from LDS (no global load behind the row prefetches).
 // =========================================================================================
 template <int MT, int CQ, bool XP, bool RELU>
-__global__ __launch_bounds__(256, 4) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+__global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? 3 : 2)) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                               const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                               float* __restrict__ out, int tasks, uint32_t magic_WP, int NW) {
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256, 4) void sepconv_stream_kernel(const float* __r
   const int lk = lane >> 4, lj = lane & 15;
   const int plane = (H + 2 * R) * WP;
   const int CQo = (Cout + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
+  const int CQr = (Cin + 3) >> 2;  // real input quads; CQ - CQr < 4 dummy quads (zero pointwise weights, rows of the last quad re-read)
+  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQr * plane;
   const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
   float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
   const int dump = XP ? WPx - 1 : 0;  // a padding pixel of the snippet's first output plane (zero before and after)
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 4) void sepconv_stream_kernel(const float* __r
     }
   };
   auto load_row = [&](int e, uint32_t off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)e * plane) + off);
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)(e < CQr ? e : CQr - 1) * plane) + off);
   };
 
   // The first three stream elements are requested before the LDS fill: the fill's own loads are younger, so its wait
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256, 4) void sepconv_stream_kernel(const float* __r
 #pragma unroll
       for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
       float d[4];
-      dw_quad_impl<3, RELU>(rows[cq & 3], dww + cq * 4 * KK, d);
+      dw_quad_impl<3, RELU>(rows[cq & 3], dww + (cq < CQr ? cq : CQr - 1) * 4 * KK, d);
       swap32(d[0], d[2]);
       swap32(d[1], d[3]);
       swap16(d[0], d[1]);
@@ -1754,13 +1755,21 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   const int VAL = 64 - 2 * lo;
   const int tasks = (a.H * a.WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
-  if constexpr (KS == 3 && MT == 2) {
+  if constexpr (KS == 3 && MT >= 2) {
     const int CQ = (a.Cin + 3) / 4, CQo = (a.Cout + 3) / 4, Wx = (a.W + 1) / 2;
     const bool shape_ok = a.RP == 1 && !a.u_out && ((uintptr_t)a.dw & 15) == 0 && (a.out_layout == 0 || (a.out_layout == 2 && ((Wx + 3) & ~3) > Wx)) &&
                           (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 28);
-    if (g_stream_windows > 0 && shape_ok) {
-      if (CQ == 4) return launch_sepconv_stream<2, 4>(st, a, tasks);
-      if (CQ == 8) return launch_sepconv_stream<2, 8>(st, a, tasks);
+    if (g_stream_windows > 0 && shape_ok) {  // the kernel is instantiated for the quad count rounded up to a multiple of 4
+      if constexpr (MT == 2) {
+        if (CQ <= 4) return launch_sepconv_stream<2, 4>(st, a, tasks);
+        if (CQ <= 8) return launch_sepconv_stream<2, 8>(st, a, tasks);
+      } else if constexpr (MT == 3) {
+        if (CQ > 4 && CQ <= 8) return launch_sepconv_stream<3, 8>(st, a, tasks);
+        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<3, 12>(st, a, tasks);
+      } else {
+        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<4, 12>(st, a, tasks);
+        if (CQ > 12 && CQ <= 16) return launch_sepconv_stream<4, 16>(st, a, tasks);
+      }
     }
   }
   dim3 grid((tasks + 3) / 4, a.B);

@@ -194,6 +194,11 @@ def test_resnet_1dconv_forward(input_shape, filters, k):
     (32, 32, 5, 64, 2, 1, 0),      # even W; Wx % 4 == 0 -> no padding column -> must fall back to the one-window kernel
     (29, 32, 33, 118, 2, 1, 1),
     (32, 20, 2, 61, 0, 1, 0),
+    (30, 40, 368, 86, 0, 1, 1),    # orcai-V1 b2/sep_a: three output tiles
+    (40, 40, 64, 86, 2, 0, 0),     # b2/sep_b: 10 input quads, streamed as 12 (two dummy quads)
+    (50, 50, 40, 43, 2, 0, 0),     # b3/sep_b: 13 quads as 16, four output tiles
+    (60, 60, 46, 22, 2, 0, 1),     # b4/sep_b: 15 quads as 16
+    (37, 64, 7, 100, 0, 1, 1),
 ])
 def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, relu_out):
     """sepconv_stream_kernel (several windows per wave, rows prefetched three quads deep) performs the arithmetic of

@@ -29,4 +29,4 @@ for nw in nws + [nws[0]]:
         ref = pred.clone()
     same = bool(torch.equal(pred, ref))
     print(f"nw={nw:2d} bit-identical={same} maxdiff={float((pred - ref).abs().max()):.3g} total={sum(tot.values()):.2f} ms",
-          {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:6]}, flush=True)
+          {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]}, flush=True)
