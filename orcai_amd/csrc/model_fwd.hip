@@ -372,6 +372,17 @@ __device__ __forceinline__ float relu_mask(float x, float hi) {  // min(max(x, 0
   return r;
 }
 
+// acc + in[HALF] * w for both halves of w / acc: v_pk_fma_f32 with its first operand broadcast from one half of a register
+// pair.  Written as asm because the compiler, left to itself, gives every broadcast scalar a register pair of its own (the
+// 15 inputs of conv0_sep_kernel then cost 30 VGPRs per set instead of 16) and unpacks a third of the fmas.
+template <int HALF>
+__device__ __forceinline__ f32x2 pk_fma_bcast(f32x2 in, f32x2 w, f32x2 acc) {
+  f32x2 r;
+  if (HALF) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(in), "s"(w), "v"(acc));
+  else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(in), "s"(w), "v"(acc));
+  return r;
+}
+
 template <int MT>
 __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
                                                          const float* __restrict__ w0_ /*[9][16]*/, const float* __restrict__ sc0_, const float* __restrict__ sh0_,
@@ -403,7 +414,9 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
   char* outq = reinterpret_cast<char*>(reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane);
 
   // the 5 x 3 input neighbourhood of window t (clamped to the last window: the stream's tail prefetch)
-  auto load_inputs = [&](int t, float (&inp)[5][3]) {
+  // input (row d, column j) lives in half (3d + j) & 1 of register pair (3d + j) >> 1: v_pk_fma_f32 takes its broadcast operand
+  // from either half of an aligned pair (op_sel), so 15 inputs cost 16 registers -- one input per pair would cost 30
+  auto load_inputs = [&](int t, f32x2 (&inp)[8]) {
     const int q = R * WP + min(t, tasks - 1) * VAL - lo + lane;
     const int prow = (int)__umulhi((uint32_t)q, magic_WP);
     const int x = q - prow * WP, iy = prow - R;
@@ -414,10 +427,10 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
     for (int d = 0; d < 5; ++d)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        inp[d][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 2) * W * 4), 0, 0));
+        inp[(3 * d + j) >> 1][(3 * d + j) & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 2) * W * 4), 0, 0));
   };
 
-  auto window = [&](int t, const float (&inp)[5][3]) {
+  auto window = [&](int t, const f32x2 (&inp)[8]) {
     const int qbase = R * WP + t * VAL - lo;
     const int q = qbase + lane;
     const int prow = (int)__umulhi((uint32_t)q, magic_WP);
@@ -461,9 +474,9 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
           for (int dx = 0; dx < 3; ++dx) {
             const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
             const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
-            const f32x2 v = {inp[r + dy][dx], inp[r + dy][dx]};
-            a01 = v * w01 + a01;
-            a23 = v * w23 + a23;
+            const int ii = 3 * (r + dy) + dx;
+            a01 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w01, a01) : pk_fma_bcast<0>(inp[ii >> 1], w01, a01));
+            a23 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w23, a23) : pk_fma_bcast<0>(inp[ii >> 1], w23, a23));
           }
         a01 = a01 * s01 + h01;
         a23 = a23 * s23 + h23;
@@ -504,7 +517,7 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 
   // The first window's inputs are requested before the LDS fill: the fill's own loads are younger, so its wait retires these
   // too and the loop is entered with nothing outstanding (the state the steady-state wait counts assume).
-  float ia[5][3], ib[5][3];
+  f32x2 ia[8], ib[8];
   load_inputs(t0, ia);
   __builtin_amdgcn_sched_barrier(0);
   for (int i = threadIdx.x; i < C0 * 16 * MT; i += 256) {
