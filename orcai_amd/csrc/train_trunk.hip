@@ -23,12 +23,15 @@ __global__ __launch_bounds__(256) void planes_sums_kernel(const float* __restric
   __shared__ double red[256][4];
   const int cq = blockIdx.y;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  const int64_t total = (int64_t)B * plane;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t b = i / plane, p = i - b * plane;
-    const float4 v = reinterpret_cast<const float4*>(x)[(b * CQ + cq) * plane + p];
-    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+  // snippet-outer / pixel-inner: no 64-bit division per element (it cost more than the rest of the loop body)
+  const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
+  for (int b = 0; b < B; ++b) {
+    const float4* xp = reinterpret_cast<const float4*>(x) + ((int64_t)b * CQ + cq) * plane;
+    for (int p = p0; p < (int)plane; p += pstep) {
+      const float4 v = xp[p];
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
   }
   for (int pass = 0; pass < (sumsq ? 2 : 1); ++pass) {
     const double* src = pass ? q : s;
@@ -59,13 +62,11 @@ __global__ __launch_bounds__(256) void bn_planes_apply_kernel(const float* __res
                                                                const float* __restrict__ var, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int B) {
   const int CQ = (C + 3) >> 2;
-  const int64_t interior = (int64_t)H * W;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)B * CQ * interior) return;
-  const int64_t bq = idx / interior, pix = idx - bq * interior;
-  const int cq = (int)(bq % CQ);
-  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
-  const int64_t off = bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx;
+  const int pix = blockIdx.x * 256 + threadIdx.x;  // grid.y = (snippet, quad): 32-bit index math only
+  if (pix >= H * W) return;
+  const int bq = blockIdx.y, cq = bq % CQ;
+  const int yy = pix / W, xx = pix - yy * W;
+  const int64_t off = (int64_t)bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx;
   const float4 a = reinterpret_cast<const float4*>(v)[off];
   float in[4] = {a.x, a.y, a.z, a.w}, o[4];
 #pragma unroll
@@ -96,20 +97,23 @@ __global__ __launch_bounds__(256) void bn_planes_bwd_sums_kernel(const float* __
     mu[k] = mean[cc]; inv[k] = rsqrtf(var[cc] + eps); g[k] = gamma[cc]; bt[k] = beta[cc];
   }
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  const int64_t total = (int64_t)B * plane;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t b = i / plane, p = i - b * plane;
-    const int64_t off = (b * CQ + cq) * plane + p;
-    const float4 d4 = reinterpret_cast<const float4*>(dy)[off];
-    const float4 v4 = reinterpret_cast<const float4*>(v)[off];
-    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+  const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
+  for (int b = 0; b < B; ++b) {  // snippet-outer / pixel-inner: no 64-bit division per element
+    const int64_t base = ((int64_t)b * CQ + cq) * plane;
+    const float4* dp = reinterpret_cast<const float4*>(dy) + base;
+    const float4* vp = reinterpret_cast<const float4*>(v) + base;
+    for (int p = p0; p < (int)plane; p += pstep) {
+      const float4 d4 = dp[p];
+      const float4 v4 = vp[p];
+      const float d[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float xh = (vv[k] - mu[k]) * inv[k];
-      float de = d[k];
-      if (relu && !(fmaf(xh, g[k], bt[k]) > 0.0f)) de = 0.0f;
-      s[k] += (double)de;
-      q[k] += (double)de * (double)xh;
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (vv[k] - mu[k]) * inv[k];
+        float de = d[k];
+        if (relu && !(fmaf(xh, g[k], bt[k]) > 0.0f)) de = 0.0f;
+        s[k] += (double)de;
+        q[k] += (double)de * (double)xh;
+      }
     }
   }
   for (int pass = 0; pass < 2; ++pass) {
@@ -748,6 +752,7 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
@@ -762,6 +767,7 @@ int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, doub
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 4 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
@@ -774,9 +780,10 @@ int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, doub
 int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
                           float eps, int relu, float* y, void* stream) {
   if (!v || !y || !mean || !var || !gamma || !beta || B <= 0 || C <= 0) return ORCAI_E_BADARG;
-  const int64_t n = (int64_t)B * ((C + 3) / 4) * H * W;
-  hipLaunchKernelGGL(bn_planes_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, v, C, H, W, orcai_padded_width(W, ksize), ksize / 2, mean, var,
-                     gamma, beta, eps, relu, y, B);
+  const int64_t bq = (int64_t)B * ((C + 3) / 4);
+  if (bq > 65535 || (int64_t)H * W >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_planes_apply_kernel, dim3(blocks_for((int64_t)H * W), (unsigned)bq), dim3(256), 0, (hipStream_t)stream, v, C, H, W,
+                     orcai_padded_width(W, ksize), ksize / 2, mean, var, gamma, beta, eps, relu, y, B);
   return (int)hipGetLastError();
 }
 
@@ -786,6 +793,7 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
@@ -926,6 +934,7 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
   hipStream_t st = (hipStream_t)stream;
   const int C = 16, CQ = 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
