@@ -276,3 +276,41 @@ def test_fused_entry_convolution_is_bit_identical(shape, filters):
     torch.cuda.synchronize()
     assert torch.equal(a_fused, a_ref)  # pads included
     assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :])
+
+
+def test_streaming_sepconv_random_shapes():
+    """Seeded sweep over shapes the launcher hands to sepconv_stream_kernel (and some it does not): every quad count and output
+    tile count, widths from narrower than a window to several windows per row, one-row planes, both output layouts."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for case in range(24):
+        Cout = int(rng.integers(17, 65))
+        Cin = int(rng.integers(1, 16 * ((Cout + 15) // 16) + 1))
+        H, W = int(rng.integers(1, 24)), int(rng.integers(3, 190))
+        layout = int(rng.integers(0, 2)) * 2
+        relu_in, relu_out = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        B, CQ, CQo, WP = 2, (Cin + 3) // 4, (Cout + 3) // 4, lib.orcai_padded_width(W, 3)
+        x = torch.zeros(B, CQ * 4, H + 2, WP)
+        x[:, :Cin, 1:H + 1, :W] = torch.randn(B, Cin, H, W, generator=g)
+        planes = x.view(B, CQ, 4, H + 2, WP).permute(0, 1, 3, 4, 2).contiguous().to(dev)
+        dw = torch.randn(CQ, 9, 4, generator=g).to(dev)
+        pw = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+        scale, shift = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+        Wx = (W + 1) // 2
+        oshape = (B, CQo, H + 2, WP, 4) if layout == 0 else (B, CQo, H, (Wx + 3) // 4 * 4, 4)
+        outs = []
+        for nw in (0, 1, 3):
+            prev = lib.orcai_sepconv_stream_windows(nw)
+            try:
+                out = torch.zeros(oshape, device=dev)
+                assert lib.orcai_sepconv_bn(N.ptr(planes), B, Cin, H, W, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, relu_out, layout,
+                                            N.ptr(out), N.stream_ptr()) == 0
+                torch.cuda.synchronize()
+            finally:
+                lib.orcai_sepconv_stream_windows(prev)
+            outs.append(out if layout == 0 else out[:, :, :, :Wx])
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (case, Cin, Cout, H, W, layout)
