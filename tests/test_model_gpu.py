@@ -314,3 +314,41 @@ def test_streaming_sepconv_random_shapes():
                 lib.orcai_sepconv_stream_windows(prev)
             outs.append(out if layout == 0 else out[:, :, :, :Wx])
         assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (case, Cin, Cout, H, W, layout)
+
+
+def test_fused_entry_random_shapes():
+    """orcai_conv0_sepconv against orcai_conv0_bn_relu + orcai_sepconv_bn on seeded random shapes and windows-per-wave settings:
+    planes narrower than a window, single rows, odd / even sizes, every output tile count; overlapping snippet views."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    g = torch.Generator(device="cpu").manual_seed(12)
+    for case in range(16):
+        H, W, Cout = int(rng.integers(1, 40)), int(rng.integers(2, 200)), int(rng.integers(1, 65))
+        B = 3
+        stride = (H // 2 + 1) * W  # overlapping snippets of one long array, as predict uses them
+        src = torch.randn((B - 1) * stride + H * W, generator=g).to(dev)
+        w0, sc0, sh0 = torch.randn(9, 16, generator=g).to(dev), torch.randn(16, generator=g).to(dev), torch.randn(16, generator=g).to(dev)
+        dw, pw = torch.randn(4, 9, 4, generator=g).to(dev), (0.25 * torch.randn(16, Cout, generator=g)).to(dev)
+        sc, sh = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+        WP, CQo = lib.orcai_padded_width(W, 3), (Cout + 3) // 4
+        relu_out = int(rng.integers(0, 2))
+        st = N.stream_ptr()
+        prev0 = torch.zeros((B, 4, H + 2, WP, 4), device=dev)
+        a_ref = torch.zeros((B, CQo, H + 2, WP, 4), device=dev)
+        assert lib.orcai_conv0_bn_relu(N.ptr(src), stride, B, H, W, 3, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(prev0), st) == 0
+        assert lib.orcai_sepconv_bn(N.ptr(prev0), B, 16, H, W, 3, 1, N.ptr(dw), N.ptr(pw), N.ptr(sc), N.ptr(sh), Cout, relu_out, 0, N.ptr(a_ref), st) == 0
+        for nw in (1, 2, 5):
+            prev = lib.orcai_entry_windows(nw)
+            try:
+                a = torch.zeros_like(a_ref)
+                sub = torch.zeros((B, 4, (H + 1) // 2, (W + 1) // 2, 4), device=dev)
+                assert lib.orcai_conv0_sepconv(N.ptr(src), stride, B, H, W, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(dw), N.ptr(pw), N.ptr(sc), N.ptr(sh), Cout, relu_out,
+                                               N.ptr(a), N.ptr(sub), st) == 0
+                torch.cuda.synchronize()
+            finally:
+                lib.orcai_entry_windows(prev)
+            assert torch.equal(a, a_ref), (case, H, W, Cout, nw)
+            assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :]), (case, H, W, Cout, nw)
