@@ -560,12 +560,12 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 // straight-line body whose entry state equals its back-edge state and emits exact partial waits instead of vmcnt(0).
 // Pointwise weights and the folded BN scale/shift come from LDS (no global load behind the row prefetches).
 // =========================================================================================
-template <int MT, int CQ, bool XP, bool RELU>
-__global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? 3 : 2)) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+template <int MT, int CQ, bool XP, bool RELU, int NS>
+__global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (NS == 2 ? 3 : 2))) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                               const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                               float* __restrict__ out, int tasks, uint32_t magic_WP, int NW) {
-  static_assert(CQ % 4 == 0 && CQ >= 4, "four rotating row sets");
+  static_assert((NS == 2 || NS == 4) && CQ % NS == 0 && CQ >= NS, "NS rotating row sets: the rotation phase must be equal at every window boundary");
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   __shared__ float pw_s[CQ * 4 * 16 * MT];  // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
   __shared__ float sc_s[MT * 16], sh_s[MT * 16];
@@ -600,11 +600,11 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? 3 : 2)) void sepconv_
 
   // The first three stream elements are requested before the LDS fill: the fill's own loads are younger, so its wait
   // retires these too and the loop is entered with nothing outstanding (the state the steady-state wait counts assume).
-  float4 rows[4][3];
+  float4 rows[NS][3];  // NS - 1 stream elements in flight
   uint32_t rc[3];
   row_index(min(t0, tasks - 1), rc);
 #pragma unroll
-  for (int e = 0; e < 3; ++e)
+  for (int e = 0; e < NS - 1; ++e)
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) rows[e][dy] = load_row(e, rc[dy]);
   __builtin_amdgcn_sched_barrier(0);
@@ -641,18 +641,18 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? 3 : 2)) void sepconv_
     const float* dww = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) {
-      {  // stream element cq + 3: this window's quad cq + 3, or the next window's quad cq + 3 - CQ
-        const int e = cq + 3;
+      {  // stream element cq + NS - 1: a quad of this window, or one of the next window's first NS - 1 quads
+        const int e = cq + NS - 1;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
-          rows[e & 3][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
+          rows[e % NS][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
       }
       __builtin_amdgcn_sched_barrier(0);  // the row loads are issued before any of the quad's arithmetic
       float afrag[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
       float d[4];
-      dw_quad_impl<3, RELU>(rows[cq & 3], dww + (cq < CQr ? cq : CQr - 1) * 4 * KK, d);
+      dw_quad_impl<3, RELU>(rows[cq % NS], dww + (cq < CQr ? cq : CQr - 1) * 4 * KK, d);
       swap32(d[0], d[2]);
       swap32(d[1], d[3]);
       swap16(d[0], d[1]);
@@ -1746,12 +1746,12 @@ int g_stream_windows = 1;  // windows per wave of sepconv_stream_kernel; 0 = use
                            // bytes); with 2 the second window re-reads them one window-time later, after the XCD has streamed three times
                            // its L2 through, and FETCH_SIZE doubles at equal speed
 
-template <int MT, int CQ>
+template <int MT, int CQ, int NS>
 int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
   const int NW = g_stream_windows;
   dim3 grid((tasks + 4 * NW - 1) / (4 * NW), a.B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
 #define ORCAI_STREAM_LAUNCH(XP, RELU)                                                                                                 \
-  hipLaunchKernelGGL((sepconv_stream_kernel<MT, CQ, XP, RELU>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
+  hipLaunchKernelGGL((sepconv_stream_kernel<MT, CQ, XP, RELU, NS>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
                      a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), NW)
   if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_STREAM_LAUNCH(true, true); else ORCAI_STREAM_LAUNCH(true, false);
@@ -1773,15 +1773,20 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
     const bool shape_ok = a.RP == 1 && !a.u_out && ((uintptr_t)a.dw & 15) == 0 && (a.out_layout == 0 || (a.out_layout == 2 && ((Wx + 3) & ~3) > Wx)) &&
                           (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 28);
     if (g_stream_windows > 0 && shape_ok) {  // the kernel is instantiated for the quad count rounded up to a multiple of 4
+      // <MT, quads rounded up to a multiple of NS, NS row sets>: four sets = three quads in flight.  Two sets (one quad in flight,
+      // 24 VGPRs fewer: one more wave per SIMD at three / four output tiles) where they save two dummy quads: 10 and 13-14 input
+      // quads (orcai-V1 b2/sep_b, b3/sep_b: -9 % against the four-set kernel with 12 / 16 quads; at equal quad counts four sets win)
       if constexpr (MT == 2) {
-        if (CQ <= 4) return launch_sepconv_stream<2, 4>(st, a, tasks);
-        if (CQ <= 8) return launch_sepconv_stream<2, 8>(st, a, tasks);
+        if (CQ <= 4) return launch_sepconv_stream<2, 4, 4>(st, a, tasks);
+        if (CQ <= 8) return launch_sepconv_stream<2, 8, 4>(st, a, tasks);
       } else if constexpr (MT == 3) {
-        if (CQ > 4 && CQ <= 8) return launch_sepconv_stream<3, 8>(st, a, tasks);
-        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<3, 12>(st, a, tasks);
+        if (CQ > 4 && CQ <= 8) return launch_sepconv_stream<3, 8, 4>(st, a, tasks);
+        if (CQ > 8 && CQ <= 10) return launch_sepconv_stream<3, 10, 2>(st, a, tasks);
+        if (CQ > 10 && CQ <= 12) return launch_sepconv_stream<3, 12, 4>(st, a, tasks);
       } else {
-        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<4, 12>(st, a, tasks);
-        if (CQ > 12 && CQ <= 16) return launch_sepconv_stream<4, 16>(st, a, tasks);
+        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<4, 12, 4>(st, a, tasks);
+        if (CQ > 12 && CQ <= 14) return launch_sepconv_stream<4, 14, 2>(st, a, tasks);
+        if (CQ > 14 && CQ <= 16) return launch_sepconv_stream<4, 16, 4>(st, a, tasks);
       }
     }
   }
