@@ -115,7 +115,7 @@ class PredictWorkload:
         if blk in couts and op in ("sep_a", "sep_b"):
             cin, cout = (cins[blk] if op == "sep_a" else couts[blk]), couts[blk]
             mt, cqr = (cout + 15) // 16, (cin + 3) // 4
-            ns = 2 if (mt, cqr) in ((3, 9), (3, 10), (4, 13), (4, 14)) else 4  # row sets (launch_sepconv_impl in csrc/model_fwd.hip)
+            ns = 2 if mt == 2 or (mt, cqr) in ((4, 13), (4, 14)) or (mt == 3 and cqr in (9, 10) and op == "sep_b") else 4  # row sets (launch_sepconv_impl)
             cq = (cqr + ns - 1) // ns * ns
             wx = (widths[blk] + 1) // 2
             streams = N.lib().orcai_sepconv_stream_windows(-1) > 0 and mt >= 2 and cq <= {2: 8, 3: 12, 4: 16}[mt] and (op == "sep_a" or (wx + 3) // 4 * 4 > wx)
@@ -127,7 +127,7 @@ class PredictWorkload:
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
-    # (sepconv_stream_kernel<2, 8, true, false, 4>) is the top symbol of rocprofv3 --stats for this workload
+    # (sepconv_stream_kernel<2, 8, true, false, 2>) is the top symbol of rocprofv3 --stats for this workload
     DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
 
     def roofline(self):

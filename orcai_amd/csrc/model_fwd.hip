@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 // Pointwise weights and the folded BN scale/shift come from LDS (no global load behind the row prefetches).
 // =========================================================================================
 template <int MT, int CQ, bool XP, bool RELU, int NS>
-__global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (NS == 2 ? 3 : 2))) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+__global__ __launch_bounds__(256, MT <= 2 ? (NS == 2 ? 5 : 4) : (MT == 3 ? (NS == 2 ? 4 : 3) : (NS == 2 ? 3 : 2))) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                               const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                               float* __restrict__ out, int tasks, uint32_t magic_WP, int NW) {
@@ -594,6 +594,14 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (
       ri[dy] = (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
     }
   };
+  // DERIVE (x-pooled two-output-tile instantiations, which run at five waves per SIMD = 96 VGPRs): keep only the centre row's flat
+  // pixel per window and derive the three offsets at each load (a few VALU) instead of holding 3 + 3 offset registers, and compute
+  // the next window's pixel where it is first needed.  The other instantiations allocate better with the offsets precomputed.
+  constexpr bool DERIVE = MT == 2 && XP;
+  auto derived_offset = [&](int q, int dy) {
+    const int i = q + (dy - 1) * WP;
+    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+  };
   auto load_row = [&](int e, uint32_t off) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)(e < CQr ? e : CQr - 1) * plane) + off);
   };
@@ -603,10 +611,11 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (
   float4 rows[NS][3];  // NS - 1 stream elements in flight
   uint32_t rc[3];
   row_index(min(t0, tasks - 1), rc);
+  int qc = R * WP + min(t0, tasks - 1) * VAL - lo + lane;  // DERIVE: this window's centre-row pixel
 #pragma unroll
   for (int e = 0; e < NS - 1; ++e)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) rows[e][dy] = load_row(e, rc[dy]);
+    for (int dy = 0; dy < 3; ++dy) rows[e][dy] = load_row(e, DERIVE ? derived_offset(qc, dy) : rc[dy]);
   __builtin_amdgcn_sched_barrier(0);
 
   for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 256) {
@@ -633,7 +642,8 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (
   for (int w = 0; w < nw; ++w) {
     const int t = t0 + 4 * w;
     uint32_t rn[3];
-    row_index(min(t + 4, tasks - 1), rn);
+    if (!DERIVE) row_index(min(t + 4, tasks - 1), rn);
+    int qn = 0;
     // the depthwise taps are re-read through the scalar cache every window: hoisted out of this loop, the CQ*36 scalars do
     // not fit the SGPR file and come back as one v_readlane per tap
     int opaque_zero = 0;
@@ -643,9 +653,12 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (
     for (int cq = 0; cq < CQ; ++cq) {
       {  // stream element cq + NS - 1: a quad of this window, or one of the next window's first NS - 1 quads
         const int e = cq + NS - 1;
+        if (DERIVE && e == CQ) qn = R * WP + min(t + 4, tasks - 1) * VAL - lo + lane;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-          rows[e % NS][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
+        for (int dy = 0; dy < 3; ++dy) {
+          if constexpr (DERIVE) rows[e % NS][dy] = (e < CQ) ? load_row(e, derived_offset(qc, dy)) : load_row(e - CQ, derived_offset(qn, dy));
+          else rows[e % NS][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);  // the row loads are issued before any of the quad's arithmetic
       float afrag[MT];
@@ -695,8 +708,11 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : (MT == 3 ? (NS == 2 ? 4 : 3) : (
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DERIVE) qc = qn;
+    else {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) rc[dy] = rn[dy];
+      for (int dy = 0; dy < 3; ++dy) rc[dy] = rn[dy];
+    }
   }
 }
 
@@ -1775,13 +1791,14 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
     if (g_stream_windows > 0 && shape_ok) {  // the kernel is instantiated for the quad count rounded up to a multiple of 4
       // <MT, quads rounded up to a multiple of NS, NS row sets>: four sets = three quads in flight.  Two sets (one quad in flight,
       // 24 VGPRs fewer: one more wave per SIMD at three / four output tiles) where they save two dummy quads: 10 and 13-14 input
-      // quads (orcai-V1 b2/sep_b, b3/sep_b: -9 % against the four-set kernel with 12 / 16 quads; at equal quad counts four sets win)
+      // quads (orcai-V1 b2/sep_b, b3/sep_b: -9 % against the four-set kernel with 12 / 16 quads; at equal quad counts four sets win),
+      // and for two output tiles, where they fit 96 VGPRs = five waves per SIMD (b1/sep_b -6 % against four sets at four waves)
       if constexpr (MT == 2) {
-        if (CQ <= 4) return launch_sepconv_stream<2, 4, 4>(st, a, tasks);
-        if (CQ <= 8) return launch_sepconv_stream<2, 8, 4>(st, a, tasks);
+        if (CQ <= 4) return launch_sepconv_stream<2, 4, 2>(st, a, tasks);
+        if (CQ <= 8) return launch_sepconv_stream<2, 8, 2>(st, a, tasks);
       } else if constexpr (MT == 3) {
         if (CQ > 4 && CQ <= 8) return launch_sepconv_stream<3, 8, 4>(st, a, tasks);
-        if (CQ > 8 && CQ <= 10) return launch_sepconv_stream<3, 10, 2>(st, a, tasks);
+        if (CQ > 8 && CQ <= 10 && a.out_layout == 2 && !a.relu_in) return launch_sepconv_stream<3, 10, 2>(st, a, tasks);  // (its other variants spill)
         if (CQ > 10 && CQ <= 12) return launch_sepconv_stream<3, 12, 4>(st, a, tasks);
       } else {
         if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<4, 12, 4>(st, a, tasks);
