@@ -1764,7 +1764,9 @@ int g_stream_windows = 1;  // windows per wave of sepconv_stream_kernel; 0 = use
 
 template <int MT, int CQ, int NS>
 int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
-  const int NW = g_stream_windows;
+  // windows per wave: the knob for two output tiles (block 1: one window keeps the row re-reads in L2); twice that for three and
+  // four tiles, whose planes are small (b2/sep_b -5 %, b3/sep_b -10 % with two windows)
+  const int NW = g_stream_windows * (MT >= 3 ? 2 : 1);
   dim3 grid((tasks + 4 * NW - 1) / (4 * NW), a.B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
 #define ORCAI_STREAM_LAUNCH(XP, RELU)                                                                                                 \
   hipLaunchKernelGGL((sepconv_stream_kernel<MT, CQ, XP, RELU, NS>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
