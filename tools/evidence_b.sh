@@ -4,6 +4,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ev
 mkdir -p $O
+rm -rf $O/prof_* $O/pmc_*   # rocprofv3 names its files by PID: results of an earlier run would be summarised along with this one
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_predict -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_predict.log 2>&1 && echo predict-trace-ok && \
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_train.log 2>&1 && echo train-trace-ok && \
