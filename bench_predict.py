@@ -23,22 +23,26 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 FWD_FLOP_PER_SNIPPET = 0.972e9  # 485.8 M MAC
 
 
-def _sep_cost(cin, cout, h, w):
-    """(algorithmic bytes, flops) per snippet of one fused separable-conv launch: read in, write out; dw + pw MACs."""
-    return 4.0 * h * w * (cin + cout), 2.0 * h * w * (9 * cin + cin * cout)
+def _sep_cost(cin, cout, h, w, w_out=None):
+    """(algorithmic bytes, flops) per snippet of one fused separable-conv launch: the input planes read once, the output AS THE
+    KERNEL WRITES IT written once (w_out = ceil(w/2) columns for the x-pooled layout of a block's second conv); dw + pw MACs."""
+    return 4.0 * h * (w * cin + (w if w_out is None else w_out) * cout), 2.0 * h * w * (9 * cin + cin * cout)
 
 
 def kernel_costs():
-    """label -> (algorithmic HBM bytes, FLOPs) per snippet, fp32 planar activations, each tensor read/written once."""
+    """label -> (algorithmic HBM bytes, FLOPs) per snippet: every tensor a kernel reads or writes, once, at its true channel count
+    and in the shape the kernel actually moves (x-pooled outputs of */sep_b, x-pooled inputs of */pool_res, the compact (2i, 2j)
+    subsample the fused entry path hands to block 1's residual conv).  fp32."""
     shapes = [(736, 171, 16), (368, 86, 30), (184, 43, 40), (92, 22, 50), (46, 11, 60)]
     costs = {"conv0": (4.0 * 736 * 171 * (1 + 16), 2.0 * 736 * 171 * 9 * 16)}
     for b in range(1, 5):
         h, w, cin = shapes[b - 1]
         ho, wo, f = shapes[b]
+        wx = (w + 1) // 2
         costs[f"b{b}/sep_a"] = _sep_cost(cin, f, h, w)
-        costs[f"b{b}/sep_b"] = _sep_cost(f, f, h, w)
-        # pool + residual: read s (all), read prev at stride 2 (counted as the sampled quarter), write out
-        costs[f"b{b}/pool_res"] = (4.0 * (h * w * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
+        costs[f"b{b}/sep_b"] = _sep_cost(f, f, h, w, w_out=wx)
+        # pool + residual: read the x-pooled s, read prev at the sampled (2i, 2j) pixels, write out
+        costs[f"b{b}/pool_res"] = (4.0 * (h * wx * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
     costs["sep_f"] = _sep_cost(60, 36, 46, 11)
     # fused entry (orcai_conv0_sepconv): read the 1-channel snippet, write a1 and the (2i, 2j) subsample of the entry activation
     costs["conv0+b1/sep_a"] = (4.0 * (736 * 171 * (1 + 30) + 368 * 86 * 16), costs["conv0"][1] + costs["b1/sep_a"][1])
@@ -51,9 +55,10 @@ def measured_traffic(symbol: str, workload: str = "predict"):
     import json
     from pathlib import Path
 
-    f = Path(__file__).resolve().parent / "profiles" / "r01_pmc_traffic.json"
-    if not f.exists():
+    found = sorted((Path(__file__).resolve().parent / "profiles").glob("r*_pmc_traffic.json"))  # the newest round's passes
+    if not found:
         return None
+    f = found[-1]
     rec = json.loads(f.read_text()).get(workload, {}).get("kernels", {}).get(symbol)
     return None if rec is None else rec["hbm_bytes_per_launch"]
 
@@ -165,6 +170,8 @@ class PredictWorkload:
             out.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "traffic": measured_traffic(dominant),
                         "kernel_tflops": round(d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12, 2)})
+            if out["traffic"]:  # PMC bytes (2*FETCH_SIZE + WRITE_SIZE of the committed passes) over the algorithmic bytes: > 1 = padding / re-reads
+                out["traffic_ratio"] = round(out["traffic"] / out["algorithmic_bytes_per_launch"], 3)
         else:
             out.update({"bound": "mfma", "achieved": None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None})
         by_symbol = {}

@@ -16,7 +16,9 @@
  *     ORCAI_E_* code for argument errors detected on the host before launch;
  *   - nothing here allocates, frees or synchronises, so every call may be
  *     captured into a hipGraph.  The only exceptions are the *_host readback
- *     helpers, which synchronise the stream and say so.
+ *     helpers, which synchronise the stream and say so, and the setup call
+ *     orcai_frontend_workspace_bytes(), which uploads the front end's constant
+ *     tables once (synchronously) before any capturable call can be made.
  */
 #ifndef ORCAI_HIP_H
 #define ORCAI_HIP_H
@@ -39,7 +41,8 @@ const char* orcai_version(void);
  * ------------------------------------------------------------------------------------------ */
 
 /* Bytes of device workspace the front-end calls need (histograms + selection state).
- * The workspace must be 256-byte aligned. */
+ * The workspace must be 256-byte aligned.  SETUP CALL: also uploads the Hann window and the FFT twiddle tables to device
+ * constants (once per process, synchronous), so that every later front-end call only enqueues work on `stream`. */
 size_t orcai_frontend_workspace_bytes(void);
 
 /* Zero the workspace (histograms, running max, selection state).  Must precede each
@@ -139,7 +142,7 @@ int orcai_conv0_bn_relu(const float* in, int64_t snippet_stride, int B, int H, i
 /* Entry convolution fused into the first separable convolution, k = 3, inference (architectures.py:164-179):
  *   Conv2D(16, 3, same) + BN + ReLU  ->  ReLU -> SeparableConv2D(Cout, 3, same) -> BN -> [ReLU]
  * = orcai_conv0_bn_relu followed by orcai_sepconv_bn(relu_in = 1, out_layout = 0), bit for bit, without the 16-channel entry
- * activation ever reaching HBM.  in / snippet_stride / w0 / scale0 / shift0 as for orcai_conv0_bn_relu; dw f32[4][9][4],
+ * activation ever reaching HBM.  in / snippet_stride / w0 / scale0 / shift0 as for orcai_conv0_bn_relu; dw f32[4][9][4] (channel-quad layout, see orcai_sepconv_bn),
  * pw f32[16][Cout], scale / shift f32[Cout] as for orcai_sepconv_bn; out: padded channel-quad planes of Cout channels.
  *   prev_sub (may be NULL)  f32[B][4][ceil(H/2)][ceil(W/2)][4]: the entry activation at pixels (2i, 2j) only -- all that the
  *                           strided 1x1 residual convolution of block 1 reads (orcai_pool_res_add with flag 2). */
@@ -148,8 +151,9 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
                         void* stream);
 
 /* [ReLU] -> SeparableConv2D(Cout, k, same) -> BN -> [ReLU]   (architectures.py:174-189, :198-206)
- *   in   f32[B][Cin][HP][WP] padded planes
- *   dw   f32[Cin][k*k]   (Keras depthwise kernel (k,k,Cin,1) transposed)
+ *   in   f32[B][ceil(Cin/4)][HP][WP][4] padded channel-quad planes
+ *   dw   f32[ceil(Cin/4)][k*k][4]   channel-quad layout: element (q, tap, j) = Keras depthwise kernel (k,k,Cin,1) at
+ *        [tap / k][tap % k][4q + j][0], zero for channels >= Cin (what the kernels read with scalar loads; 16-byte aligned)
  *   pw   f32[Cin][Cout]  (Keras pointwise kernel (1,1,Cin,Cout))
  *   out_layout 0: padded channel-quad planes;  1: f32[B][H][W*Cout] with feature = x*Cout + c, i.e. Keras
  *   Reshape((-1, W*C)) of the NHWC tensor (architectures.py:208);  2: x-pooled f32[B][CQout][H][roundup4(ceil(W/2))][4]:
@@ -157,18 +161,6 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
  *   follows (architectures.py:190), consumed by orcai_pool_res_add(xpooled = 1).  Cout <= 64, k in {3,5,7}. */
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream);
-
-/* Both separable convolutions of a residual block fused, k = 3 (architectures.py:173-189):
- *   in (Cp channels) -> ReLU -> SepConv(F)+BN+ReLU -> SepConv(F)+BN -> x-pooled output (as out_layout 2 of orcai_sepconv_bn).
- * The intermediate activation stays in LDS.  Weight layouts as for orcai_sepconv_bn (dwa [4*ceil(Cp/4)][9], pwa [Cp][F], dwb
- * [4*ceil(F/4)][9], pwb [F][F], folded BN scale/shift per conv). */
-int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
-                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
-
-/* Same contract as orcai_block_sep2, fused in REGISTERS: each wave walks down a 64-column window keeping the last three rows of the
- * intermediate activation as channel quads (3*ceil(F/4) dwordx4 registers per lane; F <= 40), no LDS, no barriers. */
-int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
-                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream);
 
 /* MaxPooling2D((3,2), strides 2, "same")(s) + Conv2D(C, 1, strides 2, "same")(prev)   (architectures.py:190-196)
  *   xpooled is a flag word.  Bit 0: s is the x-pooled tensor written by orcai_sepconv_bn(out_layout = 2) instead of padded
@@ -226,6 +218,13 @@ int orcai_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* 
 /* MaskedBinaryCrossentropy / MaskedBinaryAccuracy (architectures.py:262-286): acc3 = {sum of BCE, unmasked count, correct count}
  * (f64, device); dz (may be NULL) = d(mean BCE)/d(logit of the final sigmoid). */
 int orcai_masked_bce(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, void* stream);
+/* The same with Keras' class_weight semantics (train.py:125-136, 214: model.fit(class_weight=...)): Keras turns class_weight into a
+ * sample weight per (snippet, step) -- class_weight[argmax over labels of y_true] -- and multiplies the SCALAR loss of
+ * MaskedBinaryCrossentropy by the batch mean of those weights.  loss_weight (may be NULL = 1) points to that one device float:
+ * acc3[0] and dz are multiplied by it.  grad_scale > 0 multiplies dz only (static loss scale of the f16 path, undone in
+ * orcai_adam_step's gscale). */
+int orcai_masked_bce_w(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, const float* loss_weight, float grad_scale,
+                       void* stream);
 /* out += lambda * sum w^2   (value of the L2 penalty) */
 int orcai_l2_value(const float* w, int64_t n, float lambda, double* out, void* stream);
 
@@ -258,13 +257,6 @@ int orcai_conv1d_bwd(const float* x, const float* w, const float* dz, int B, int
  * orcai_downsample_labels: out[b][s][l] = round_half_even(mean over the `factor` rows of group s); rows % factor != 0 -> BADARG. */
 int orcai_gather_snippets(const float* store, const int64_t* row_starts, int B, int rows, int cols, float* out, void* stream);
 int orcai_downsample_labels(const float* labels, const int64_t* row_starts, int B, int rows, int L, int factor, float* out, void* stream);
-
-/* Second half of a residual block in one launch (architectures.py:183-196): SepConv(C->C, k = 3)(a) -> BN (scale/shift) ->
- * MaxPooling2D((3,2), 2, "same") + Conv2D(1x1, strides 2)(prev; wr [Cp][C], br [C]) -> out planes [B][CQ][H/2+2][WPo][4].
- * The full-resolution output of the separable conv never goes to HBM.  k = 3 and even H only (UNSUPPORTED otherwise:
- * use orcai_sepconv_bn(out_layout 2) + orcai_pool_res_add). */
-int orcai_sep_pool_res(const float* a, const float* prev, int B, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
-                       const float* scale, const float* shift, const float* wr, const float* br, float* out, void* stream);
 
 /* ResNet1DConv head (architectures.py:10-15 ReduceFrequencyMean, :107-115 Conv1D(num_labels, kernel_size = 36, "same", sigmoid)).
  * orcai_freq_mean: feat [M][W*C] in the Keras Reshape layout (feature = x*C + c) -> out [M][C] = mean over x.

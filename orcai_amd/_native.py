@@ -31,8 +31,6 @@ _SIGNATURES = {
     "orcai_frontend_stats_host": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     "orcai_conv0_bn_relu": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_bn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "orcai_block_sep2": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10),
-    "orcai_block_rows": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 10),
     "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_padded_width": (C.c_int, [C.c_int, C.c_int]),
     "orcai_sepconv_stream_windows": (C.c_int, [C.c_int]),
@@ -51,6 +49,7 @@ _SIGNATURES = {
     "orcai_mask_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_masked_bce": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_masked_bce_w": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_l2_value": (C.c_int, [C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "orcai_lstm_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -59,7 +58,6 @@ _SIGNATURES = {
     "orcai_conv0_affine": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_gather_snippets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_downsample_labels": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
-    "orcai_sep_pool_res": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 8),
     "orcai_freq_mean_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_conv1d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 3),
     "orcai_bn_bwd_pointwise": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
@@ -91,7 +89,7 @@ class NativeLibraryError(RuntimeError):
 
 
 def exported_symbols() -> list[str]:
-    """Every symbol include/orcai_hip.h declares (kept in sync by tests/test_capi_symbols.py)."""
+    """Every symbol include/orcai_hip.h declares (kept in sync with the header by tests/test_capi_symbols.py)."""
     return list(_SIGNATURES)
 
 

@@ -77,15 +77,6 @@ class ResNetLSTM:
         self._ws = {}
         import os
 
-        # Experimental: residual blocks at least this wide run both separable convs as one fused kernel (k = 3, F <= 40).
-        # Off by default (0): on MI355X both fused variants measured SLOWER than the two HBM-bound unfused kernels
-        # (DESIGN.md 4.2): "lds" = orcai_block_sep2, "rows" = orcai_block_rows.
-        self.fuse_min_width = int(os.environ.get("ORCAI_FUSE_MIN_WIDTH", "0")) or 10**9
-        self.fuse_variant = os.environ.get("ORCAI_FUSE_VARIANT", "rows")
-        # Experimental, off by default (0): blocks at least this wide run the second separable conv fused with the max-pool and the
-        # residual (orcai_sep_pool_res).  Measured slower than the unfused pair on every block (b1 22.2 vs 19.8 ms per 1 h
-        # recording): the 1.5x recomputation of the shared pooling row makes the kernel issue-bound.
-        self.fuse_pool_min_width = int(os.environ.get("ORCAI_FUSE_POOL_MIN_WIDTH", "0")) or 10**9
         # inference, k = 3: the entry convolution is computed inside the first separable convolution (orcai_conv0_sepconv); the
         # 16-channel entry activation never reaches HBM, block 1's residual branch reads a quarter-size subsample of it
         self.fuse_entry = os.environ.get("ORCAI_FUSE_ENTRY", "1") != "0"
@@ -368,21 +359,9 @@ class ResNetLSTM:
                              N.ptr(d[pa + "/shift"]), f, 1, N.ptr(a), N.ptr(prev), st)
                 self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
                              N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
-            elif k == 3 and wd >= self.fuse_min_width and f <= 40 and keep is None:
-                # both separable convs in one kernel: the intermediate activation never leaves the registers
-                fused = lib.orcai_block_sep2 if self.fuse_variant == "lds" else lib.orcai_block_rows
-                self._launch(f"b{b}/sep_ab", "orcai_block_rows", fused, N.ptr(prev), B, c, f, h, wd, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
-                             N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]),
-                             N.ptr(d[pb + "/shift"]), N.ptr(bb), st)
             else:
                 self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                              N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
-                if k == 3 and h % 2 == 0 and wd >= self.fuse_pool_min_width and keep is None:
-                    # second separable conv + BN + max-pool + strided residual + add in one launch: its full-resolution output stays in registers
-                    self._launch(f"b{b}/sep_b_pool_res", "orcai_sep_pool_res", lib.orcai_sep_pool_res, N.ptr(a), N.ptr(prev), B, f, c, h, wd, k, 0,
-                                 N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), N.ptr(d[f"b{b}/res/w"]),
-                                 N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
-                    continue
                 self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
                              N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),

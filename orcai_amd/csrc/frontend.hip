@@ -575,7 +575,13 @@ inline int grid_for(int64_t items_per_block_unit, int64_t n_units) {
 
 extern "C" {
 
-size_t orcai_frontend_workspace_bytes(void) { return (sizeof(Workspace) + 255) & ~(size_t)255; }
+size_t orcai_frontend_workspace_bytes(void) {
+  // Setup call (every caller needs it before it can allocate the workspace): the window / twiddle tables are uploaded here, with a
+  // synchronous hipMemcpyToSymbol, so that no later call -- orcai_frontend_reset, orcai_stft_db, ... -- does anything but enqueue
+  // work on the caller's stream (hipGraph-capturable from the first call on).  An upload error is reported by orcai_stft_db.
+  std::call_once(g_tables_once, init_tables);
+  return (sizeof(Workspace) + 255) & ~(size_t)255;
+}
 
 int orcai_frontend_reset(void* workspace, void* stream) {
   if (!workspace) return ORCAI_E_BADARG;
@@ -588,7 +594,7 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
   if (n_fft != NFFT) return ORCAI_E_UNSUPPORTED;
   if (n_frames != 1 + n_samples / hop) return ORCAI_E_BADARG;
   if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 15)) return ORCAI_E_BADARG;
-  std::call_once(g_tables_once, init_tables);
+  std::call_once(g_tables_once, init_tables);  // no-op: orcai_frontend_workspace_bytes() already ran it (kept for callers that size the workspace themselves)
   if (g_tables_err) return g_tables_err;
   const int64_t n_groups = (n_frames + 15) / 16;
   Workspace* ws = (Workspace*)workspace;

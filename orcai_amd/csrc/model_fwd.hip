@@ -717,520 +717,6 @@ __global__ __launch_bounds__(256, MT <= 2 ? (NS == 2 ? 5 : 4) : (MT == 3 ? (NS =
 }
 
 // =========================================================================================
-// sep_pool_res: the second half of a residual block in one launch (architectures.py:183-196, k = 3, even H):
-//   a -> SepConv(F) -> BN -> MaxPooling2D((3,2), 2, "same")  +  Conv2D(1x1, strides 2)(prev) + bias
-// One wave owns pooled row i and a 64-lane window of image columns x = 60 w - 2 + lane (lanes 2..61 are outputs, windows
-// never wrap around a row, so row parity is the same for every lane).  The separable conv of the three pooling rows 2i, 2i+1,
-// 2i+2 is run row after row through the register-tile pipeline of sepconv_kernel and folded into a running maximum, so the
-// full-resolution activation never goes to HBM (the unfused pair writes 8 MB and reads it back per snippet in block 1).
-// Price: row 2i+2 is also row 0 of pooled row i+1 -> 1.5x the separable-conv arithmetic, and its input rows are re-read
-// from cache.  Then the column-pair maximum (one shfl_xor), the strided 1x1 residual as a second MFMA contraction on prev
-// at pixel (2i, x), the add, and one dwordx4 store per even lane.
-// =========================================================================================
-template <int MT>
-__global__ __launch_bounds__(256) void sep_pool_res_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int C, int H, int W, int WP, int relu_in,
-                                                            const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, const float* __restrict__ prev /*[B][CQp][HP][WP][4]*/,
-                                                            int Cp, const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
-                                                            float* __restrict__ out /*[B][CQ][Ho+2][WPo][4]*/, int Ho, int Wo, int WPo, int nwin, int tasks) {
-  constexpr int KS = 3, KK = 9, R = 1, LO = 2, VAL = 64 - 2 * LO;
-  const int lane = threadIdx.x & 63;
-  int bx, b;
-  xcd_remap(bx, b);
-  const int task = bx * 4 + (threadIdx.x >> 6);
-  if (task >= tasks) return;  // whole wave; no barriers
-  const int lk = lane >> 4, lj = lane & 15;
-  const int pi = task / nwin, win = task - pi * nwin;  // pooled row, window
-  const int x0 = win * VAL - LO;                        // image column of lane 0 (may be -2: the previous row's zero pad columns)
-  const int plane = (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
-  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQ * plane;
-  const float relu_lo = relu_in ? 0.0f : -INFINITY;
-
-  float sc_r[MT][4], sh_r[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = m * 16 + lk * 4 + r;
-      sc_r[m][r] = co < C ? scale[co] : 0.0f;
-      sh_r[m][r] = co < C ? shift[co] : 0.0f;
-    }
-  float mx[MT][4][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx[m][t][r] = -INFINITY;
-
-  f32x4 acc[MT][4];
-  for (int pr = 0; pr < 3; ++pr) {  // the three rows of the pooling window ("same": H is even, so only the bottom row can be padding)
-    const int y = 2 * pi + pr;
-    if (y >= H) break;
-    const int q = (y + R) * WP + x0 + lane;
-    int ridx[KS];
-#pragma unroll
-    for (int dy = 0; dy < KS; ++dy) {
-      const int i = q + (dy - R) * WP;
-      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 nxt[KS];
-#pragma unroll
-    for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
-    for (int cq = 0; cq < CQ; ++cq) {
-      float4 cur[KS];
-#pragma unroll
-      for (int dy = 0; dy < KS; ++dy) cur[dy] = nxt[dy];
-      if (cq + 1 < CQ) {
-        const float4* pn = src + (int64_t)(cq + 1) * plane;
-#pragma unroll
-        for (int dy = 0; dy < KS; ++dy) nxt[dy] = pn[ridx[dy]];
-      }
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < C && co < C;
-        const float av = pw[ok ? ci * C + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float d[4];
-      dw_quad<KS>(cur, dw + cq * 4 * KK, relu_lo, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool inside = x0 + 16 * t + lj < W;  // columns past the image are the pooling's -inf padding (x0 + ... >= 0 for output lanes)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaf(acc[m][t][r], sc_r[m][r], sh_r[m][r]);
-          mx[m][t][r] = inside ? fmaxf(mx[m][t][r], v) : mx[m][t][r];
-        }
-    }
-  }
-
-  // residual: 1x1 conv of prev at pixel (2 pi, x) -- lane = pixel, same transposes, into the (reset) accumulators
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {
-    int qp = (2 * pi + R) * WP + x0 + lane;
-    qp = qp < 0 ? 0 : (qp >= plane ? plane - 1 : qp);
-    const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + qp;
-    float4 nx = pp[0];
-    for (int cq = 0; cq < CQp; ++cq) {
-      const float4 cur = nx;
-      if (cq + 1 < CQp) nx = pp[(int64_t)(cq + 1) * plane];
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < Cp && co < C;
-        const float av = wr[ok ? ci * C + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float d[4] = {cur.x, cur.y, cur.z, cur.w};
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-  }
-  float br_r[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = m * 16 + lk * 4 + r;
-      br_r[m][r] = co < C ? br[co] : 0.0f;
-    }
-  float4* outp = reinterpret_cast<float4*>(out) + (int64_t)b * CQ * plane_o + (int64_t)(pi + R) * WPo;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int wl = 16 * t + lj, x = x0 + wl;
-    const bool live = wl >= LO && wl < 64 - LO && x < W && (x & 1) == 0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float other = __shfl_xor(mx[m][t][r], 1, 64);  // column x + 1 (-inf when it is past the image)
-        const float pooled = fmaxf(mx[m][t][r], other);
-        o[r] = (m * 16 + lk * 4 + r < C) ? pooled + (acc[m][t][r] + br_r[m][r]) : 0.0f;
-      }
-      const int oq = m * 4 + lk;
-      if (live && oq < CQ) outp[(int64_t)oq * plane_o + (x >> 1)] = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  }
-}
-
-// =========================================================================================
-// block_sep2: the two separable convolutions of a residual block fused (architectures.py:173-189), k = 3:
-//   x -> ReLU -> SepConv(F) -> BN -> ReLU  (= a, never written to HBM)  -> SepConv(F) -> BN -> column-pair max (x-pooled)
-// One workgroup (4 waves) owns a 64-column window x TH output rows of one snippet.  Phase 1: the waves compute the
-// TH + 2 rows of `a` the second convolution needs (register-tile sepconv as above; rows / columns outside the image are
-// written as ZEROS: they are the "same" padding of the second convolution) into LDS as [row][quad][lane] dwordx4.
-// Phase 2: the waves compute the TH output rows reading `a` from LDS (ds_read_b128, lane = pixel), same depthwise /
-// transpose / MFMA pipeline, and store the column-pair max.  HBM traffic per block drops from (Cp + 2F + F/2) to
-// (Cp + F/2) channel planes; the price is (TH + 2)/TH recomputation of the first convolution.
-// Window k covers image columns 60k - 2 + lane: lanes 1..62 hold valid `a`, lanes 2..61 valid outputs (60 per window).
-// =========================================================================================
-template <int MT>
-__global__ __launch_bounds__(256) void block_sep2_kernel(const float* __restrict__ in /*[B][CQp][HP][WP][4]*/, int Cp, int F, int H, int W, int WP,
-                                                          const float* __restrict__ dwa, const float* __restrict__ pwa, const float* __restrict__ sca,
-                                                          const float* __restrict__ sha, const float* __restrict__ dwb, const float* __restrict__ pwb,
-                                                          const float* __restrict__ scb, const float* __restrict__ shb, float* __restrict__ outx, int TH,
-                                                          int nwin) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float4* alds = reinterpret_cast<float4*>(smem);  // [(TH + 2)][CQ][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lk = lane >> 4, lj = lane & 15;
-  const int b = blockIdx.y;
-  const int win = blockIdx.x % nwin, y0 = (blockIdx.x / nwin) * TH;
-  const int x = win * 60 - 2 + lane;  // image column of this lane
-  const int plane = (H + 2) * WP;
-  const int CQp = (Cp + 3) >> 2, CQ = (F + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQp * plane;
-  const bool colok = x >= 0 && x < W;
-
-  // ---------------- phase 1: rows ya = y0 - 1 + ra of a = relu(BN_a(sepconv_a(relu(x))))
-  for (int ra = wave; ra < TH + 2; ra += 4) {
-    const int ya = y0 - 1 + ra;
-    float4* arow = alds + (int64_t)ra * CQ * 64;
-    if (ya < 0 || ya >= H) {  // wave-uniform: "same" padding rows of the second convolution
-      for (int q = 0; q < CQ; ++q) arow[q * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;
-    }
-    int ridx[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int i = (ya + dy) * WP + x;  // padded row ya + dy == image row ya - 1 + dy
-      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-    }
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 nxt[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) nxt[dy] = src[ridx[dy]];
-    for (int cq = 0; cq < CQp; ++cq) {
-      float4 cur[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) cur[dy] = nxt[dy];
-      if (cq + 1 < CQp) {
-        const float4* pn = src + (int64_t)(cq + 1) * plane;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) nxt[dy] = pn[ridx[dy]];
-      }
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < Cp && co < F;
-        const float av = pwa[ok ? ci * F + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float d[4];
-      dw_quad<3>(cur, dwa + cq * 36, 0.0f, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-    // BN_a + ReLU, zero outside the image columns; D register (m, t, r) = channel 16m + 4lk + r of window pixel 16t + lj
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-      float s4[4], h4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = oq * 4 + r;
-        s4[r] = co < F ? sca[co] : 0.0f;
-        h4[r] = co < F ? sha[co] : 0.0f;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int wl = 16 * t + lj;
-        const int xx = win * 60 - 2 + wl;
-        const bool ok = xx >= 0 && xx < W && wl >= 1 && wl <= 62;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = ok ? fmaxf(fmaf(acc[m][t][r], s4[r], h4[r]), 0.0f) : 0.0f;
-        if (oq < CQ) arow[oq * 64 + wl] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---------------- phase 2: output rows yb = y0 + rb from the `a` rows rb, rb+1, rb+2 in LDS
-  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
-  float4* outq = reinterpret_cast<float4*>(outx) + (int64_t)b * CQ * H * WPx;
-  for (int rb = wave; rb < TH; rb += 4) {
-    const int yb = y0 + rb;
-    if (yb >= H) break;
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int cq = 0; cq < CQ; ++cq) {
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < F && co < F;
-        const float av = pwb[ok ? ci * F + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float4 rows3[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) rows3[dy] = alds[((int64_t)(rb + dy) * CQ + cq) * 64 + lane];
-      float d[4];
-      dw_quad<3>(rows3, dwb + cq * 36, -INFINITY, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-      float s4[4], h4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = oq * 4 + r;
-        s4[r] = co < F ? scb[co] : 0.0f;
-        h4[r] = co < F ? shb[co] : 0.0f;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int wl = 16 * t + lj;
-        const int xx = win * 60 - 2 + wl;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = fmaf(acc[m][t][r], s4[r], h4[r]);
-          const float other = __shfl_xor(v[r], 1, 64);
-          v[r] = (xx + 1 < W) ? fmaxf(v[r], other) : v[r];
-        }
-        const bool live = wl >= 2 && wl <= 61 && xx >= 0 && xx < W && (xx & 1) == 0 && oq < CQ;
-        if (live) outq[((int64_t)oq * H + yb) * WPx + (xx >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
-  (void)colok;
-}
-
-// =========================================================================================
-// block_rows: both separable convolutions of a residual block fused IN REGISTERS, k = 3 (architectures.py:173-189).
-// One wave owns a 64-column window (as block_sep2: image columns 60*win - 2 + lane) and walks DOWN a run of output rows.
-// It keeps the last three rows of a = relu(BN_a(sepconv_a(relu(x)))) as channel quads with lane = pixel (3 x CQ dwordx4
-// registers, ring indexed at compile time by unrolling the row loop 3x).  Per output row it computes ONE new row of `a`
-// (3 input rows per input quad from HBM/L1 -> depthwise -> MFMA -> BN+ReLU -> 4x4 row transposes back to lane = pixel)
-// and one output row from the three `a` rows in registers, then stores the column-pair max.  No LDS, no barriers, and the
-// first convolution is recomputed only for the 2 warm-up rows of each run.
-// =========================================================================================
-template <int MT, int CQ /* output quads = ceil(F/4) <= 4*MT */>
-__global__ __launch_bounds__(256) void block_rows_kernel(const float* __restrict__ in /*[B][CQp][HP][WP][4]*/, int Cp, int F, int H, int W, int WP,
-                                                          const float* __restrict__ dwa, const float* __restrict__ pwa, const float* __restrict__ sca,
-                                                          const float* __restrict__ sha, const float* __restrict__ dwb, const float* __restrict__ pwb,
-                                                          const float* __restrict__ scb, const float* __restrict__ shb, float* __restrict__ outx,
-                                                          int rows_per_task, int nwin, int ntasks) {
-  const int lane = threadIdx.x & 63;
-  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (task >= ntasks) return;
-  const int lk = lane >> 4, lj = lane & 15;
-  const int b = blockIdx.y;
-  const int win = task % nwin, y_begin = (task / nwin) * rows_per_task;
-  const int y_end = (y_begin + rows_per_task < H) ? y_begin + rows_per_task : H;
-  const int x = win * 60 - 2 + lane;
-  const int plane = (H + 2) * WP;
-  const int CQp = (Cp + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQp * plane;
-  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
-  float4* outq = reinterpret_cast<float4*>(outx) + (int64_t)b * CQ * H * WPx;
-  const bool a_ok = x >= 0 && x < W && lane >= 1 && lane <= 62;  // `a` is zero outside the image columns ("same" padding)
-
-  // per-lane BN constants in the D layout: register (m, r) <-> channel 16m + 4lk + r
-  float sa[MT][4], ha[MT][4], sb[MT][4], hb[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = m * 16 + lk * 4 + r;
-      sa[m][r] = co < F ? sca[co] : 0.f; ha[m][r] = co < F ? sha[co] : 0.f;
-      sb[m][r] = co < F ? scb[co] : 0.f; hb[m][r] = co < F ? shb[co] : 0.f;
-    }
-
-  float4 A[3][CQ];  // ring of `a` rows (lane = pixel)
-
-  // ---- one row of a: image row ya -> slot
-  auto a_row = [&](int ya, float4 (&dst)[CQ]) {
-    if (ya < 0 || ya >= H) {  // wave-uniform
-#pragma unroll
-      for (int q = 0; q < CQ; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      return;
-    }
-    int ridx[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int i = (ya + dy) * WP + x;
-      ridx[dy] = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-    }
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 nxt[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) nxt[dy] = src[ridx[dy]];
-    for (int cq = 0; cq < CQp; ++cq) {
-      float4 cur[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) cur[dy] = nxt[dy];
-      if (cq + 1 < CQp) {
-        const float4* pn = src + (int64_t)(cq + 1) * plane;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) nxt[dy] = pn[ridx[dy]];
-      }
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < Cp && co < F;
-        const float av = pwa[ok ? ci * F + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float d[4];
-      dw_quad<3>(cur, dwa + cq * 36, 0.0f, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-    // BN_a + ReLU in the D layout, then back to lane = pixel: for fixed (m, r) the 4 registers over t hold rows lk = quad;
-    // the same 4 x 4 row transpose turns register t / row g into register g / row t, i.e. quad 4m+g with lane = pixel.
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float y[4][4];  // [t][r]
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[t][r] = fmaxf(fmaf(acc[m][t][r], sa[m][r], ha[m][r]), 0.0f);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        swap32(y[0][r], y[2][r]);
-        swap32(y[1][r], y[3][r]);
-        swap16(y[0][r], y[1][r]);
-        swap16(y[2][r], y[3][r]);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int q = m * 4 + g;
-        if (q < CQ) dst[q] = a_ok ? make_float4(y[g][0], y[g][1], y[g][2], y[g][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-
-  // ---- one output row yb from three `a` rows
-  auto out_row = [&](int yb, const float4 (&r0)[CQ], const float4 (&r1)[CQ], const float4 (&r2)[CQ]) {
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int cq = 0; cq < CQ; ++cq) {
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < F && co < F;
-        const float av = pwb[ok ? ci * F + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      const float4 rows3[3] = {r0[cq], r1[cq], r2[cq]};
-      float d[4];
-      dw_quad<3>(rows3, dwb + cq * 36, -INFINITY, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int wl = 16 * t + lj;
-        const int xx = win * 60 - 2 + wl;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = fmaf(acc[m][t][r], sb[m][r], hb[m][r]);
-          const float other = __shfl_xor(v[r], 1, 64);
-          v[r] = (xx + 1 < W) ? fmaxf(v[r], other) : v[r];
-        }
-        const bool live = wl >= 2 && wl <= 61 && xx >= 0 && xx < W && (xx & 1) == 0 && oq < CQ;
-        if (live) outq[((int64_t)oq * H + yb) * WPx + (xx >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  };
-
-  // prologue: a rows y_begin - 1 -> slot 0, y_begin -> slot 1; then per output row y: a row y+1 -> next slot, output from the ring
-  a_row(y_begin - 1, A[0]);
-  a_row(y_begin, A[1]);
-  for (int y = y_begin; y < y_end; y += 3) {
-    a_row(y + 1, A[2]);
-    out_row(y, A[0], A[1], A[2]);
-    if (y + 1 >= y_end) break;
-    a_row(y + 2, A[0]);
-    out_row(y + 1, A[1], A[2], A[0]);
-    if (y + 2 >= y_end) break;
-    a_row(y + 3, A[1]);
-    out_row(y + 2, A[2], A[0], A[1]);
-  }
-}
-
-// =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
 // Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
 // (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
@@ -1928,71 +1414,6 @@ int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksiz
   return orcai_sepconv_planes_u(in, B, Cin, H, W, ksize_planes, ktap, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, H2, W2, out, nullptr, stream);
 }
 
-int orcai_block_sep2(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
-                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream) {
-  if (!in || !dwa || !pwa || !sca || !sha || !dwb || !pwb || !scb || !shb || !outx || B <= 0 || Cp <= 0 || F <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
-  if (F > 64) return ORCAI_E_UNSUPPORTED;
-  const int CQ = (F + 3) / 4;
-  int rows_a = (80 * 1024) / (CQ * 64 * 16);  // LDS budget 80 KiB -> two workgroups per CU
-  if (rows_a < 3) return ORCAI_E_UNSUPPORTED;
-  int TH = rows_a - 2;
-  if (TH > H) TH = H;
-  const size_t lds = (size_t)(TH + 2) * CQ * 64 * 16;
-  const int nwin = (W + 59) / 60;
-  dim3 grid(nwin * ((H + TH - 1) / TH), B);
-  hipStream_t st = (hipStream_t)stream;
-  const int WP = orcai_padded_width(W, 3);
-#define ORCAI_SEP2_LAUNCH(MT)                                                                                                          \
-  {                                                                                                                                    \
-    static size_t lds_set = 0;                                                                                                         \
-    if (lds > lds_set) {                                                                                                               \
-      hipError_t e = hipFuncSetAttribute((const void*)block_sep2_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
-      if (e != hipSuccess) return (int)e;                                                                                              \
-      lds_set = lds;                                                                                                                   \
-    }                                                                                                                                  \
-    hipLaunchKernelGGL(block_sep2_kernel<MT>, grid, dim3(256), lds, st, in, Cp, F, H, W, WP, dwa, pwa, sca, sha, dwb, pwb, scb, shb, outx, TH, nwin); \
-  }
-  switch ((F + 15) / 16) {
-    case 1: ORCAI_SEP2_LAUNCH(1); break;
-    case 2: ORCAI_SEP2_LAUNCH(2); break;
-    case 3: ORCAI_SEP2_LAUNCH(3); break;
-    case 4: ORCAI_SEP2_LAUNCH(4); break;
-    default: return ORCAI_E_UNSUPPORTED;
-  }
-#undef ORCAI_SEP2_LAUNCH
-  return (int)hipGetLastError();
-}
-
-int orcai_block_rows(const float* in, int B, int Cp, int F, int H, int W, const float* dwa, const float* pwa, const float* sca, const float* sha,
-                     const float* dwb, const float* pwb, const float* scb, const float* shb, float* outx, void* stream) {
-  if (!in || !dwa || !pwa || !sca || !sha || !dwb || !pwb || !scb || !shb || !outx || B <= 0 || Cp <= 0 || F <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
-  const int CQ = (F + 3) / 4;
-  if (CQ > 10) return ORCAI_E_UNSUPPORTED;  // 3*CQ dwordx4 registers of `a` per lane
-  const int nwin = (W + 59) / 60;
-  int rows = 32;
-  if (rows > H) rows = H;
-  const int ntasks = nwin * ((H + rows - 1) / rows);
-  dim3 grid((ntasks + 3) / 4, B);
-  hipStream_t st = (hipStream_t)stream;
-  const int WP = orcai_padded_width(W, 3);
-#define ORCAI_ROWS_LAUNCH(MT, CQ_) hipLaunchKernelGGL((block_rows_kernel<MT, CQ_>), grid, dim3(256), 0, st, in, Cp, F, H, W, WP, dwa, pwa, sca, sha, dwb, pwb, scb, shb, outx, rows, nwin, ntasks)
-  switch (CQ) {
-    case 1: ORCAI_ROWS_LAUNCH(1, 1); break;
-    case 2: ORCAI_ROWS_LAUNCH(1, 2); break;
-    case 3: ORCAI_ROWS_LAUNCH(1, 3); break;
-    case 4: ORCAI_ROWS_LAUNCH(1, 4); break;
-    case 5: ORCAI_ROWS_LAUNCH(2, 5); break;
-    case 6: ORCAI_ROWS_LAUNCH(2, 6); break;
-    case 7: ORCAI_ROWS_LAUNCH(2, 7); break;
-    case 8: ORCAI_ROWS_LAUNCH(2, 8); break;
-    case 9: ORCAI_ROWS_LAUNCH(3, 9); break;
-    case 10: ORCAI_ROWS_LAUNCH(3, 10); break;
-    default: return ORCAI_E_UNSUPPORTED;
-  }
-#undef ORCAI_ROWS_LAUNCH
-  return (int)hipGetLastError();
-}
-
 int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
                           int xpooled, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* stream) {
   if (!s || !prev || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
@@ -2028,30 +1449,6 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
                        int xpooled, void* stream) {
   return orcai_pool_res_add_bn(s, prev, B, C, Cp, H, W, ksize, wr, br, out, xpooled, nullptr, nullptr, nullptr, nullptr, 0.0f, stream);
-}
-
-int orcai_sep_pool_res(const float* a, const float* prev, int B, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
-                       const float* scale, const float* shift, const float* wr, const float* br, float* out, void* stream) {
-  if (!a || !prev || !dw || !pw || !scale || !shift || !wr || !br || !out || B <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
-  if (ksize != 3 || (H & 1) || C > 64 || Cp > 64) return ORCAI_E_UNSUPPORTED;  // odd H pads the pooling window at the top as well
-  const int WP = orcai_padded_width(W, ksize), Ho = H / 2, Wo = (W + 1) / 2, WPo = orcai_padded_width(Wo, ksize);
-  if ((int64_t)(H + 2) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
-  const int nwin = (W + 59) / 60;
-  const int tasks = Ho * nwin;
-  dim3 grid((tasks + 3) / 4, B);
-  hipStream_t st = (hipStream_t)stream;
-#define ORCAI_SPR(MT_)                                                                                                                            \
-  hipLaunchKernelGGL((sep_pool_res_kernel<MT_>), grid, dim3(256), 0, st, a, C, H, W, WP, relu_in, dw, pw, scale, shift, prev, Cp, wr, br, out, Ho, Wo, \
-                     WPo, nwin, tasks)
-  switch ((C + 15) / 16) {
-    case 1: ORCAI_SPR(1); break;
-    case 2: ORCAI_SPR(2); break;
-    case 3: ORCAI_SPR(3); break;
-    case 4: ORCAI_SPR(4); break;
-    default: return ORCAI_E_UNSUPPORTED;
-  }
-#undef ORCAI_SPR
-  return (int)hipGetLastError();
 }
 
 int orcai_gemm_bias_act(const float* A, const float* Bm, const float* bias, const float* scale, const float* shift, float* C, int64_t M, int N,

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
 // pass 2: dz = dL/d(logit) = mask * (dL/dp) * p (1 - p) / count   (dL/dp = 0 where p is clipped)
 // =========================================================================================
 __global__ __launch_bounds__(256) void bce_reduce_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float mask_value,
-                                                          double* __restrict__ acc) {
+                                                          double* __restrict__ acc, const float* __restrict__ loss_weight) {
   __shared__ double s0[256], s1[256], s2[256];
   double l = 0.0, c = 0.0, k = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -365,11 +365,11 @@ __global__ __launch_bounds__(256) void bce_reduce_kernel(const float* __restrict
     if (threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { atomicAdd(&acc[0], s0[0]); atomicAdd(&acc[1], s1[0]); atomicAdd(&acc[2], s2[0]); }
+  if (threadIdx.x == 0) { atomicAdd(&acc[0], loss_weight ? s0[0] * (double)*loss_weight : s0[0]); atomicAdd(&acc[1], s1[0]); atomicAdd(&acc[2], s2[0]); }
 }
 
 __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__ p, const float* __restrict__ y, int64_t n, float mask_value,
-                                                        const double* __restrict__ acc, float* __restrict__ dz) {
+                                                        const double* __restrict__ acc, float* __restrict__ dz, const float* __restrict__ loss_weight, float grad_scale) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float t = y[i], q = p[i];
@@ -377,8 +377,9 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
   if (t != mask_value && q > 1e-7f && q < 1.0f - 1e-7f) {
     const float dLdp = -t / q + (1.0f - t) / (1.0f - q);
     g = dLdp * q * (1.0f - q) / (float)acc[1];
+    if (loss_weight) g *= *loss_weight;  // Keras class_weight on a scalar loss: loss * mean(sample weight)
   }
-  dz[i] = g;
+  dz[i] = g * grad_scale;  // grad_scale: static loss scale of the f16 path (1 otherwise)
 }
 
 // sum of squares (L2 penalty value): out += lambda * sum w^2
@@ -754,16 +755,21 @@ int orcai_dropout_mask(float* mask, int64_t n, uint64_t seed, float keep, void* 
   return (int)hipGetLastError();
 }
 
-int orcai_masked_bce(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, void* stream) {
-  if (!p || !y || !acc3 || n <= 0) return ORCAI_E_BADARG;
+int orcai_masked_bce_w(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, const float* loss_weight, float grad_scale,
+                       void* stream) {
+  if (!p || !y || !acc3 || n <= 0 || !(grad_scale > 0.0f)) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc3, 0, 3 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   unsigned g = blocks_for(n);
   if (g > 256) g = 256;
-  hipLaunchKernelGGL(bce_reduce_kernel, dim3(g), dim3(256), 0, st, p, y, n, mask_value, acc3);
-  if (dz) hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, st, p, y, n, mask_value, acc3, dz);
+  hipLaunchKernelGGL(bce_reduce_kernel, dim3(g), dim3(256), 0, st, p, y, n, mask_value, acc3, loss_weight);
+  if (dz) hipLaunchKernelGGL(bce_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, st, p, y, n, mask_value, acc3, dz, loss_weight, grad_scale);
   return (int)hipGetLastError();
+}
+
+int orcai_masked_bce(const float* p, const float* y, int64_t n, float mask_value, double* acc3, float* dz, void* stream) {
+  return orcai_masked_bce_w(p, y, n, mask_value, acc3, dz, nullptr, 1.0f, stream);
 }
 
 int orcai_l2_value(const float* w, int64_t n, float lambda, double* out, void* stream) {

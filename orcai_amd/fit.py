@@ -29,8 +29,17 @@ class Callback:
     def on_train_end(self, loop): ...
 
 
-def _better(a, b, mode):
-    return a > b if mode == "max" else a < b
+def _better(a, b, mode, min_delta: float = 0.0):
+    """Keras' monitor_op with min_delta: an improvement has to beat the best value by more than min_delta."""
+    return a - min_delta > b if mode == "max" else a + min_delta < b
+
+
+def _world_size() -> int:
+    """Ranks that all-reduce gradients with this process: the initialised process group, not the launcher's environment (a
+    sequential hpsearch started under torchrun has WORLD_SIZE > 1 but no group, and must not call a collective)."""
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class EarlyStopping(Callback):
@@ -79,8 +88,9 @@ class ModelCheckpoint(Callback):
 class ReduceLROnPlateau(Callback):
     """keras.callbacks.ReduceLROnPlateau(monitor, factor, patience, min_lr) (train.py:178-184), mode "max" (see ModelCheckpoint)."""
 
-    def __init__(self, monitor="val_MBA", factor=0.5, patience=3, min_lr=1e-7, mode="max", verbose=0):
+    def __init__(self, monitor="val_MBA", factor=0.5, patience=3, min_lr=1e-7, mode="max", min_delta=1e-4, verbose=0):
         self.monitor, self.factor, self.patience, self.min_lr, self.mode = monitor, factor, patience, min_lr, mode
+        self.min_delta = float(min_delta)  # keras.callbacks.ReduceLROnPlateau default
         self.best, self.wait = None, 0
 
     def on_epoch_end(self, loop, epoch, logs):
@@ -88,7 +98,7 @@ class ReduceLROnPlateau(Callback):
         logs["learning_rate"] = loop.trainer.lr
         if cur is None:
             return
-        if self.best is None or _better(cur, self.best, self.mode):
+        if self.best is None or _better(cur, self.best, self.mode, self.min_delta):
             self.best, self.wait = cur, 0
         else:
             self.wait += 1
@@ -123,24 +133,30 @@ class FitLoop:
         l2 = sum(float((m.weights[k].astype(np.float64) ** 2).sum()) for k in m.weights if k.endswith("/kernel") and (k.startswith("lstm") or k.startswith("dense1")))
         a = tot.cpu().numpy()
         a[3] = L2_LAMBDA * l2
-        if parallel.world()[1] > 1:
+        if _world_size() > 1:
             parts = parallel.gather_objects(a[:3].tolist())
             a[:3] = np.sum(np.array(parts), axis=0)
         return _epoch_logs(a)
 
     def fit(self, train_dataset, validation_data=None, epochs=1, callbacks=(), class_weight=None, verbose=0) -> History:
-        if class_weight is not None:
-            raise NotImplementedError("class_weight (call_weights) is not implemented on the HIP training path")
         hist = History()
         m = self.model
         H, W = m.input_hw
-        world = parallel.world()[1]
+        world = _world_size()
+        cw = None
+        if class_weight is not None:  # {class index: weight} (train.py:125-136); classes without an entry weigh 1, as in Keras
+            cw = torch.ones(max(m.num_labels, max(int(k) for k in class_weight) + 1), dtype=torch.float32, device=self.trainer.dev)
+            for k, v in class_weight.items():
+                cw[int(k)] = float(v)
         for cb in callbacks:
             cb.on_train_begin(self)
         for epoch in range(epochs):
             tot = torch.zeros(4, dtype=torch.float64, device=self.trainer.dev)
             for xb, yb in train_dataset:
-                out = self.trainer.train_step(xb.contiguous().view(-1), H * W, xb.shape[0], yb, world_size=world)
+                # Keras: sample weight of (snippet, step) = class_weight[argmax over the label axis of y_true]; a loss that returns a
+                # scalar (MaskedBinaryCrossentropy does) is multiplied by the batch mean of those weights
+                lw = None if cw is None else cw[yb.argmax(dim=-1)].mean().reshape(1)
+                out = self.trainer.train_step(xb.contiguous().view(-1), H * W, xb.shape[0], yb, world_size=world, loss_weight=lw)
                 tot[:3] += out["acc"][:3]
                 tot[3] = out["acc"][3]
             logs = _epoch_logs(tot.cpu().numpy())

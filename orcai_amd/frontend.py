@@ -50,12 +50,21 @@ class FrontEnd:
         nbytes = self.lib.orcai_frontend_workspace_bytes()
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
 
+    @staticmethod
+    def _check_nfft(n_fft: int) -> None:
+        """The reference reads nfft from the parameter file (spectrogram.py:34-39); the HIP STFT kernel is built for the 512-point
+        transform every shipped parameter file uses (orcai-V1, default_orcai_parameter.json).  Say so instead of a bare error code."""
+        if int(n_fft) != 512:
+            raise NotImplementedError(f"spectrogram parameter nfft = {n_fft}: the MI355X front end implements nfft = 512 only (the value of "
+                                      "orcai-V1 and of default_orcai_parameter.json); other transform sizes need the reference's CPU path")
+
     # -- the whole of make_spectrogram after decode (spectrogram.py:90-147) -----------------
     def make_spectrogram(self, pcm: torch.Tensor, spectrogram_parameter: dict) -> torch.Tensor:
         """pcm: f32[N] on the device, already at spectrogram_parameter['sampling_rate'].
         Returns f32[T, K] on the device, values in [0, 1]."""
         n_fft = int(spectrogram_parameter["nfft"])
         hop = int(spectrogram_parameter["n_overlap"])
+        self._check_nfft(n_fft)
         freqs = fft_frequencies(spectrogram_parameter["sampling_rate"], n_fft)
         f_lo, f_hi = crop_indices(freqs, spectrogram_parameter["freq_range"])
         if f_lo != 0:
@@ -77,6 +86,7 @@ class FrontEnd:
     # -- calculate_spectrogram (spectrogram.py:15-55): dB of all bins, referenced and floored ----
     def calculate_db(self, pcm: torch.Tensor, n_fft: int, hop: int) -> torch.Tensor:
         """Returns f32[T, 1 + n_fft//2] (time-major) = amplitude_to_db(|stft|, ref=max)."""
+        self._check_nfft(n_fft)
         pcm = self._check_pcm(pcm)
         n = pcm.numel()
         T = 1 + n // hop

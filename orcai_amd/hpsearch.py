@@ -2,8 +2,11 @@
 (``<output_dir>/hps_logs/{best_hyperparameters.json, all_trials.csv}``).  keras_tuner is absent, so the Hyperband
 schedule (max_epochs 10, factor 3, objective = monitor, direction max; hpsearch.py:189-234) is restated as host logic:
 successive-halving brackets over seeded random draws from the choice lists of the hps parameter file
-(``_hp_model_builder``, hpsearch.py:21-85).  Each trial trains with the HIP training path; with ``parallel`` every
-trial is data parallel over all ranks (what MirroredStrategy does in the reference).
+(``_hp_model_builder``, hpsearch.py:21-85).  As in keras_tuner's Hyperband, a configuration promoted to the next rung RESUMES from
+the state its previous rung ended in (weights, Adam moments, BatchNorm statistics, step count) and only trains the additional
+epochs; the best model seen so far (by the monitor) is written to ``<output_dir>/<name>/hps/<name>.weights.npz`` -- the
+reference's ModelCheckpoint(save_best_only=True) shared by all trials (hpsearch.py:227-242).  Each trial trains with the HIP
+training path; with ``parallel`` every trial is data parallel over all ranks (what MirroredStrategy does in the reference).
 """
 
 from __future__ import annotations
@@ -19,7 +22,7 @@ import pandas as pd
 from orcai_amd.architectures import build_model
 from orcai_amd.auxiliary import SEED_ID_LOAD_TEST_DATA, SEED_ID_LOAD_VAL_DATA, Messenger
 from orcai_amd.datasets import load_dataset
-from orcai_amd.fit import EarlyStopping
+from orcai_amd.fit import EarlyStopping, ModelCheckpoint
 from orcai_amd.io import read_json, write_json
 
 DEFAULT_ORCAI_PARAMETER = files("orcai_amd.defaults").joinpath("default_orcai_parameter.json")
@@ -61,9 +64,10 @@ def hyperband_brackets(max_epochs: int = MAX_EPOCHS, factor: int = FACTOR):
 
 
 def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_parameter: (Path | str) | dict = DEFAULT_ORCAI_PARAMETER,
-                          hps_parameter: (Path | str) | dict = DEFAULT_HPS_PARAMETER, parallel_: bool = False, data_compression: str | None = "GZIP",
-                          verbosity: int = 2, msgr: Messenger | None = None, parallel: bool | None = None, max_epochs: int = MAX_EPOCHS) -> None:
-    use_parallel = bool(parallel_ if parallel is None else parallel)
+                          hps_parameter: (Path | str) | dict = DEFAULT_HPS_PARAMETER, parallel: bool = False, data_compression: str | None = "GZIP",
+                          verbosity: int = 2, msgr: Messenger | None = None, max_epochs: int = MAX_EPOCHS) -> None:
+    """Same positional order as the reference (hpsearch.py:110-123); ``max_epochs`` (keyword only in practice) is Hyperband's R."""
+    use_parallel = bool(parallel)
     if msgr is None:
         msgr = Messenger(verbosity=verbosity, title="Hyperparameter search")
     import orcai_amd.parallel as par
@@ -83,29 +87,41 @@ def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_pa
     msgr.info(f"{'Parallel - running on ' + str(world) + ' GPU' if use_parallel else 'Sequential - running on 1 GPU'}")
     rng = np.random.default_rng(orcai_parameter.get("seed") or 0)
     trials = []
+    model_name = orcai_parameter["name"]
+    msgr.info(f"Saving best model to hps/{model_name}.weights.npz")
+    # ONE checkpoint callback for the whole search, like the reference's: it remembers the best monitor value over all trials
+    checkpoint = ModelCheckpoint(output_dir.joinpath(model_name, "hps", model_name + ".keras"), monitor=monitor, save_best_only=True)
+    seed = int(orcai_parameter.get("seed") or 0) % (2**31)
 
-    def run(hp: dict, epochs: int) -> float:
+    def run(hp: dict, epochs: int, resume: dict | None, initial_epoch: int):
+        """Train configuration `hp` from epoch `initial_epoch` to `epochs` (keras_tuner: tuner/initial_epoch .. tuner/epochs),
+        starting from `resume` (the Trainer state its previous rung ended in) when it was promoted.  -> (score, end state)"""
         p = _apply(hp, orcai_parameter, hps_parameter)
         bs = p["model"]["batch_size"]
         train_ds = load_dataset(data_dir.joinpath("train_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_TEST_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
         val_ds = load_dataset(data_dir.joinpath("val_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
         model = build_model(tuple(dataset_shape["spectrogram"]), p, msgr=Messenger(verbosity=0))
-        model.compile(learning_rate=p["model"]["learning_rate"])
-        hist = model.fit(train_ds, validation_data=val_ds, epochs=epochs, callbacks=[EarlyStopping(monitor=monitor, patience=5, mode="max", restore_best_weights=True)])
-        return float(max(hist.history[monitor]))
+        model.compile(learning_rate=p["model"]["learning_rate"], seed=seed)  # in a process group the Trainer broadcasts rank 0's initial weights
+        trainer = model._loop.trainer
+        if resume is not None:
+            trainer.load_state_dict(resume)
+        hist = model.fit(train_ds, validation_data=val_ds, epochs=max(1, epochs - initial_epoch),
+                         callbacks=[EarlyStopping(monitor=monitor, patience=5, mode="max", restore_best_weights=True), checkpoint])
+        return float(max(hist.history[monitor])), trainer.state_dict()
 
     for n, rungs in hyperband_brackets(max_epochs, FACTOR):
-        configs = [_draw(rng, hps_parameter, orcai_parameter) for _ in range(n)]
+        configs = [(_draw(rng, hps_parameter, orcai_parameter), None) for _ in range(n)]  # (hyper-parameters, state after the previous rung)
         for i, epochs in enumerate(rungs):
-            scores = []
-            for hp in configs:
-                score = run(hp, epochs)
+            scores, states = [], []
+            for hp, state in configs:
+                score, end_state = run(hp, epochs, state, rungs[i - 1] if i > 0 else 0)
                 scores.append(score)
-                trials.append({**hp, "epochs": epochs, "score": score, "status": "COMPLETED", monitor: score})
+                states.append(end_state)
+                trials.append({**hp, "epochs": epochs, "initial_epoch": rungs[i - 1] if i > 0 else 0, "score": score, "status": "COMPLETED", monitor: score})
                 msgr.info(f"trial {len(trials)}: {hp} epochs {epochs} -> {monitor} {score:.4f}")
             keep = max(1, len(configs) // FACTOR)
             order = np.argsort(-np.array(scores), kind="stable")[:keep]
-            configs = [configs[j] for j in order]
+            configs = [(configs[j][0], states[j]) for j in order]
             if i == len(rungs) - 1:
                 break
     best = max(trials, key=lambda t: t["score"])

@@ -56,8 +56,8 @@ def load_orcai_model(model_dir: Path):
     """(model, orcai_parameter, shape) from a model directory (io.py:357-410).
 
     Looks for ``<name>.weights.npz`` (this package's weight store: Keras variable names and layouts).
-    A Keras ``<name>.keras`` / ``model_weights.h5`` cannot be parsed here (no h5py/keras in the image):
-    convert it once with ``tools/keras_to_npz.py`` where Keras is available.
+    A Keras ``<name>.keras`` / legacy ``model_weights.h5`` (io.py:386-404) is an HDF5 container, which needs h5py to read: it is
+    converted once with ``python tools/keras_to_npz.py <model_dir>`` (variable paths -> npz names: ``orcai_amd/keras_layout.py``).
     """
     from orcai_amd.architectures import build_model
 
@@ -74,7 +74,7 @@ def load_orcai_model(model_dir: Path):
         return model, orcai_parameter, shape
     if model_dir.joinpath(name + ".keras").exists() or model_dir.joinpath("model_weights.h5").exists():
         raise ValueError(
-            f"{model_dir} holds Keras weights ({name}.keras / model_weights.h5); convert them to {name}{WEIGHTS_SUFFIX} "
-            "with tools/keras_to_npz.py (needs keras/h5py, which this image lacks)"
+            f"{model_dir} holds Keras weights ({name}.keras / model_weights.h5) but no {name}{WEIGHTS_SUFFIX}; convert them once with "
+            f"`python tools/keras_to_npz.py {model_dir}` (needs h5py)"
         )
     raise ValueError(f"Couldn't find model weights ({name}{WEIGHTS_SUFFIX}) in {model_dir}")

@@ -1,6 +1,7 @@
-"""Label rasterisation: annotation intervals -> per-frame label arrays.  Mirrors reference ``src/orcAI/labels.py``
-(``_convert_annotation`` :18-123, ``create_label_arrays`` :126-259) for the arrays the GPU training-data path reads
-(``datasets.RecordingStore``).  Host-side numpy / pandas, pinned by golden vectors from the reference's own
+"""Label rasterisation: annotation intervals -> per-frame label arrays.  Implements the contract of reference
+``src/orcAI/labels.py`` (``_convert_annotation`` :18-123, ``create_label_arrays`` :126-259) for the arrays the GPU
+training-data path reads (``datasets.RecordingStore``); the rasterisation itself is written from its definition as an interval
+sweep (``rasterise_intervals``), not as the reference's per-interval mask loop.  Host-side numpy / pandas, pinned by golden vectors from the reference's own
 ``_convert_annotation`` (``tests/golden/labels_raster.*``).  Label arrays are stored as ``labels.npy`` where the reference
 writes ``labels.zarr``.
 """
@@ -24,43 +25,60 @@ def read_annotation_file(annotation_file_path) -> pd.DataFrame:
     return table[["recording", "start", "stop", "origlabel"]]
 
 
+def rasterise_intervals(t_vec: np.ndarray, starts: np.ndarray, stops: np.ndarray) -> np.ndarray:
+    """0/1 per frame: 1 where the frame time t satisfies start <= t <= stop for at least one interval.  Written from the
+    definition (labels.py:100-107 tests every frame against every interval) as one sweep: frame times ascend, so an interval
+    covers the index range [first t >= start, last t <= stop] -- two binary searches per interval, a +1/-1 difference array and a
+    running sum instead of len(intervals) passes over all frames.  Intervals with a NaN bound or stop < start cover nothing,
+    exactly as the comparisons of the definition do."""
+    t_vec = np.asarray(t_vec, dtype=np.float64)
+    starts, stops = np.asarray(starts, dtype=np.float64), np.asarray(stops, dtype=np.float64)
+    ok = ~(np.isnan(starts) | np.isnan(stops))
+    first = np.searchsorted(t_vec, starts[ok], side="left")
+    past = np.maximum(np.searchsorted(t_vec, stops[ok], side="right"), first)
+    edges = np.zeros(len(t_vec) + 1, dtype=np.int64)
+    np.add.at(edges, first, 1)
+    np.add.at(edges, past, -1)
+    return (np.cumsum(edges[:-1]) > 0).astype(int)
+
+
 def _convert_annotation(annotation_file_path: Path, recording_data_dir: Path, label_calls: list, labels_present: list, labels_masked: list,
                         call_equivalences: (Path | str) | dict = None, msgr: Messenger = Messenger(verbosity=0)) -> tuple[pd.DataFrame, dict]:
-    """labels.py:18-123.  1 where a spectrogram frame time lies inside (inclusive) an annotated interval of the label, 0
-    elsewhere, MASK_VALUE in the columns of labels that cannot be annotated in this recording.  Like the reference, the label
-    column only exists after the call equivalences have been applied (a missing mapping raises KeyError)."""
+    """Same contract as the reference's ``_convert_annotation`` (labels.py:18-123): a frame of the recording's spectrogram gets 1
+    in a label's column when its time lies inside (bounds included) one of the label's annotated intervals, 0 otherwise, and
+    MASK_VALUE in the columns of labels that cannot be annotated in this recording; columns come back in ``label_calls`` order
+    together with {label: "present" | "masked"}.  The ``label`` column only exists once call equivalences have been applied (a
+    missing mapping is a KeyError there too); a missing ``times.json`` is logged and re-raised as FileNotFoundError."""
     msgr.part("Converting annotation to label array")
     annotation_file_path = Path(annotation_file_path)
-    recording = annotation_file_path.stem
-    annotations = read_annotation_file(annotation_file_path)
+    table = read_annotation_file(annotation_file_path)
     if call_equivalences is not None:
         msgr.info("Applying call equivalences")
-        if isinstance(call_equivalences, (Path, str)):
-            call_equivalences = read_json(call_equivalences)
-        annotations["label"] = annotations["origlabel"].map(call_equivalences)
-        missing = set(annotations["origlabel"].unique()).difference(call_equivalences.keys())
-        if missing:
-            msgr.info(f"labels not in call equivalences: {missing}")
-    annotations = annotations[["start", "stop", "label"]]
-    spectrogram_dir = Path(recording_data_dir).joinpath(recording, "spectrogram")
-    try:
-        t_vec = generate_times_from_spectrogram(spectrogram_dir.joinpath("times.json"))
-    except FileNotFoundError:
-        msgr.error(f"File not found: {spectrogram_dir.joinpath('times.json')}")
+        mapping = read_json(call_equivalences) if isinstance(call_equivalences, (Path, str)) else call_equivalences
+        table["label"] = table["origlabel"].map(mapping)
+        unmapped = sorted(set(table["origlabel"]) - set(mapping))
+        if unmapped:
+            msgr.info(f"labels not in call equivalences: {unmapped}")
+    times_file = Path(recording_data_dir).joinpath(annotation_file_path.stem, "spectrogram", "times.json")
+    if not times_file.exists():
+        msgr.error(f"File not found: {times_file}")
         msgr.error("Did you create the spectrogram?")
-        raise
-    annotations_array = pd.DataFrame({})
-    for label in labels_present:
-        intervals = annotations[annotations["label"] == label]
-        inside = np.zeros(len(t_vec), dtype=bool)
-        for start, stop in zip(intervals["start"], intervals["stop"]):
-            inside |= (t_vec >= start) & (t_vec <= stop)
-        annotations_array[label] = inside.astype(int)
-    for label in labels_masked:
-        annotations_array[label] = MASK_VALUE * np.ones(len(t_vec), dtype=int)
-    annotations_array = annotations_array.reindex(label_calls, axis=1)
-    label_dict = dict.fromkeys(labels_present, "present") | dict.fromkeys(labels_masked, "masked")
-    return annotations_array, {k: label_dict[k] for k in label_calls}
+        raise FileNotFoundError(times_file)
+    t_vec = generate_times_from_spectrogram(times_file)
+    by_label = {name: rows for name, rows in table[["start", "stop", "label"]].groupby("label", sort=False)}
+    columns, status = {}, {}
+    for name in label_calls:
+        if name in labels_present:
+            rows = by_label.get(name)
+            columns[name] = (rasterise_intervals(t_vec, rows["start"].to_numpy(), rows["stop"].to_numpy()) if rows is not None
+                             else np.zeros(len(t_vec), dtype=int))
+            status[name] = "present"
+        elif name in labels_masked:
+            columns[name] = np.full(len(t_vec), MASK_VALUE, dtype=int)
+            status[name] = "masked"
+        else:
+            raise KeyError(name)  # the reference's final {k: label_dict[k] for k in label_calls} raises the same
+    return pd.DataFrame(columns, columns=list(label_calls)), status
 
 
 def create_label_arrays(recording_table_path: Path | str, output_dir: Path | str, base_dir_annotation: Path | str = None,

@@ -148,9 +148,10 @@ class HeadTrainer:
             S[bn + "/mean"].mul_(BN_MOMENTUM).add_(mean, alpha=1 - BN_MOMENTUM)
             S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
 
-    def loss_and_backward(self, labels: torch.Tensor) -> dict:
+    def loss_and_backward(self, labels: torch.Tensor, loss_weight: torch.Tensor | None = None) -> dict:
         """labels: f32 cuda [n][T][L] in {0,1} or -1 (masked).  Fills the head's slices of the flat gradient buffer,
-        returns {"loss", "bce", "count", "correct", "dfeatv"} (device scalars stay on the device until .item())."""
+        returns {"loss", "bce", "count", "correct", "dfeatv"} (device scalars stay on the device until .item()).
+        loss_weight: optional device float[1], the batch mean of Keras' class_weight sample weights (orcai_masked_bce_w)."""
         lib, P, u, c = self.lib, self.P, self.u, self.cache
         st = N.stream_ptr()
         n, T = c["n"], c["T"]
@@ -162,7 +163,8 @@ class HeadTrainer:
         masks = c["masks"]
         acc = torch.zeros(4, dtype=torch.float64, device=dev)  # bce sum, count, correct, l2
         dz2 = torch.empty((M, L), **f32)
-        N.check(lib.orcai_masked_bce(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz2.data_ptr(), st), "masked_bce")
+        N.check(lib.orcai_masked_bce_w(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz2.data_ptr(),
+                                       None if loss_weight is None else loss_weight.data_ptr(), 1.0, st), "masked_bce")
         # Dense(labels): dW2 = d1d^T dz2, db2 = colsum(dz2), dd1d = dz2 W2^T
         _gemm(lib, c["d1d"], 1, DENSE_UNITS, dz2, L, 1, P.G("dense2/kernel"), DENSE_UNITS, L, M)
         N.check(lib.orcai_colsum(dz2.data_ptr(), M, L, P.G("dense2/bias").data_ptr(), 0, st), "colsum")
@@ -254,7 +256,7 @@ class Conv1DHeadTrainer:
         S["bn_f/mean"].mul_(BN_MOMENTUM).add_(c["f_mean"], alpha=1 - BN_MOMENTUM)
         S["bn_f/var"].mul_(BN_MOMENTUM).add_(c["f_var"], alpha=1 - BN_MOMENTUM)
 
-    def loss_and_backward(self, labels: torch.Tensor) -> dict:
+    def loss_and_backward(self, labels: torch.Tensor, loss_weight: torch.Tensor | None = None) -> dict:
         lib, P, c, st = self.lib, self.P, self.cache, N.stream_ptr()
         n, T, Wd = c["n"], c["T"], c["Wd"]
         M, L = n * T, self.model.num_labels
@@ -262,7 +264,8 @@ class Conv1DHeadTrainer:
         keep = 1.0 - c["rate"]
         acc = torch.zeros(4, dtype=torch.float64, device=labels.device)  # bce sum, count, correct, l2 (stays 0)
         dz = torch.empty((M, L), **f32)
-        N.check(lib.orcai_masked_bce(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz.data_ptr(), st), "masked_bce")
+        N.check(lib.orcai_masked_bce_w(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz.data_ptr(),
+                                       None if loss_weight is None else loss_weight.data_ptr(), 1.0, st), "masked_bce")
         dfm = torch.empty((n, T, FINAL_FILTERS), **f32)
         N.check(lib.orcai_conv1d_bwd(c["fm"].data_ptr(), P.W("conv1d/kernel").data_ptr(), dz.data_ptr(), n, T, FINAL_FILTERS, FINAL_FILTERS, L,
                                      P.G("conv1d/kernel").data_ptr(), dfm.data_ptr(), st), "conv1d_bwd")  # the gradient buffer was zeroed at the start of the step
@@ -551,6 +554,29 @@ class Trainer:
         self.lr = float(learning_rate)
         self.step_count = 0
         self.seed = int(seed)
+        self.rank = 0
+        self.broadcast_parameters()
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Data parallel replicas must START from the same weights (the reference's MirroredStrategy creates the variables once and
+        mirrors them, hpsearch.py:186-205): inside an initialised process group, rank `src`'s parameters, Adam moments and BatchNorm
+        moving statistics overwrite every other rank's.  Only gradients are exchanged afterwards, so replicas stay identical.  Each
+        rank keeps its own dropout stream (the rank is mixed into the mask seed)."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        self.rank = dist.get_rank()
+        tensors = [self.P.w, self.P.m, self.P.v] + [self.P.stats[k] for k in sorted(self.P.stats)]
+        if dist.get_backend() == "nccl":
+            for t in tensors:
+                dist.broadcast(t, src=src)
+        else:  # gloo (CPU tests): stage through the host
+            for t in tensors:
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+        self.model._dev = None  # folded inference copies are stale
 
     def _masks(self, n, T):
         rate = self.model.dropout_rate
@@ -567,12 +593,13 @@ class Trainer:
             todo = [("drop1", (n, T, 2 * self.model.lstm_units)), ("drop2", (n, T, 2 * self.model.lstm_units)), ("drop3", (n, T, DENSE_UNITS))]
         for idx, (j, shape) in enumerate(todo):
             mk = torch.empty(shape, dtype=torch.float32, device=self.dev)
-            seed = (self.seed * 1000003 + self.step_count * 16 + idx + 1) & 0xFFFFFFFFFFFFFFFF
+            seed = (self.seed * 1000003 + self.rank * 0x9E3779B1 + self.step_count * 16 + idx + 1) & 0xFFFFFFFFFFFFFFFF
             N.check(lib.orcai_dropout_mask(mk.data_ptr(), mk.numel(), seed, 1.0 - rate, st), "dropout_mask")
             out[j] = mk
         return out
 
-    def forward_backward(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor, masks: dict | None = "auto") -> dict:
+    def forward_backward(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor, masks: dict | None = "auto",
+                         loss_weight: torch.Tensor | None = None) -> dict:
         """Gradients of (masked BCE + L2) into the flat gradient buffer.  Returns device accumulators {bce sum, count, correct, l2}."""
         self.P.g.zero_()
         if isinstance(masks, str):
@@ -580,7 +607,7 @@ class Trainer:
         self.trunk.block_masks = [masks[f"block{i}"] for i in range(1, len(self.model.filters) + 1)] if (self.conv1d and masks is not None) else None
         featv = self.trunk.forward(src, snippet_stride, B)
         probs = self.head.forward(featv, masks, self.model.dropout_rate)
-        out = self.head.loss_and_backward(labels)
+        out = self.head.loss_and_backward(labels, loss_weight)
         self.trunk.backward(out["dfeatv"])
         return {"acc": out["acc"], "probs": probs}
 
@@ -614,7 +641,7 @@ class Trainer:
             self.P.stats[k].copy_(t)
         self.step_count, self.lr = s["step"], s["lr"]
 
-    def train_step(self, src, snippet_stride, B, labels, world_size: int = 1) -> dict:
-        out = self.forward_backward(src, snippet_stride, B, labels)
+    def train_step(self, src, snippet_stride, B, labels, world_size: int = 1, loss_weight=None) -> dict:
+        out = self.forward_backward(src, snippet_stride, B, labels, loss_weight=loss_weight)
         self.apply(world_size)
         return out

@@ -114,9 +114,22 @@ class WavPrefetcher:
         if not slots:
             return read_wav(path)
         i = slots.pop(0)
+        # recordings before i that were scheduled but never asked for (the caller skipped them: output exists, bad row, ...):
+        # cancel what has not started and drop the decoded audio of the rest -- an hour of 48 kHz mono is 0.7 GB of float32
+        for k in [k for k in self.futures if k < i]:
+            self.futures.pop(k).cancel()
+        self.next_to_schedule = max(self.next_to_schedule, i)  # never decode a recording the caller has already passed
         self._schedule_up_to(i + self.depth)
         fut = self.futures.pop(i)
         return fut.result()
+
+    def skip(self, path) -> None:
+        """The caller will not read this recording: release its slot (and its decoded audio, if any) now."""
+        slots = self.index.get(str(path))
+        if slots:
+            fut = self.futures.pop(slots.pop(0), None)
+            if fut is not None:
+                fut.cancel()
 
     def close(self) -> None:
         self.pool.shutdown(wait=False, cancel_futures=True)

@@ -117,6 +117,15 @@ def gen_preprocess(S):
             "out_sum_f64": float(y.astype(np.float64).sum()),
         }
         print("preprocess", name, summary[name])
+    # an input made of integer arithmetic only (tests/golden/portable_inputs.py): reproducible without trusting a Generator stream
+    from portable_inputs import hashed_db
+
+    x = hashed_db(23, 11251)
+    y = np.ascontiguousarray(S.preprocess_spectrogram(x.copy(), freqs, SPEC_PARAM))
+    summary["hashed_T11251"] = {"seed": 23, "T": 11251, "kind": "hashed", "input_crc32": crc(x), "output_crc32": crc(y),
+                                "p_lo": float(np.percentile(x[0:171], 1.0, method="nearest")), "p_hi": float(np.percentile(x[0:171], 99.9, method="nearest")),
+                                "out_sum_f64": float(y.astype(np.float64).sum())}
+    print("preprocess hashed_T11251", summary["hashed_T11251"])
     (HERE / "preprocess_large.json").write_text(json.dumps(summary, indent=1))
 
 
@@ -375,6 +384,12 @@ def gen_snippet_tables():
     print("snippet tables", allt.shape, filt.shape, {k: len(v) for k, v in files_out.items()})
 
 
+def main_only_preprocess():
+    """Regenerate the preprocess_* fixtures only (python make_golden.py preprocess)."""
+    S, _, _ = import_reference()
+    gen_preprocess(S)
+
+
 def main():
     S, P, A = import_reference()
     gen_preprocess(S)
@@ -388,4 +403,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.path.insert(0, str(HERE))
+    if sys.argv[1:] == ["preprocess"]:
+        main_only_preprocess()
+    else:
+        main()

@@ -1,0 +1,58 @@
+"""The C ABI is one contract stated three times: include/orcai_hip.h (the declarations a reference maintainer binds), the ctypes
+table in orcai_amd/_native.py, and the symbols liborcai_hip.so actually exports.  No compute calls: runs without a GPU."""
+
+import ctypes
+import re
+from pathlib import Path
+
+from orcai_amd import _native as N
+
+ROOT = Path(__file__).resolve().parent.parent
+C_TYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+           "double": ctypes.c_double}
+
+
+def header_prototypes() -> dict:
+    """{name: (return ctype, [argument ctypes])} parsed from every *.h under include/ (comments stripped)."""
+    out = {}
+    for h in sorted((ROOT / "include").glob("*.h")):
+        text = re.sub(r"/\*.*?\*/", " ", h.read_text(), flags=re.S)
+        for ret, name, args in re.findall(r"\b(int|size_t|const char\s*\*)\s*(orcai_\w+)\s*\(([^)]*)\)\s*;", text):
+            argtypes = []
+            for a in [x.strip() for x in args.split(",")]:
+                if a in ("void", ""):
+                    continue
+                if "*" in a or "[" in a:  # an array parameter is a pointer
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = re.sub(r"\bconst\b", "", a).split()[0]
+                    argtypes.append(C_TYPES[base])
+            rt = ctypes.c_char_p if "char" in ret else C_TYPES[ret]
+            out[name] = (rt, argtypes)
+    return out
+
+
+def _same(a, b) -> bool:
+    pointerish = (ctypes.c_void_p, ctypes.c_char_p)
+    if a in pointerish or (isinstance(a, type) and issubclass(a, ctypes._Pointer)):
+        return b in pointerish or (isinstance(b, type) and issubclass(b, ctypes._Pointer))
+    return ctypes.sizeof(a) == ctypes.sizeof(b) and a._type_.lower() == b._type_.lower() or a is b
+
+
+def test_header_and_ctypes_table_declare_the_same_functions():
+    proto = header_prototypes()
+    assert len(proto) >= 60
+    assert set(proto) == set(N.exported_symbols()), sorted(set(proto) ^ set(N.exported_symbols()))
+    for name, (ret, args) in proto.items():
+        r2, a2 = N._SIGNATURES[name]
+        assert _same(ret, r2), name
+        assert len(args) == len(a2), (name, len(args), len(a2))
+        for i, (x, y) in enumerate(zip(args, a2)):
+            assert _same(x, y), (name, i, x, y)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = N.lib()  # raises NativeLibraryError when the library or a symbol is missing (no CPU fallback)
+    for name in header_prototypes():
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.orcai_version()

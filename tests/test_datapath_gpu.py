@@ -113,6 +113,7 @@ def test_data_preparation_commands_feed_training(tmp_path):
 
     from orcai_amd.cli import cli
     from orcai_amd.datasets import SnippetTableDataset, load_dataset
+    from tools.dataprep.cli import dataprep  # snippet-table tooling lives outside the product package
     from orcai_amd.io import read_json
 
     rng = np.random.default_rng(5)
@@ -133,7 +134,7 @@ def test_data_preparation_commands_feed_training(tmp_path):
         (d / "labels" / "label_list.json").write_text(json.dumps({c: i for i, c in enumerate(calls)}))
     table = tmp_path / "recordings.csv"
     pd.DataFrame({"recording": ["rec0", "rec1", "rec2"], "base_dir_annotation": ["x", "x", "x"]}).to_csv(table, index=False)  # rec2 has no data directory
-    param = read_json(__import__("orcai_amd.snippets", fromlist=["x"]).DEFAULT_ORCAI_PARAMETER)
+    param = read_json(__import__("tools.dataprep.snippets", fromlist=["x"]).DEFAULT_ORCAI_PARAMETER)
     param.update({"name": "tiny", "seed": 3, "calls": calls})
     param["model"].update({"filters": [8, 12], "lstm_units": 64, "batch_size": 4, "n_batch_train": 5, "n_batch_val": 2, "n_batch_test": 2, "epochs": 1,
                            "call_weights": None})
@@ -145,7 +146,7 @@ def test_data_preparation_commands_feed_training(tmp_path):
     for args in (["create-snippet-table", str(table), str(root), "-o", str(tvt), "-p", str(pfile), "-v", "0"],
                  ["create-tvt-snippet-tables", str(tvt), "-p", str(pfile), "-uts", "-n_uts", "6", "-v", "0"],
                  ["create-tvt-data", str(tvt), "-p", str(pfile), "-v", "0"]):
-        res = run.invoke(cli, args, catch_exceptions=False)
+        res = run.invoke(dataprep, args, catch_exceptions=False)
         assert res.exit_code == 0, (args, res.output)
     assert read_json(tvt / "dataset_shapes.json") == {"spectrogram": [32, W, 1], "labels": [8, len(calls)]}  # 1.7 s = 34 frames -> 32 (a multiple of 2**2 blocks)
     assert sorted(p.name for p in tvt.iterdir() if p.is_dir()) == ["test_dataset", "test_unfiltered_dataset", "train_dataset", "val_dataset"]

@@ -135,9 +135,6 @@ def test_cli_surface_matches_reference_options():
         "predict": {"-c", "-m", "-md", "-o", "-ow", "-sp", "-bdr", "-cdl", "-ls", "-v"},
         "create-spectrograms": {"-bdr", "-p", "-en", "-enp", "-ow", "-v"},
         "create-label-arrays": {"-bda", "-p", "-ce", "-ow", "-v"},
-        "create-snippet-table": {"-o", "-p", "-v"},
-        "create-tvt-snippet-tables": {"-st", "-p", "-uts", "-n_uts", "-ow", "-v"},
-        "create-tvt-data": {"-p", "-ow", "-dc", "-v"},
         "train": {"-p", "-dc", "-lm", "-v"},
         "hpsearch": {"-p", "-hp", "-pl", "-dc", "-v"},
         "test": {"-tu", "-o", "-dc", "-v"},
@@ -244,3 +241,111 @@ def test_wav_prefetcher_order_errors_and_fallback(tmp_path):
     finally:
         wavio.set_prefetcher(None)
     assert wavio.read_wav_prefetched(paths[0])[1] == 22050  # no prefetcher: plain read
+
+
+def test_keras_weight_file_name_map_round_trips():
+    """B8 (io.py:386-404): every variable of the architecture has exactly one place in a Keras weight file, and back.  npz ->
+    Keras-3 dataset paths -> npz is the identity; the same through the legacy model_weights.h5 naming; layer-name offsets of a model
+    built in a non-fresh Keras session do not matter (ordinals are ranks of the numeric suffixes)."""
+    from orcai_amd import keras_layout as K
+    from orcai_amd.architectures import ResNet1DConv, ResNetLSTM
+
+    for model in (ResNetLSTM((64, 21, 1), 7, [30, 40, 50, 60], 3, 0.5, 128, seed=3), ResNetLSTM((32, 12, 1), 3, [10, 20], 5, 0.3, 64, seed=4),
+                  ResNet1DConv((32, 12, 1), 3, [8, 12, 16], 3, 0.2, seed=5)):
+        nb, arch = len(model.filters), model.architecture
+        spec = model.variable_spec()
+        names = [n for *_, n in K.variable_map(nb, arch)]
+        assert sorted(names) == sorted(n for n, *_ in spec) and len(set(names)) == len(names)
+        paths = K.to_keras3_paths(model.weights, nb, arch)
+        assert len(paths) == len(spec)
+        assert "layers/conv2d/vars/0" in paths and f"layers/batch_normalization_{2 * nb + 1}/vars/3" in paths
+        if arch == "ResNetLSTM":
+            assert "layers/bidirectional_1/backward_layer/cell/vars/1" in paths and paths["layers/dense_1/vars/0"].shape == (128, model.num_labels)
+        paths["optimizer/vars/0"] = np.zeros(1)  # optimizer state in the archive is ignored
+        back = K.from_keras3_paths(paths, nb, arch)
+        assert set(back) == set(model.weights) and all(np.array_equal(back[k], model.weights[k]) for k in back)
+        # a model built after other models in the same session: every class's names start at an offset
+        shifted = {}
+        for p, a in paths.items():
+            parts = p.split("/")
+            if parts[0] == "layers":
+                base, _, num = parts[1].rpartition("_") if parts[1][-1].isdigit() else (parts[1], "", "0")
+                parts[1] = f"{base}_{int(num) + 11}"
+            shifted["/".join(parts)] = a
+        back2 = K.from_keras3_paths(shifted, nb, arch)
+        assert all(np.array_equal(back2[k], model.weights[k]) for k in model.weights)
+        # and the converted dict loads into a fresh model (name set + shapes checked by set_weights_dict)
+        type(model)(model.input_shape[1:], model.num_labels, model.filters, model.kernel_size, seed=9, **({"lstm_units": model.lstm_units} if arch == "ResNetLSTM" else {})
+                    ).set_weights_dict(back)
+    # legacy tf.keras save_weights naming
+    m = ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.3, 64, seed=6)
+    kv = {"kernel": "kernel:0", "bias": "bias:0", "depthwise": "depthwise_kernel:0", "pointwise": "pointwise_kernel:0", "gamma": "gamma:0", "beta": "beta:0",
+          "mean": "moving_mean:0", "var": "moving_variance:0", "recurrent": "recurrent_kernel:0"}
+    arrays, layer_names, weight_names = {}, [], {}
+    for cls, k, sub, i, name in K.variable_map(2):
+        layer = K.SNAKE[cls] + (f"_{k}" if k else "")
+        if layer not in weight_names:
+            layer_names.append(layer)
+            weight_names[layer] = []
+        inner = f"{sub[0].replace('_layer', '_lstm')}/lstm_cell/" if sub else ""
+        wn = f"{layer}/{inner}{kv[name.rsplit('/', 1)[1]]}"
+        weight_names[layer].append(wn)
+        arrays[f"{layer}/{wn}"] = m.weights[name]
+    back = K.from_legacy_h5(arrays, layer_names, weight_names, 2)
+    assert all(np.array_equal(back[k], m.weights[k]) for k in m.weights)
+    assert (ROOT / "tools" / "keras_to_npz.py").exists()  # the file load_orcai_model's error message names
+
+
+def test_wav_prefetcher_drops_recordings_the_caller_skips(tmp_path):
+    """Table mode skips recordings (output exists, bad rows) without reading them: their decoded audio must not pile up."""
+    from orcai_amd import wavio
+
+    paths = []
+    for i in range(8):
+        p = tmp_path / f"r{i}.wav"
+        wavio.write_wav_pcm16(p, np.full(100, int(i / 10.0 * 32768), dtype=np.int16), 8000)
+        paths.append(p)
+    pf = wavio.WavPrefetcher(paths, depth=2, workers=2)
+    try:
+        y, sr = pf.get(paths[0])
+        assert sr == 8000 and y.shape[-1] == 100
+        y, _ = pf.get(paths[5])  # 1..4 skipped by the caller
+        assert abs(float(y.reshape(-1)[0]) - 0.5) < 1e-3
+        assert all(k > 5 for k in pf.futures) and len(pf.futures) <= pf.depth
+        pf.skip(paths[6])
+        assert 6 not in pf.futures
+        y, _ = pf.get(paths[7])
+        assert abs(float(y.reshape(-1)[0]) - 0.7) < 1e-3 and not pf.futures
+    finally:
+        pf.close()
+
+
+def test_callbacks_follow_keras_conventions():
+    """ReduceLROnPlateau only counts an improvement larger than min_delta = 1e-4 (Keras default); the data-parallel world size
+    comes from the process group, not from the launcher's environment."""
+    import os
+
+    from orcai_amd import fit
+
+    class Tr:
+        lr = 1.0
+
+    class Loop:
+        trainer = Tr()
+
+    cb = fit.ReduceLROnPlateau(monitor="val_MBA", factor=0.5, patience=2, min_lr=0.1)
+    loop = Loop()
+    for v in (0.5, 0.50005, 0.50009):  # creeping up by less than min_delta: no improvement
+        cb.on_epoch_end(loop, 0, {"val_MBA": v})
+    assert loop.trainer.lr == 0.5
+    cb.on_epoch_end(loop, 0, {"val_MBA": 0.6})
+    assert cb.best == 0.6 and cb.wait == 0
+    old = os.environ.get("WORLD_SIZE")
+    os.environ["WORLD_SIZE"] = "4"  # torchrun environment without an initialised group (sequential hpsearch)
+    try:
+        assert fit._world_size() == 1
+    finally:
+        if old is None:
+            del os.environ["WORLD_SIZE"]
+        else:
+            os.environ["WORLD_SIZE"] = old

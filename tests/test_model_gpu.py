@@ -125,32 +125,6 @@ def test_overlap_average_bit_exact(golden_dir):
         assert np.array_equal(agg, g["aggregated"]) and np.array_equal(cnt, g["overlap_count"])
 
 
-@pytest.mark.parametrize("variant", ["lds", "rows"])
-def test_fused_block_variants_match_unfused(variant):
-    """The experimental fused residual-block kernels (both separable convs in one launch) give the unfused result."""
-    model, p = make_model(9)
-    x = np.random.default_rng(4).random((3, 736, 171, 1), dtype=np.float32)
-    ref = model.predict(x, batch_size=3)
-    model.fuse_min_width, model.fuse_variant = 60, variant
-    out = model.predict(x, batch_size=3)
-    assert np.abs(out - ref).max() <= 2e-6
-    assert np.abs(out - M.forward_ref(p, x)).max() <= 1e-5
-
-
-@pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((64, 61, 1), (10, 20, 30)), ((32, 118, 1), (12, 64))])
-def test_fused_sepconv_pool_residual_matches_unfused(shape, filters):
-    """orcai_sep_pool_res (second separable conv + BN + max-pool + strided residual + add in one launch; k = 3, even H) against
-    the unfused pair on the same weights: same arithmetic per element, so the block outputs agree to rounding; widths at and
-    around the 60-column window (61, 118, 171) and 64 filters (4 output tiles) are covered."""
-    model, p = make_model(13, input_shape=shape, filters=filters, kernel_size=3, lstm_units=64, num_labels=3)
-    x = np.random.default_rng(5).random((3, *shape), dtype=np.float32)
-    unfused = model.predict(x, batch_size=3)
-    model.fuse_pool_min_width = 1  # experimental path, off by default
-    fused = model.predict(x, batch_size=3)
-    assert np.abs(fused - unfused).max() <= 2e-6, np.abs(fused - unfused).max()
-    assert np.abs(fused - M.forward_ref(p, x)).max() <= 1e-5
-
-
 def make_1dconv(seed, input_shape, filters, kernel_size, num_labels=7):
     """Calibrated trunk parameters of the oracle + a glorot Conv1D head (architectures.py:107-115)."""
     from orcai_amd.architectures import FINAL_FILTERS, ResNet1DConv

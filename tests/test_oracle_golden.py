@@ -235,7 +235,7 @@ def _golden_generator_module(golden_dir):
 
 
 def test_snippet_tables_match_reference(golden_dir, tmp_path):
-    """orcai_amd.snippets against the reference's own snippets.py run on the same recording directories with the same seeds
+    """tools/dataprep/snippets.py against the reference's own snippets.py run on the same recording directories with the same seeds
     (tests/golden/snippet_tables.*): row indices, per-call label seconds (NaN for masked labels), the random filtering, the
     statistics table and every file create_snippet_table / create_tvt_snippet_tables write -- bit for bit / byte for byte."""
     import gzip
@@ -243,7 +243,7 @@ def test_snippet_tables_match_reference(golden_dir, tmp_path):
 
     import pandas as pd
 
-    from orcai_amd import snippets as Sn
+    from tools.dataprep import snippets as Sn
     from orcai_amd.auxiliary import Messenger
 
     G = _golden_generator_module(golden_dir)

@@ -68,7 +68,7 @@ def _oracle_pipeline(y48, p):
     agg, cnt = P.aggregate_predictions_ref(pred, spec.shape[0], 736, 4, 7)
     s, e, n = P.compute_binary_predictions_ref(agg, cnt, CALLS)
     labels = P.compute_labels_ref(s, e, n, 16, "*")
-    return agg, cnt, P.labels_to_tsv_ref(labels, times[1] - times[0])
+    return agg, cnt, P.labels_to_tsv_ref(labels, times[1] - times[0]), times[1] - times[0]
 
 
 @pytest.mark.parametrize("sr", [48000, 22050])
@@ -86,13 +86,31 @@ def test_predict_wav_end_to_end(tmp_path, sr):
     predict(wav, channel=1, model_dir=model_dir, output_path=out, save_probabilities=True, verbosity=0)
     y = pcm16_to_float(pcm)
     y48 = y if sr == 48000 else resample_ref(y, sr, 48000)
-    agg_ref, cnt_ref, tsv_ref = _oracle_pipeline(y48, p)
+    agg_ref, cnt_ref, tsv_ref, delta_t = _oracle_pipeline(y48, p)
     probs = pd.read_csv(io.BytesIO(gzip.decompress((tmp_path / "rec_pred_probabilities.csv.gz").read_bytes())), index_col="time")
     assert list(probs.columns) == CALLS and probs.shape == agg_ref.shape
     assert np.abs(probs.to_numpy() - agg_ref).max() <= 2e-4
+    # Label intervals: identical to the oracle's except where an averaged probability lies within tolerance of the
+    # threshold -- those (step, label) cells are COUNTED, set to the oracle's side of the threshold in the GPU probabilities, and the
+    # intervals extracted from the result must then equal the oracle's text exactly.  Never skipped; few cells may be ambiguous.
     thr = 0.5 / cnt_ref.max()
-    if np.abs(agg_ref - thr).min() > 1e-3:
-        assert out.read_text() == tsv_ref
+    ambiguous = np.abs(agg_ref - thr) <= 1e-3
+    n_amb = int(ambiguous.sum())
+    print(f"e2e sr={sr}: {n_amb} of {agg_ref.size} (step, label) cells within 1e-3 of the threshold {thr}")
+    assert n_amb <= max(3, agg_ref.size // 200), n_amb
+    from oracle import postprocess_ref as P
+
+    gpu_agg = probs.to_numpy().copy()
+    gpu_agg[ambiguous] = agg_ref[ambiguous]
+    s_, e_, n_ = P.compute_binary_predictions_ref(gpu_agg, cnt_ref, CALLS)
+    assert P.labels_to_tsv_ref(P.compute_labels_ref(s_, e_, n_, 16, "*"), delta_t) == tsv_ref
+    if n_amb == 0:
+        assert out.read_text() == tsv_ref  # the file the product wrote, byte for byte
+    else:  # the product's file differs from the oracle's at most by runs touching an ambiguous cell
+        got = [ln.split("\t") for ln in out.read_text().splitlines()[1:]]
+        want = [ln.split("\t") for ln in tsv_ref.splitlines()[1:]]
+        amb_labels = {CALLS[j] + "*" for j in np.nonzero(ambiguous.any(axis=0))[0]}
+        assert [g for g in got if g[2] not in amb_labels] == [w for w in want if w[2] not in amb_labels]
     with pytest.raises(FileExistsError):
         predict(wav, channel=1, model_dir=model_dir, output_path=out, verbosity=0)
     predict(wav, channel=1, model_dir=model_dir, output_path=out, overwrite=True, verbosity=0)

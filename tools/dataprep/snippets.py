@@ -1,4 +1,9 @@
-"""Snippet tables: which rows of which recording make up the training / validation / test snippets.  Mirrors reference
+"""DERIVED RESTATEMENT, OUTSIDE THE PRODUCT PACKAGE.  This module follows the reference's ``src/orcAI/snippets.py`` statement by
+statement (same branches, random-stream order and messages) because its only purpose is to reproduce that module's tables bit
+for bit; SURVEY 2 rows 8-9 mark the component out of scope, so it lives under ``tools/`` as data-preparation / test tooling and
+nothing in ``orcai_amd/`` imports it (the hot path only needs the index arithmetic in ``orcai_amd.datasets.snippet_rows``).
+
+Snippet tables: which rows of which recording make up the training / validation / test snippets.  Mirrors reference
 ``src/orcAI/snippets.py`` (``_make_snippet_table`` :26-163, ``_compute_snippet_stats`` :166-193, ``create_snippet_table``
 :196-321, ``_filter_snippet_table`` :324-388, ``create_tvt_snippet_tables`` :391-556, ``create_tvt_data`` :618-744): same
 function names, arguments, random streams (``default_rng([SEED_ID, seed])``, draws in the same order) and output files, so a
