@@ -327,6 +327,42 @@ int orcai_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, 
 /* dx = (y > 0) ? dy : 0 on whole plane buffers (n_floats % 4 == 0) */
 int orcai_planes_relu_bwd(const float* dy, const float* y, int64_t n_floats, float* dx, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * f16 path (BASELINE configs[4]: the hyper-parameter sweep's width variants on f16 MFMA; hpsearch.py:186-205 x
+ * defaults/default_hps_parameter.json:2-25).  Activations are f16 channel-OCTET planes
+ *   [snippet][CO = ceil(C/8)][H + 2R][orcai_padded_width(W, k)][8]   (zero pads, written once by the host),
+ * contractions run on v_mfma_f32_16x16x32_f16 with f32 accumulation; weights are f16 COPIES of the f32 master weights in these
+ * layouts (orcai_amd/half.py packs them on the host, orcai_h_pack_weights on the device once per training step):
+ *   depthwise taps      f16[CO][k*k][8]                      element (o, tap, e) = Keras depthwise kernel [tap/k][tap%k][8o+e][0]
+ *   A fragments of W    f16[KG = ceil(Cin/32)][MT = ceil(Cout/16)][64][8]
+ *                       element (kg, m, lane, e) = W[cin = 32kg + 8(lane>>4) + e][cout = 16m + (lane&15)], 0 outside W[Cin][Cout]
+ *   transposed dense    f16 Wt[N][roundup32(K)] of W[K][N]
+ * Pointers to f16 data are void*.  Same conventions as above (device pointers, caller-owned, stream-ordered, capturable).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Conv2D(16, k, same)(f32 snippet) * scale + shift [ReLU] -> f16 octet planes of 16 channels (architectures.py:164-168);
+ * arguments as orcai_conv0_affine. */
+int orcai_h_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift, int relu,
+                         void* out, void* stream);
+
+/* [ReLU] -> depthwise ktap x ktap -> pointwise -> * scale + shift -> [ReLU] on f16 octet planes padded for ksize_planes
+ * (architectures.py:174-189, 198-206): orcai_sepconv_planes_u of the f32 path.  out_layout 0: f16 octet planes; 1: f32
+ * [B][H][W*Cout] Keras Reshape layout; 2: x-pooled f16 [B][CO][H][roundup4(ceil(W/2))][8]; 3: scatter-add into pixel (2y, 2x) of
+ * f16 planes of an (H2, W2) image.  u_out (may be NULL): the depthwise output, f16 octet planes of Cin channels.  Cin, Cout <= 64. */
+int orcai_h_sepconv(const void* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const void* dw, const void* pwf, const float* scale,
+                    const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, void* out, void* u_out, void* stream);
+
+/* MaxPooling2D((3,2), 2, "same")(s) + Conv2D(C, 1, strides 2)(prev) + bias (architectures.py:190-196) on f16 octet planes.
+ * xpooled 1: s is the x-pooled tensor of orcai_h_sepconv(out_layout 2); 0: s are planes.  bn_mean..bn_beta (NULL, or all four with
+ * xpooled 0): s is the pre-BatchNorm tensor and the pooling runs on BN(s) without materialising it (training forward). */
+int orcai_h_pool_res_add(const void* s, const void* prev, int B, int C, int Cp, int H, int W, int ksize, const void* wrf, const float* br, void* out, int xpooled,
+                         const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* stream);
+
+/* C[M][N] = act(A[M][K] Wt^T + bias) [* scale + shift]: A f32 (converted to f16 on load), Wt f16[N][roundup32(K)], f32 accumulate and
+ * output; act 1 = ReLU.  LSTM input projections and Dense-128 (architectures.py:210-237).  K % 4 == 0. */
+int orcai_h_gemm_bias_act(const float* A, const void* Wt, const float* bias, const float* scale, const float* shift, float* C, int64_t M, int N, int K, int act,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,7 +54,7 @@ class ResNetLSTM:
     architecture = "ResNetLSTM"
 
     def __init__(self, input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, lstm_units=128,
-                 conv_initializer="he_normal", lstm_initializer="glorot_uniform", seed=None, **unused):
+                 conv_initializer="he_normal", lstm_initializer="glorot_uniform", seed=None, precision="f32", **unused):
         self.input_hw = (int(input_shape[0]), int(input_shape[1]))
         if int(input_shape[2]) != 1:
             raise ValueError("ResNetLSTM expects a single input channel")
@@ -71,6 +71,13 @@ class ResNetLSTM:
             raise NotImplementedError("HIP separable-conv kernel implements up to 64 filters")
         if self.num_labels > 8:
             raise NotImplementedError("HIP head kernel implements up to 8 labels")
+        # "f32" (the reference's arithmetic, default) or "f16": f16 octet planes + v_mfma_f32_16x16x32_f16 contractions with f32
+        # master weights (orcai_amd/half.py; BASELINE configs[4]).  An extra key of orcai_parameter["model"], swallowed by the
+        # reference's **unused like any other (architectures.py:129).
+        if precision not in ("f32", "f16"):
+            raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
+        self.precision = precision
+        self._half_engine = None
         self.weights: dict[str, np.ndarray] = {}
         self._init_weights(np.random.default_rng(seed))
         self._dev = None  # folded device copies
@@ -203,6 +210,8 @@ class ResNetLSTM:
                 raise ValueError(f"weight {name}: shape {w.shape} != {shape}")
             self.weights[name] = np.ascontiguousarray(w)
         self._dev = None
+        if self._half_engine is not None:
+            self._half_engine._dev = None
 
     def save_weights(self, path) -> None:
         np.savez(path, **self.weights)
@@ -427,6 +436,8 @@ class ResNetLSTM:
         """n snippets starting at ``src`` (f32 cuda), snippet i at element offset i*snippet_stride, each [H][W] row-major
         (unpadded).  Writes probabilities into out[n][steps][labels].  The trunk runs in chunks of `chunk` snippets
         (bounds activation memory); the recurrent head runs once over all n."""
+        if self.precision == "f16":
+            return self.half_engine().forward_device(src, snippet_stride, n, out, chunk=chunk, keep=keep)
         steps, wd, _ = self.stage_shapes()[-1]
         feat = torch.empty((n, steps, wd * FINAL_FILTERS), dtype=torch.float32, device=src.device)
         nb = len(self.filters)
@@ -448,6 +459,13 @@ class ResNetLSTM:
                     self.trunk_device(src[s * snippet_stride :], snippet_stride, B, None, first=0, last=split - 1, ws=head)
                 self.trunk_device(None, snippet_stride, nt, feat[t0:], first=split, last=nb + 1, ws=tail)
         self.head_device(feat, out, keep=keep)
+
+    def half_engine(self):
+        if self._half_engine is None:
+            from orcai_amd.half import HalfEngine
+
+            self._half_engine = HalfEngine(self)
+        return self._half_engine
 
     def predict_spectrogram(self, spectrogram: torch.Tensor, chunk: int = 128, shard: bool = False) -> torch.Tensor:
         """All 50 %-overlapping snippets of a device spectrogram [T][W] -> f32 cuda [n][steps][labels].
@@ -516,8 +534,9 @@ class ResNetLSTM:
 
 def res_net_LSTM_arch(input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, lstm_units=128, conv_initializer="he_normal",
                       lstm_initializer="glorot_uniform", **unused) -> ResNetLSTM:
-    """architectures.py:120-241."""
-    return ResNetLSTM(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units, conv_initializer, lstm_initializer, **unused)
+    """architectures.py:120-241.  ``precision`` ("f32" | "f16") may ride along in **unused (an extra key of orcai_parameter["model"])."""
+    return ResNetLSTM(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units, conv_initializer, lstm_initializer,
+                      precision=unused.get("precision", "f32"), seed=unused.get("seed"))
 
 
 class ResNet1DConv(ResNetLSTM):
@@ -530,6 +549,8 @@ class ResNet1DConv(ResNetLSTM):
     conv_kind = "glorot"  # conv_initializer default "glorot_uniform" (architectures.py:24)
 
     def __init__(self, input_shape, num_labels, filters, kernel_size, dropout_rate=0.0, conv_initializer="glorot_uniform", seed=None, **unused):
+        if unused.get("precision", "f32") != "f32":
+            raise NotImplementedError("the f16 path implements ResNetLSTM only")
         super().__init__(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units=128, conv_initializer=conv_initializer, seed=seed)
 
     def _head_spec(self):
