@@ -363,6 +363,33 @@ int orcai_h_pool_res_add(const void* s, const void* prev, int B, int C, int Cp, 
 int orcai_h_gemm_bias_act(const float* A, const void* Wt, const float* bias, const float* scale, const float* shift, float* C, int64_t M, int N, int K, int act,
                           void* stream);
 
+/* f16 path, training: the twins of the f32 training-trunk entry points on f16 octet planes.  Argument lists are IDENTICAL to
+ * orcai_bn_planes_stats, orcai_planes_sum, orcai_bn_planes_apply, orcai_bn_bwd_pointwise, orcai_pool_bwd_bn, orcai_outer_reduce,
+ * orcai_dw_wgrad, orcai_conv0_bn_bwd, orcai_pack_weights, orcai_feat_to_planes, orcai_planes_relu_bwd (see those for the arithmetic and
+ * the reference lines); plane tensors are f16 octet planes, statistics / weight gradients / scratch stay f32 / f64, and matrix operands
+ * are f16 A fragments: wtf of orcai_h_bn_bwd_pointwise = fragments of the TRANSPOSED pointwise matrix (row = conv-input channel,
+ * k = conv-output channel).  Gradient planes carry the caller's static loss scale; nothing here knows its value.
+ * scratch2C: f64[16 * ceil(C/8)].  orcai_h_planes_relu_bwd counts f16 elements (a multiple of 8).
+ * orcai_h_pack_weights descriptors {type, src offset (floats), dst offset (halves), C, aux}: 0 / 1 depthwise octets forward / reversed
+ * (aux = k*k), 2 A fragments of W[C][aux], 3 A fragments of its transpose, 4 identity fragments of C channels, 5 all-ones taps. */
+int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize, double* scratch2C, float* mean, float* var, void* stream);
+int orcai_h_planes_sum(const void* x, int B, int C, int H, int W, int ksize, double* scratchC, float* out, int accumulate, void* stream);
+int orcai_h_bn_planes_apply(const void* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, int relu, void* y, void* stream);
+int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                             const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma, const void* wtf, int Cin,
+                             void* dv, void* du, void* stream);
+int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                        const float* bn_var, float bn_eps, double* bn_sums, void* stream);
+int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, float* workspace,
+                         int64_t workspace_floats, void* stream);
+int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
+int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                         const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream);
+int orcai_h_pack_weights(const float* w, const int* desc, int n_desc, void* out, void* stream);
+int orcai_h_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, void* out, void* stream);
+int orcai_h_planes_relu_bwd(const void* dy, const void* y, int64_t n_halves, void* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,17 @@ _SIGNATURES = {
     "orcai_h_sepconv": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_h_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]),
     "orcai_h_gemm_bias_act": (C.c_int, [C.c_void_p] * 6 + [c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "orcai_h_bn_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4),
+    "orcai_h_planes_sum": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "orcai_h_bn_planes_apply": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_h_bn_bwd_pointwise": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    "orcai_h_pool_bwd_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "orcai_h_outer_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "orcai_h_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
+    "orcai_h_conv0_bn_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 5),
+    "orcai_h_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_h_feat_to_planes": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
+    "orcai_h_planes_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

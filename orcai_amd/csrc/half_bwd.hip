@@ -1,0 +1,824 @@
+// half_bwd.hip -- training on the f16 path (BASELINE configs[4]): batch-statistics BatchNorm and the backward kernels of the
+// convolutional trunk on f16 channel-octet planes (half_planes.h).  Activations AND activation gradients are stored in f16 (the
+// gradients carry a static loss scale, orcai_masked_bce_w / orcai_adam_step's gscale); every reduction -- BatchNorm sums, weight
+// gradients -- accumulates in f32 / f64 and lands in the f32 gradient buffer of the f32 master weights.
+// Same decomposition as train_trunk.hip (reference: architectures.py:162-206; train.py:201-219 computes these inside Keras).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "half_planes.h"
+#include "orcai_hip.h"
+
+namespace {
+
+using namespace orcai_half;
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+struct O8 {
+  float v[8];
+};
+__device__ __forceinline__ O8 ld8(const h16* base, int64_t idx) {
+  O8 o;
+  unpack8(reinterpret_cast<const h16x8*>(base)[idx], o.v);
+  return o;
+}
+__device__ __forceinline__ void st8(h16* base, int64_t idx, const O8& o) { reinterpret_cast<h16x8*>(base)[idx] = pack8(o.v); }
+
+// block reduction of 8 doubles per thread (256 threads) -> thread 0..7 hold the totals in red[0][k]
+__device__ __forceinline__ void block_reduce8(double (&red)[256][8], const double (&val)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = val[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- per-channel sums over planes (pads are zero: no masks)
+__global__ __launch_bounds__(256) void planes_sums_h_kernel(const h16* __restrict__ x, int CO, int64_t plane, int B, double* __restrict__ sums,
+                                                             double* __restrict__ sumsq) {
+  __shared__ double red[256][8];
+  const int co = blockIdx.y;
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
+  for (int b = 0; b < B; ++b) {
+    const int64_t base = ((int64_t)b * CO + co) * plane;
+    for (int p = p0; p < (int)plane; p += pstep) {
+      const O8 v = ld8(x, base + p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s[k] += v.v[k]; q[k] += (double)v.v[k] * v.v[k]; }
+    }
+  }
+  block_reduce8(red, s);
+  if (threadIdx.x < 8) atomicAdd(&sums[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+  __syncthreads();
+  if (sumsq) {
+    block_reduce8(red, q);
+    if (threadIdx.x < 8) atomicAdd(&sumsq[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+  }
+}
+
+__global__ void bn_finish_stats_h_kernel(const double* __restrict__ sums, const double* __restrict__ sumsq, int C, double count, float* __restrict__ mean,
+                                         float* __restrict__ var) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / count;
+  const double v = sumsq[c] / count - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(v < 0.0 ? 0.0 : v);
+}
+
+__global__ void f64_to_f32_h_kernel(const double* __restrict__ a, float* __restrict__ b, int n, int accumulate) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
+}
+
+// y = [relu](v * s + t) at interior pixels; pads of y stay zero
+__global__ __launch_bounds__(256) void bn_planes_apply_h_kernel(const h16* __restrict__ v, int C, int H, int W, int WP, int R, const float* __restrict__ mean,
+                                                                 const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, int relu, h16* __restrict__ y) {
+  const int CO = (C + 7) >> 3;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= H * W) return;
+  const int bq = blockIdx.y, co = bq % CO;
+  const int yy = pix / W, xx = pix - yy * W;
+  const int64_t off = (int64_t)bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx;
+  const O8 a = ld8(v, off);
+  O8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = co * 8 + k;
+    if (c < C) {
+      const float s = gamma[c] * rsqrtf(var[c] + eps);
+      const float r = fmaf(a.v[k], s, beta[c] - mean[c] * s);
+      o.v[k] = relu ? fmaxf(r, 0.0f) : r;
+    } else {
+      o.v[k] = 0.0f;
+    }
+  }
+  st8(y, off, o);
+}
+
+// BN backward sums over planes: dbeta[c] += sum dy_eff, dgamma[c] += sum dy_eff * xhat   (dy_eff = relu ? dy * (BN(v) > 0) : dy)
+__global__ __launch_bounds__(256) void bn_planes_bwd_sums_h_kernel(const h16* __restrict__ dy, const h16* __restrict__ v, int C, int64_t plane, int B,
+                                                                    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps, int relu, double* __restrict__ dbeta,
+                                                                    double* __restrict__ dgamma) {
+  __shared__ double red[256][8];
+  const int co = blockIdx.y, CO = (C + 7) >> 3;
+  float mu[8], inv[8], g[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = co * 8 + k, cc = c < C ? c : 0;
+    mu[k] = mean[cc]; inv[k] = rsqrtf(var[cc] + eps); g[k] = gamma[cc]; bt[k] = beta[cc];
+  }
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
+  for (int b = 0; b < B; ++b) {
+    const int64_t base = ((int64_t)b * CO + co) * plane;
+    for (int p = p0; p < (int)plane; p += pstep) {
+      const O8 d = ld8(dy, base + p), vv = ld8(v, base + p);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (vv.v[k] - mu[k]) * inv[k];
+        float de = d.v[k];
+        if (relu && !(fmaf(xh, g[k], bt[k]) > 0.0f)) de = 0.0f;
+        s[k] += (double)de;
+        q[k] += (double)de * (double)xh;
+      }
+    }
+  }
+  block_reduce8(red, s);
+  if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&dbeta[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+  __syncthreads();
+  block_reduce8(red, q);
+  if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&dgamma[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------- BN backward apply fused with the transposed pointwise conv
+// dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) (stored, f16) AND du = Wpw dv in one pass: one wave = 64 consecutive flat pixels.
+// wtf: A fragments of the TRANSPOSED pointwise weights, [KG of the conv-OUTPUT channels][MT of the conv-INPUT channels][64][8].
+template <int MT>
+__global__ __launch_bounds__(256) void bn_bwd_pw_h_kernel(const h16* dy, const h16* __restrict__ v, int C, int H, int W, int WP, int R,
+                                                           const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int relu, const double* __restrict__ dbeta,
+                                                           const double* __restrict__ dgamma, float inv_count, const h16* __restrict__ wtf, int Cin,
+                                                           h16* dv /*may alias dy*/, h16* __restrict__ du, int tasks, uint32_t magic_WP) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;
+  const int b = blockIdx.y;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int CO = (C + 7) >> 3, COi = (Cin + 7) >> 3, KG = (CO + 3) >> 2;
+  const int plane = (H + 2 * R) * WP;
+  const int qbase = R * WP + task * 64;
+  const int q = qbase + lane;
+  const int row = (int)__umulhi((uint32_t)q, magic_WP);
+  const bool live = (q - row * WP) < W && row < R + H;
+  const int qc = q < plane ? q : plane - 1;
+  const int64_t base = (int64_t)b * CO * plane + qc;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int kg = 0; kg < KG; ++kg) {
+    u32x4 d[4];
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo) {
+      const int o = kg * 4 + oo;
+      if (o < CO) {  // wave-uniform
+        const O8 dd = ld8(dy, base + (int64_t)o * plane), vv = ld8(v, base + (int64_t)o * plane);
+        O8 r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = o * 8 + k;
+          if (c < C) {
+            const float inv = rsqrtf(var[c] + eps);
+            const float xh = (vv.v[k] - mean[c]) * inv;
+            float de = dd.v[k];
+            if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+            r.v[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
+          } else {
+            r.v[k] = 0.0f;
+          }
+        }
+        const h16x8 packed = pack8(r.v);
+        if (live) reinterpret_cast<h16x8*>(dv)[base + (int64_t)o * plane] = packed;
+        d[oo] = as_u(packed);
+      } else {
+        d[oo] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    octets_to_fragments(d);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const h16x8 a = reinterpret_cast<const h16x8*>(wtf)[(kg * MT + m) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = mfma_h(a, as_h(d[t]), acc[m][t]);
+    }
+  }
+#pragma unroll
+  for (int tp = 0; tp < 4; tp += 2) {
+    const int flat = qbase + 16 * (tp + (lk & 1)) + lj;
+    const int r2 = (int)__umulhi((uint32_t)flat, magic_WP);
+    const bool ok = (flat - r2 * WP) < W && r2 < R + H;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float a[4], bq[4], o8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = acc[m][tp][r]; bq[r] = acc[m][tp + 1][r]; }
+      tiles_to_octet(a, bq, o8);
+      const int oq = 2 * m + (lk >> 1);
+      if (ok && oq < COi) reinterpret_cast<h16x8*>(du)[((int64_t)b * COi + oq) * plane + flat] = pack8(o8);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- max-pool backward (row-marching; see pool_bwd_kernel of train_trunk.hip)
+constexpr int PB_ROWS = 8;
+
+__device__ __forceinline__ O8 o8_fill(float x) {
+  O8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.v[k] = x;
+  return o;
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__ dout, const h16* __restrict__ ybn, int C, int H, int W, int WP, int R, int Ho, int Wo,
+                                                          int WPo, int pad_top, int pad_left, h16* __restrict__ dy, const float* __restrict__ bn_gamma,
+                                                          const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float bn_eps,
+                                                          double* __restrict__ bn_sums /*[2][8*CO]*/) {
+  const int CO = (C + 7) >> 3;
+  const int nchunk = (Ho + PB_ROWS - 1) / PB_ROWS;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool in_range = idx < nchunk * Wo;
+  const int j = in_range ? idx % Wo : 0;
+  const int chunk = in_range ? idx / Wo : 0;
+  const int64_t bq = blockIdx.y;
+  const int co = (int)(bq % CO);
+  float bs[8], bqs[8], bmu[8], binv[8], sgn[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = co * 8 + k, cc = c < C ? c : 0;
+    bs[k] = 0.f; bqs[k] = 0.f;
+    bmu[k] = bn_sums ? bn_mean[cc] : 0.f;
+    binv[k] = bn_sums ? rsqrtf(bn_var[cc] + bn_eps) : 0.f;
+    sgn[k] = (bn_gamma && bn_gamma[cc] < 0.f) ? -1.f : 1.f;
+  }
+  const int64_t pin = bq * ((int64_t)(H + 2 * R) * WP), pout = bq * ((int64_t)(Ho + 2 * R) * WPo);
+  const int x0 = 2 * j - pad_left, x1 = x0 + 1;
+  const bool cx0 = x0 >= 0 && x0 < W, cx1 = x1 < W;
+  auto ld = [&](int y, int x, bool cx) -> O8 {
+    if (!(cx && y >= 0 && y < H)) return o8_fill(-INFINITY);
+    O8 t = ld8(ybn, pin + (int64_t)(y + R) * WP + x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t.v[k] *= sgn[k];
+    return t;
+  };
+  auto mx8 = [](const O8& a, const O8& b) { O8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(a.v[k], b.v[k]);
+    return o; };
+  auto sel = [](const O8& v, const O8& m, const O8& d) { O8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = v.v[k] == m.v[k] ? d.v[k] : 0.f;
+    return o; };
+  auto add8 = [](const O8& a, const O8& b) { O8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = a.v[k] + b.v[k];
+    return o; };
+  auto emit = [&](int64_t pos, const O8& g, const O8& tv) {
+    // the gradient is STORED in f16: the BatchNorm sums must see the same rounded values the consumer will read
+    const h16x8 gh = pack8(g.v);
+    reinterpret_cast<h16x8*>(dy)[pin + pos] = gh;
+    if (bn_sums) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float gg = (float)gh[k];
+        bs[k] += gg;
+        bqs[k] = fmaf(gg, (tv.v[k] * sgn[k] - bmu[k]) * binv[k], bqs[k]);
+      }
+    }
+  };
+  const int i0 = chunk * PB_ROWS, i1 = in_range ? ((i0 + PB_ROWS < Ho) ? i0 + PB_ROWS : Ho) : i0;
+  const int istart = i0 > 0 ? i0 - 1 : 0;
+  O8 t0 = ld(2 * istart - pad_top, x0, cx0), t1 = ld(2 * istart - pad_top, x1, cx1);
+  O8 c0 = o8_fill(0.f), c1 = o8_fill(0.f);
+  for (int i = istart; i < i1; ++i) {
+    const int r0 = 2 * i - pad_top;
+    const O8 m0 = ld(r0 + 1, x0, cx0), m1 = ld(r0 + 1, x1, cx1);
+    const O8 b0 = ld(r0 + 2, x0, cx0), b1 = ld(r0 + 2, x1, cx1);
+    const O8 d = ld8(dout, pout + (int64_t)(i + R) * WPo + j);
+    const O8 m = mx8(mx8(mx8(t0, t1), mx8(m0, m1)), mx8(b0, b1));
+    if (i >= i0) {
+      if (r0 >= 0) {
+        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add8(c0, sel(t0, m, d)), t0);
+        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add8(c1, sel(t1, m, d)), t1);
+      }
+      if (r0 + 1 < H) {
+        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, sel(m0, m, d), m0);
+        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, sel(m1, m, d), m1);
+      }
+    }
+    c0 = sel(b0, m, d);
+    c1 = sel(b1, m, d);
+    t0 = b0;
+    t1 = b1;
+  }
+  const int rl = 2 * i1 - pad_top;
+  if (in_range && i1 == Ho && rl < H) {
+    if (cx0) emit((int64_t)(rl + R) * WP + x0, c0, t0);
+    if (cx1) emit((int64_t)(rl + R) * WP + x1, c1, t1);
+  }
+  if (bn_sums) {
+    __shared__ double red[256][8];
+    double a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (double)bs[k];
+    block_reduce8(red, a);
+    if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&bn_sums[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (double)bqs[k];
+    block_reduce8(red, a);
+    if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&bn_sums[8 * CO + co * 8 + threadIdx.x], red[0][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------- D[ca][cb] += sum_pixels A[ca][p] * Bq[cb][p]   (pointwise / residual weight gradients)
+// 256 pixels per pass go through LDS as [channel][pixel] f16 (pitch 264 halves = 132 dwords = 4 mod 64: the 16 channel rows of a
+// fragment read hit 16 distinct 16-byte bank slots), so that a lane's 16-byte LDS read is 8 consecutive PIXELS of one channel = one
+// operand fragment of v_mfma_f32_16x16x32_f16 with k = pixel.  Per-workgroup partial products + an add kernel (train_trunk.hip).
+constexpr int ORH_P = 264;
+
+__global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restrict__ A, int Ca, const h16* __restrict__ Bq, int Cb, int H, int W, int WP, int R, int B,
+                                                              int a_mode, int Ha, int WPa, float* __restrict__ part, uint32_t magic_WP) {
+  extern __shared__ __attribute__((aligned(16))) h16 smem_h[];
+  const int COa = (Ca + 7) >> 3, COb = (Cb + 7) >> 3;
+  const int MT = (Ca + 15) >> 4, NT = (Cb + 15) >> 4, ntile = MT * NT;
+  h16* As = smem_h;                      // [MT*16][ORH_P]
+  h16* Bs = smem_h + MT * 16 * ORH_P;    // [NT*16][ORH_P]
+  for (int i = threadIdx.x; i < (MT + NT) * 16 * ORH_P / 2; i += 256) reinterpret_cast<uint32_t*>(smem_h)[i] = 0u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int64_t plane_a = a_mode ? (int64_t)(Ha + 2 * R) * WPa : plane;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int chunks_per_plane = (plane + 255) >> 8;
+  const int64_t nchunks = (int64_t)B * chunks_per_plane;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t b = ch / chunks_per_plane;
+    const int p = (int)(ch - b * chunks_per_plane) * 256 + tid;
+    const bool pin = p < plane;
+    int pa = p;
+    bool ain = pin;
+    if (a_mode) {
+      const int row = (int)__umulhi((uint32_t)(pin ? p : 0), magic_WP);
+      const int x = p - row * WP, i = row - R;
+      ain = pin && i >= 0 && i < H && x < W;
+      pa = ain ? (2 * i + R) * WPa + 2 * x : 0;
+    }
+    __syncthreads();  // the previous pass's MFMA reads are done (and the zero fill is visible)
+    for (int q = 0; q < COa; ++q) {
+      const h16x8 v = ain ? reinterpret_cast<const h16x8*>(A)[((int64_t)b * COa + q) * plane_a + pa] : zero_h();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) As[(8 * q + e) * ORH_P + tid] = v[e];
+    }
+    for (int q = 0; q < COb; ++q) {
+      const h16x8 v = pin ? reinterpret_cast<const h16x8*>(Bq)[((int64_t)b * COb + q) * plane + p] : zero_h();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bs[(8 * q + e) * ORH_P + tid] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int tile = wave + 4 * ti;
+      if (tile < ntile) {  // wave-uniform
+        const int mt = tile / NT, nt = tile - mt * NT;
+        const h16* ar = As + (mt * 16 + lj) * ORH_P + 8 * lk;  // A[row = ca][k = pixel 8 lk + e]
+        const h16* br = Bs + (nt * 16 + lj) * ORH_P + 8 * lk;  // B[k = pixel][col = cb]
+        f32x4 c0 = acc[ti];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) c0 = mfma_h(*reinterpret_cast<const h16x8*>(ar + 32 * s), *reinterpret_cast<const h16x8*>(br + 32 * s), c0);
+        acc[ti] = c0;
+      }
+    }
+  }
+  float* mine = part + (int64_t)blockIdx.x * Ca * Cb;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int tile = wave + 4 * ti;
+    if (tile < ntile) {
+      const int mt = tile / NT, nt = tile - mt * NT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
+        if (ca < Ca && cb < Cb) mine[ca * Cb + cb] = acc[ti][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_partials_h_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ D) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int per = (nparts + gridDim.y - 1) / gridDim.y;
+  const int k0 = blockIdx.y * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
+  float s = 0.f;
+  for (int k = k0; k < k1; ++k) s += part[(int64_t)k * n + i];
+  if (k1 > k0) atomicAdd(&D[i], s);
+}
+
+// ---------------------------------------------------------------- depthwise weight gradient
+// dW[tap][c] += sum_p r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x.  One block handles ONE HALF of an octet (4 channels:
+// 4 x k x k f32 accumulators per lane), one wave = 64-pixel windows, lanes R..63-R contribute; wave + block reduction, then atomics.
+template <int SH>
+__device__ __forceinline__ float lshf(float v) {
+  return __uint_as_float(lane_shift_u<SH>(__float_as_uint(v)));
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__ x, const h16* __restrict__ du, int C, int H, int W, int WP, int RP, int relu_in,
+                                                          float* __restrict__ dW /*[KS*KS][C]*/, int tasks, int tasks_per_wave) {
+  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int co = blockIdx.y >> 1, half = blockIdx.y & 1, b = blockIdx.z;
+  const int CO = (C + 7) >> 3;
+  const int plane = (H + 2 * RP) * WP;
+  const int64_t base = ((int64_t)b * CO + co) * plane;
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const bool contributes = lane >= R && lane < 64 - R;
+  for (int task = wv * tasks_per_wave; task < (wv + 1) * tasks_per_wave && task < tasks; ++task) {
+    const int q = RP * WP + task * VAL - R + lane;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (contributes && q < plane) {
+      const O8 g8 = ld8(du, base + q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = g8.v[4 * half + j];
+    }
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      int i = q + (dy - R) * WP;
+      i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+      const O8 a8 = ld8(x, base + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = a8.v[4 * half + j];
+        if (relu_in) a = fmaxf(a, 0.0f);
+        if constexpr (KS == 3) {
+          acc[j][dy * 3 + 0] = fmaf(lshf<-1>(a), g[j], acc[j][dy * 3 + 0]);
+          acc[j][dy * 3 + 1] = fmaf(a, g[j], acc[j][dy * 3 + 1]);
+          acc[j][dy * 3 + 2] = fmaf(lshf<1>(a), g[j], acc[j][dy * 3 + 2]);
+        } else if constexpr (KS == 5) {
+          acc[j][dy * 5 + 0] = fmaf(lshf<-2>(a), g[j], acc[j][dy * 5 + 0]);
+          acc[j][dy * 5 + 1] = fmaf(lshf<-1>(a), g[j], acc[j][dy * 5 + 1]);
+          acc[j][dy * 5 + 2] = fmaf(a, g[j], acc[j][dy * 5 + 2]);
+          acc[j][dy * 5 + 3] = fmaf(lshf<1>(a), g[j], acc[j][dy * 5 + 3]);
+          acc[j][dy * 5 + 4] = fmaf(lshf<2>(a), g[j], acc[j][dy * 5 + 4]);
+        } else {
+          acc[j][dy * 7 + 0] = fmaf(lshf<-3>(a), g[j], acc[j][dy * 7 + 0]);
+          acc[j][dy * 7 + 1] = fmaf(lshf<-2>(a), g[j], acc[j][dy * 7 + 1]);
+          acc[j][dy * 7 + 2] = fmaf(lshf<-1>(a), g[j], acc[j][dy * 7 + 2]);
+          acc[j][dy * 7 + 3] = fmaf(a, g[j], acc[j][dy * 7 + 3]);
+          acc[j][dy * 7 + 4] = fmaf(lshf<1>(a), g[j], acc[j][dy * 7 + 4]);
+          acc[j][dy * 7 + 5] = fmaf(lshf<2>(a), g[j], acc[j][dy * 7 + 5]);
+          acc[j][dy * 7 + 6] = fmaf(lshf<3>(a), g[j], acc[j][dy * 7 + 6]);
+        }
+      }
+    }
+  }
+  __shared__ float red[4][4 * KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
+    const int c = co * 8 + 4 * half + j;
+    if (c < C) atomicAdd(&dW[t * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------- entry conv weight gradient with bn0 (+ReLU) backward on the fly
+// dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) is formed per pixel from (dy, v, sums) and consumed at once (never written).
+// Block (bx, cq): quad cq of the 16 entry channels = half (cq & 1) of octet (cq >> 1).
+template <int KS>
+__global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __restrict__ in, int64_t snippet_stride, const h16* __restrict__ dy,
+                                                                const h16* __restrict__ v /*[B][2][HP][WP][8]*/, int H, int W, int WP, int B,
+                                                                const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, const double* __restrict__ dbeta,
+                                                                const double* __restrict__ dgamma, float inv_count, float* __restrict__ dW /*[KS*KS][16]*/) {
+  constexpr int R = KS / 2, KK = KS * KS;
+  __shared__ float red[4][4 * KK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = blockIdx.y, co = cq >> 1, half = cq & 1;
+  const int plane = (H + 2 * R) * WP;
+  float mu[4], inv[4], g[4], bt[4], c1[4], c2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;
+    mu[k] = mean[c]; inv[k] = rsqrtf(var[c] + eps); g[k] = gamma[c]; bt[k] = beta[c];
+    c1[k] = (float)dbeta[c] * inv_count; c2[k] = (float)dgamma[c] * inv_count;
+  }
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const int total = H * W;
+  for (int b = 0; b < B; ++b) {
+    const float* src = in + (int64_t)b * snippet_stride;
+    const int64_t base = ((int64_t)b * 2 + co) * plane;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+      const int y = p / W, x = p - y * W;
+      const O8 d8 = ld8(dy, base + (y + R) * WP + x), v8 = ld8(v, base + (y + R) * WP + x);
+      float gq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (v8.v[4 * half + k] - mu[k]) * inv[k];
+        const float de = (fmaf(xh, g[k], bt[k]) > 0.0f) ? d8.v[4 * half + k] : 0.0f;
+        gq[k] = g[k] * inv[k] * (de - c1[k] - xh * c2[k]);
+      }
+#pragma unroll
+      for (int dyy = 0; dyy < KS; ++dyy)
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx) {
+          const int yy = y + dyy - R, xx = x + dx - R;
+          const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[yy * W + xx] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][dyy * KS + dx] = fmaf(a, gq[j], acc[j][dyy * KS + dx]);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float s2 = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+      if (lane == 0) red[wave][j * KK + t] = s2;
+    }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
+    atomicAdd(&dW[t * 16 + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------- f16 kernel-layout copies of the f32 master weights, one launch per step
+// desc[i] = {type, src offset (floats), dst offset (halves), C, aux}:
+//   0  Keras depthwise (k,k,C,1)  -> [ceil(C/8)][k*k][8]                       aux = k*k
+//   1  the same with the taps reversed (input-gradient convolution)
+//   2  pointwise / residual (1,1,Cin,Cout) -> A fragments [KG(Cin)][MT(Cout)][64][8]       C = Cin, aux = Cout   (forward)
+//   3  its transpose -> A fragments [KG(Cout)][MT(Cin)][64][8] with row = cin, k = cout     C = Cin, aux = Cout   (input gradient)
+//   4  identity matrix of C channels as A fragments [KG(C)][MT(C)][64][8] (depthwise-only passes); src unused
+//   5  all-ones depthwise taps [ceil(C/8)][1][8] (pointwise-only passes); src unused
+__global__ __launch_bounds__(256) void pack_weights_h_kernel(const float* __restrict__ w, const int* __restrict__ desc, h16* __restrict__ out) {
+  const int* d = desc + blockIdx.x * 5;
+  const int type = d[0], C = d[3], aux = d[4];
+  const float* src = w + d[1];
+  h16* dst = out + d[2];
+  if (type <= 1) {
+    const int KK = aux, CO = (C + 7) >> 3;
+    for (int i = threadIdx.x; i < CO * KK * 8; i += 256) {
+      const int e = i & 7, tap = (i >> 3) % KK, co = (i >> 3) / KK;
+      const int c = co * 8 + e, ts = type ? KK - 1 - tap : tap;
+      dst[i] = (h16)(c < C ? src[ts * C + c] : 0.0f);
+    }
+  } else if (type == 5) {
+    const int CO = (C + 7) >> 3;
+    for (int i = threadIdx.x; i < CO * 8; i += 256) dst[i] = (h16)(i < C ? 1.0f : 0.0f);
+  } else {
+    const int Cin = C, Cout = (type == 4) ? C : aux;
+    const int Kc = (type == 3) ? Cout : Cin;   // contraction (k) channels
+    const int Rc = (type == 3) ? Cin : Cout;   // row (output) channels
+    const int KG = (Kc + 31) >> 5, MT = (Rc + 15) >> 4;
+    for (int i = threadIdx.x; i < KG * MT * 512; i += 256) {
+      const int e = i & 7, lane = (i >> 3) & 63, m = (i >> 9) % MT, kg = (i >> 9) / MT;
+      const int kc = 32 * kg + 8 * (lane >> 4) + e, rc = 16 * m + (lane & 15);
+      float v = 0.0f;
+      if (kc < Kc && rc < Rc) v = (type == 4) ? (kc == rc ? 1.0f : 0.0f) : (type == 2 ? src[kc * Cout + rc] : src[rc * Cout + kc]);
+      dst[i] = (h16)v;
+    }
+  }
+}
+
+// Keras Reshape layout f32 [B][H][W*C] -> f16 octet planes (gradient of the final conv's output)
+__global__ __launch_bounds__(256) void feat_to_planes_h_kernel(const float* __restrict__ f, int C, int H, int W, int WP, int R, h16* __restrict__ out, int B) {
+  const int CO = (C + 7) >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t interior = (int64_t)H * W;
+  if (idx >= (int64_t)B * CO * interior) return;
+  const int64_t bq = idx / interior, pix = idx - bq * interior;
+  const int co = (int)(bq % CO);
+  const int64_t b = bq / CO;
+  const int yy = (int)(pix / W), xx = (int)(pix - (int64_t)yy * W);
+  const float* src = f + ((b * H + yy) * (int64_t)W + xx) * C + co * 8;
+  O8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o.v[k] = (co * 8 + k < C) ? src[k] : 0.0f;
+  st8(out, bq * ((int64_t)(H + 2 * R) * WP) + (int64_t)(yy + R) * WP + xx, o);
+}
+
+// dx = (y > 0) ? dy : 0 on whole plane buffers
+__global__ __launch_bounds__(256) void relu_bwd_h_kernel(const h16x8* __restrict__ dy, const h16x8* __restrict__ y, int64_t n8, h16x8* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const h16x8 d = dy[i], v = y[i];
+  h16x8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = v[k] > (h16)0 ? d[k] : (h16)0;
+  dx[i] = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize, double* scratch2C, float* mean, float* var, void* stream) {
+  if (!v || !scratch2C || !mean || !var || B <= 0 || C <= 0 || C > 64) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(planes_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)v, CO, plane, B, scratch2C, scratch2C + 8 * CO);
+  hipLaunchKernelGGL(bn_finish_stats_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, scratch2C + 8 * CO, C, (double)B * H * W, mean, var);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_planes_sum(const void* x, int B, int C, int H, int W, int ksize, double* scratchC, float* out, int accumulate, void* stream) {
+  if (!x || !scratchC || !out || B <= 0 || C <= 0 || C > 64) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 8 * CO, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(planes_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)x, CO, plane, B, scratchC, (double*)nullptr);
+  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratchC, out, C, accumulate);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_bn_planes_apply(const void* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, int relu, void* y, void* stream) {
+  if (!v || !y || !mean || !var || !gamma || !beta || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  const int64_t bq = (int64_t)B * ((C + 7) / 8);
+  if (bq > 65535 || (int64_t)H * W >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_planes_apply_h_kernel, dim3(blocks_for((int64_t)H * W), (unsigned)bq), dim3(256), 0, (hipStream_t)stream, (const h16*)v, C, H, W,
+                     orcai_padded_width(W, ksize), ksize / 2, mean, var, gamma, beta, eps, relu, (h16*)y);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
+                             const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma, const void* wtf, int Cin,
+                             void* dv, void* du, void* stream) {
+  if (!dy || !v || !dv || !du || !wtf || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0 || Cin <= 0 || C > 64 || Cin > 64) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  double* db = scratch2C;
+  double* dg = scratch2C + 8 * CO;
+  if (!sums_ready) {
+    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+    if (e != hipSuccess) return (int)e;
+    int gx = (int)((B * plane + 255) / 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  }
+  const int tasks = (H * WP + 63) / 64;
+  dim3 grid((tasks + 3) / 4, B);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+#define ORCAI_HBBP(MT_)                                                                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_pw_h_kernel<MT_>), grid, dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg, \
+                     inv_count, (const h16*)wtf, Cin, (h16*)dv, (h16*)du, tasks, magic_for(WP))
+  switch ((Cin + 15) / 16) {
+    case 1: ORCAI_HBBP(1); break;
+    case 2: ORCAI_HBBP(2); break;
+    case 3: ORCAI_HBBP(3); break;
+    case 4: ORCAI_HBBP(4); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_HBBP
+  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                        const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
+  if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0 || C > 64) return ORCAI_E_BADARG;
+  if (bn_sums && (!bn_gamma || !bn_mean || !bn_var)) return ORCAI_E_BADARG;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
+  if (tot_h < 0) tot_h = 0;
+  if (tot_w < 0) tot_w = 0;
+  const int CO = (C + 7) / 8;
+  if ((int64_t)B * CO > 65535) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (bn_sums) {
+    hipError_t e = hipMemsetAsync(bn_sums, 0, sizeof(double) * 16 * CO, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
+  dim3 grid((per_bq + 255) / 256, (unsigned)(B * CO));
+  hipLaunchKernelGGL(pool_bwd_h_kernel, grid, dim3(256), 0, st, (const h16*)dout, (const h16*)ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, (h16*)dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, float* workspace,
+                         int64_t workspace_floats, void* stream) {
+  if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0 || workspace_floats < (int64_t)Ca * Cb) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
+  const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * ORH_P * sizeof(h16);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)outer_reduce_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 30)) return ORCAI_E_UNSUPPORTED;
+  const int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
+  int64_t grid = nchunks < 512 ? nchunks : 512;
+  if (grid * Ca * Cb > workspace_floats) grid = workspace_floats / ((int64_t)Ca * Cb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(outer_reduce_h_kernel, dim3((unsigned)grid), dim3(256), lds, st, (const h16*)A, Ca, (const h16*)Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
+                     a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
+  hipLaunchKernelGGL(add_partials_h_kernel, dim3(blocks_for((int64_t)Ca * Cb), 8), dim3(256), 0, st, workspace, (int)grid, Ca * Cb, D);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {
+  if (!x || !du || !dW || B <= 0 || C <= 0 || C > 64 || B > 65535) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
+  const int VAL = 64 - 2 * (ktap / 2);
+  const int tasks = (H * WP + VAL - 1) / VAL;
+  int tpw = (tasks + 7) / 8;
+  if (tpw < 8) tpw = 8;
+  dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, 2 * ((C + 7) / 8), B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (ktap) {
+    case 3: hipLaunchKernelGGL(dw_wgrad_h_kernel<3>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 5: hipLaunchKernelGGL(dw_wgrad_h_kernel<5>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 7: hipLaunchKernelGGL(dw_wgrad_h_kernel<7>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                         const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream) {
+  if (!in || !dy || !v || !dW || !scratch2C || !dbeta || !dgamma || B <= 0) return ORCAI_E_BADARG;
+  if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = 16, CO = 2, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((B * plane + 255) / 256);
+  if (gx > 128) gx = 128;
+  double* db = scratch2C;
+  double* dg = scratch2C + 8 * CO;
+  hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, 1, db, dg);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+  dim3 grid(256, 4);
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 5: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 7: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3(1), dim3(64), 0, st, dg, dgamma, C, 0);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_pack_weights(const float* w, const int* desc, int n_desc, void* out, void* stream) {
+  if (!w || !desc || !out || n_desc <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(pack_weights_h_kernel, dim3(n_desc), dim3(256), 0, (hipStream_t)stream, w, desc, (h16*)out);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, void* out, void* stream) {
+  if (!f || !out || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  const int64_t n = (int64_t)B * ((C + 7) / 8) * H * W;
+  hipLaunchKernelGGL(feat_to_planes_h_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, f, C, H, W, orcai_padded_width(W, ksize), ksize / 2, (h16*)out, B);
+  return (int)hipGetLastError();
+}
+
+int orcai_h_planes_relu_bwd(const void* dy, const void* y, int64_t n_halves, void* dx, void* stream) {
+  if (!dy || !y || !dx || n_halves <= 0 || (n_halves & 7)) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(relu_bwd_h_kernel, dim3(blocks_for(n_halves / 8)), dim3(256), 0, (hipStream_t)stream, (const h16x8*)dy, (const h16x8*)y, n_halves / 8, (h16x8*)dx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

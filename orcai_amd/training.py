@@ -68,13 +68,26 @@ class HeadTrainer:
     """Training forward / backward of everything after the convolutional trunk: BN+ReLU of the final separable conv
     (Keras Reshape layout), two BiLSTM layers with dropout, Dense-128 + BN + dropout, Dense-labels + sigmoid, loss."""
 
-    def __init__(self, model: ResNetLSTM, params: FlatParams):
+    def __init__(self, model: ResNetLSTM, params: FlatParams, half: bool = False, grad_scale: float = 1.0):
         self.model, self.P = model, params
         self.lib = N.lib()
         self.u = model.lstm_units
         self.perm = torch.from_numpy(lstm_column_permutation(self.u)).to(params.w.device)
         self.inv_perm = torch.argsort(self.perm)
         self.cache = None
+        # half: the forward GEMMs (LSTM input projections, Dense-128) run on f16 MFMA with f32 accumulation (orcai_h_gemm_bias_act);
+        # the backward GEMMs stay on the f32 kernels.  grad_scale: static loss scale carried by every gradient (undone in Adam).
+        self.half, self.grad_scale = bool(half), float(grad_scale)
+
+    def _gemm_fwd(self, x, W, bias, out, M, Nn, K, act):
+        """out = act(x W + bias): f32 MFMA, or (half) f16 MFMA on a transposed, zero-padded f16 copy of W made here."""
+        st = N.stream_ptr()
+        if not self.half:
+            N.check(self.lib.orcai_gemm_bias_act(x.data_ptr(), W.data_ptr(), bias.data_ptr(), None, None, out.data_ptr(), M, Nn, K, act, st), "gemm")
+            return
+        Wt = torch.zeros((Nn, (K + 31) // 32 * 32), dtype=torch.float16, device=W.device)
+        Wt[:, :K] = W.t()
+        N.check(self.lib.orcai_h_gemm_bias_act(x.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, None, out.data_ptr(), M, Nn, K, act, st), "h_gemm")
 
     # -- kernel-layout LSTM weights from the flat master copy (tiny device-side index ops)
     def _lstm_weights(self, layer):
@@ -105,7 +118,7 @@ class HeadTrainer:
         for layer in (1, 2):
             Wc, bc, Uc = self._lstm_weights(layer)
             xz = torch.empty((n, T, 2, 4 * u), **f32)
-            N.check(lib.orcai_gemm_bias_act(x.data_ptr(), Wc.data_ptr(), bc.data_ptr(), None, None, xz.data_ptr(), M, 8 * u, fin, 0, st), "gemm")
+            self._gemm_fwd(x, Wc, bc, xz, M, 8 * u, fin, 0)
             h = torch.empty((n, T, 2 * u), **f32)
             gates = torch.empty((n, T, 2, 4 * u), **f32)
             cs = torch.empty((n, T, 2, u), **f32)
@@ -119,8 +132,7 @@ class HeadTrainer:
             x, fin = hd, 2 * u
         c["h2d"] = x
         pre1 = torch.empty((n, T, DENSE_UNITS), **f32)
-        N.check(lib.orcai_gemm_bias_act(x.data_ptr(), P.W("dense1/kernel").data_ptr(), P.W("dense1/bias").data_ptr(), None, None, pre1.data_ptr(), M, DENSE_UNITS,
-                                        2 * u, 1, st), "gemm")
+        self._gemm_fwd(x, P.W("dense1/kernel"), P.W("dense1/bias"), pre1, M, DENSE_UNITS, 2 * u, 1)
         c["pre1"] = pre1
         c["d_mean"], c["d_var"] = torch.empty(DENSE_UNITS, **f32), torch.empty(DENSE_UNITS, **f32)
         N.check(lib.orcai_bn_rows_stats(pre1.data_ptr(), M, DENSE_UNITS, DENSE_UNITS, c["d_mean"].data_ptr(), c["d_var"].data_ptr(), st), "bn_rows_stats")
@@ -164,7 +176,8 @@ class HeadTrainer:
         acc = torch.zeros(4, dtype=torch.float64, device=dev)  # bce sum, count, correct, l2
         dz2 = torch.empty((M, L), **f32)
         N.check(lib.orcai_masked_bce_w(c["probs"].data_ptr(), labels.contiguous().data_ptr(), M * L, MASK_VALUE, acc.data_ptr(), dz2.data_ptr(),
-                                       None if loss_weight is None else loss_weight.data_ptr(), 1.0, st), "masked_bce")
+                                       None if loss_weight is None else loss_weight.data_ptr(), self.grad_scale, st), "masked_bce")
+        l2g = 2 * L2_LAMBDA * self.grad_scale  # the regularisers' gradients join loss-scaled gradients
         # Dense(labels): dW2 = d1d^T dz2, db2 = colsum(dz2), dd1d = dz2 W2^T
         _gemm(lib, c["d1d"], 1, DENSE_UNITS, dz2, L, 1, P.G("dense2/kernel"), DENSE_UNITS, L, M)
         N.check(lib.orcai_colsum(dz2.data_ptr(), M, L, P.G("dense2/bias").data_ptr(), 0, st), "colsum")
@@ -179,7 +192,7 @@ class HeadTrainer:
                                       dpre.data_ptr(), st), "bn_rows_bwd")
         N.check(lib.orcai_relu_bwd(dpre.data_ptr(), c["pre1"].data_ptr(), dpre.numel(), dpre.data_ptr(), st), "relu_bwd")
         # Dense-128: dW1 = h2d^T dpre + 2 lambda W1, db1, dh2d = dpre W1^T
-        _gemm(lib, c["h2d"], 1, 2 * u, dpre, DENSE_UNITS, 1, P.G("dense1/kernel"), 2 * u, DENSE_UNITS, M, wreg=P.W("dense1/kernel"), beta_w=2 * L2_LAMBDA)
+        _gemm(lib, c["h2d"], 1, 2 * u, dpre, DENSE_UNITS, 1, P.G("dense1/kernel"), 2 * u, DENSE_UNITS, M, wreg=P.W("dense1/kernel"), beta_w=l2g)
         N.check(lib.orcai_colsum(dpre.data_ptr(), M, DENSE_UNITS, P.G("dense1/bias").data_ptr(), 0, st), "colsum")
         N.check(lib.orcai_l2_value(P.W("dense1/kernel").data_ptr(), P.W("dense1/kernel").numel(), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_value")
         dh = torch.empty((M, 2 * u), **f32)
@@ -203,7 +216,7 @@ class HeadTrainer:
                 _gemm(lib, hp.view(-1)[d * u :], 1, 2 * u, dxz.view(-1)[d * 4 * u :], 8 * u, 1, dU, u, 4 * u, M)
                 P.G(f"lstm{layer}/{name}/recurrent").copy_(dU[:, self.inv_perm])
                 Wk = P.W(f"lstm{layer}/{name}/kernel")
-                P.G(f"lstm{layer}/{name}/kernel").copy_(dWc[:, d * 4 * u : (d + 1) * 4 * u][:, self.inv_perm] + 2 * L2_LAMBDA * Wk)
+                P.G(f"lstm{layer}/{name}/kernel").copy_(dWc[:, d * 4 * u : (d + 1) * 4 * u][:, self.inv_perm] + l2g * Wk)
                 P.G(f"lstm{layer}/{name}/bias").copy_(dbc[d * 4 * u : (d + 1) * 4 * u][self.inv_perm])
                 N.check(lib.orcai_l2_value(Wk.data_ptr(), Wk.numel(), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_value")
             dx = torch.empty((M, fin), **f32)
@@ -294,7 +307,7 @@ class TrunkTrainer:
     re-materialised for the pointwise weight gradient, and depthwise-only / pointwise-only passes reuse the
     separable-conv kernel with identity factors)."""
 
-    def __init__(self, model: ResNetLSTM, params: FlatParams):
+    def __init__(self, model: ResNetLSTM, params: FlatParams, half: bool = False):
         self.model, self.P = model, params
         self.lib = N.lib()
         self.k = model.kernel_size
@@ -303,6 +316,13 @@ class TrunkTrainer:
         self.buf = {}
         self.B = None
         self.consts = {}
+        # half: activations and activation gradients as f16 channel-octet planes, contractions on f16 MFMA (csrc/half_fwd.hip,
+        # half_bwd.hip); the launchers have the f32 path's signatures, only the weight operands differ (f16 copies packed once per step)
+        self.half = bool(half)
+        self.G = 8 if self.half else 4  # channels per 16-byte pixel vector
+        self.adt = torch.float16 if self.half else torch.float32
+        if self.half and getattr(model, "architecture", "") != "ResNetLSTM":
+            raise NotImplementedError("the f16 path implements ResNetLSTM only")
         self.scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad, <= 64 channels
         # ResNet1DConv drops out the output of every residual block (architectures.py:97); ResNetLSTM has no Dropout in the trunk
         self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
@@ -311,7 +331,31 @@ class TrunkTrainer:
 
     # ------------------------------------------------------------- helpers
     def _planes(self, B, c, h, w):
-        return torch.zeros((B, (c + 3) // 4, h + 2 * self.R, self.model.padded_width(w), 4), dtype=torch.float32, device=self.dev)
+        G = self.G
+        return torch.zeros((B, (c + G - 1) // G, h + 2 * self.R, self.model.padded_width(w), G), dtype=self.adt, device=self.dev)
+
+    def _fn(self, name):
+        """C-ABI launcher `orcai_<name>` (f32 quad planes) or its f16 octet-plane twin `orcai_h_<name>` (same argument list)."""
+        if self.half:
+            name = {"sepconv_planes_u": "sepconv", "pool_res_add_bn": "pool_res_add"}.get(name, name)
+            return getattr(self.lib, "orcai_h_" + name)
+        return getattr(self.lib, "orcai_" + name)
+
+    # weight operands of the trunk kernels: f32 master views / packed f32 copies, or packed f16 copies (half)
+    def _w_dw(self, name, reverse=False):
+        return self._packed(1 if reverse else 0, name + "/depthwise", (-1,))
+
+    def _w_pw(self, name):  # forward contraction operand of a pointwise / residual kernel [Cin][Cout]
+        return self._packed(2, name, (-1,)) if self.half else self.P.W(name)
+
+    def _w_pwT(self, name, cin, cout):  # input-gradient operand
+        return self._packed(3, name, (-1,)) if self.half else self._packed(2, name, (cout, cin))
+
+    def _w_eye(self, c):
+        return self._packed(4, f"eye{c}", (-1,)) if self.half else self._eye(c)
+
+    def _w_ones_dw(self, c):
+        return self._packed(5, f"ones{c}", (-1,)) if self.half else self._ones(4 * ((c + 3) // 4))
 
     def _const(self, key, make):
         if key not in self.consts:
@@ -328,7 +372,7 @@ class TrunkTrainer:
         return self._const(("eye", c), lambda: torch.eye(c, dtype=torch.float32, device=self.dev).contiguous())
 
     def _sep(self, x, Cin, H, W, ktap, relu_in, dw, pw, shift, Cout, out, layout=0, H2=0, W2=0, u_out=None):
-        N.check(self.lib.orcai_sepconv_planes_u(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
+        N.check(self._fn("sepconv_planes_u")(x.data_ptr(), self.B, Cin, H, W, self.k, ktap, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(),
                                                 shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), None if u_out is None else u_out.data_ptr(),
                                                 N.stream_ptr()), "orcai_sepconv_planes_u")
 
@@ -337,12 +381,12 @@ class TrunkTrainer:
         lib, P, st = self.lib, self.P, N.stream_ptr()
         mean = torch.empty(C, dtype=torch.float32, device=self.dev)
         var = torch.empty(C, dtype=torch.float32, device=self.dev)
-        N.check(lib.orcai_bn_planes_stats(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
+        N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
         self.stats[bn] = (mean, var)
         if y is None:
             return
-        N.check(lib.orcai_bn_planes_apply(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
-                                          P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), st), "bn_planes_apply")
+        N.check(self._fn("bn_planes_apply")(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), st), "bn_planes_apply")
         self.stats[bn] = (mean, var)
 
     def _bn_bwd(self, dy, v, bn, C, H, W, relu, dv):
@@ -380,31 +424,50 @@ class TrunkTrainer:
         self._build_pack_table()
 
     def _build_pack_table(self):
-        """Descriptor table for orcai_pack_weights: depthwise taps (forward and reversed) and transposed pointwise / residual
-        weights of every layer, as views into one packed buffer refreshed once per step."""
+        """Descriptor table for orcai_pack_weights / orcai_h_pack_weights: kernel-layout copies of every trunk weight as views into
+        one packed buffer refreshed once per step.  f32: depthwise taps (forward / reversed) and transposed pointwise / residual
+        matrices.  f16 (half): depthwise octets (forward / reversed), A fragments of every pointwise / residual matrix and of its
+        transpose, identity fragments and all-ones taps for the depthwise-only / pointwise-only passes."""
         P, m, k = self.P, self.model, self.k
         desc, self.packed_views, off = [], {}, 0
+        align = 8 if self.half else 4  # keep every view 16-byte aligned
 
-        def add(kind, name, C, aux, numel):
+        def add(kind, key, src_name, C, aux, numel):
             nonlocal off
-            desc.append([kind, P.offsets[name][0], off, C, aux])
-            self.packed_views[(kind, name)] = (off, numel)
-            off += (numel + 3) & ~3  # keep every view 16-byte aligned
+            desc.append([kind, P.offsets[src_name][0] if src_name else 0, off, C, aux])
+            self.packed_views[(kind, key)] = (off, numel)
+            off += (numel + align - 1) // align * align
+
+        def frag(ck, cr):  # halves of an A-fragment array: contraction channels ck, row channels cr
+            return ((ck + 31) // 32) * ((cr + 15) // 16) * 512
 
         names = []
         c = 16
         for i, f in enumerate(m.filters, start=1):
             names += [(f"b{i}/sep_a", c, f), (f"b{i}/sep_b", f, f)]
-            add(2, f"b{i}/res/kernel", c, f, c * f)
+            if self.half:
+                add(2, f"b{i}/res/kernel", f"b{i}/res/kernel", c, f, frag(c, f))
+                add(3, f"b{i}/res/kernel", f"b{i}/res/kernel", c, f, frag(f, c))
+            else:
+                add(2, f"b{i}/res/kernel", f"b{i}/res/kernel", c, f, c * f)
             c = f
         names.append(("sep_f", c, FINAL_FILTERS))
         for name, cin, cout in names:
-            cq4 = 4 * ((cin + 3) // 4)
-            add(0, name + "/depthwise", cin, k * k, cq4 * k * k)
-            add(1, name + "/depthwise", cin, k * k, cq4 * k * k)
-            add(2, name + "/pointwise", cin, cout, cin * cout)
+            G = self.G
+            cpad = G * ((cin + G - 1) // G)
+            add(0, name + "/depthwise", name + "/depthwise", cin, k * k, cpad * k * k)
+            add(1, name + "/depthwise", name + "/depthwise", cin, k * k, cpad * k * k)
+            if self.half:
+                add(2, name + "/pointwise", name + "/pointwise", cin, cout, frag(cin, cout))
+                add(3, name + "/pointwise", name + "/pointwise", cin, cout, frag(cout, cin))
+            else:
+                add(2, name + "/pointwise", name + "/pointwise", cin, cout, cin * cout)
+        if self.half:
+            for ch in sorted({16, FINAL_FILTERS, *m.filters}):
+                add(4, f"eye{ch}", None, ch, 0, frag(ch, ch))
+                add(5, f"ones{ch}", None, ch, 0, 8 * ((ch + 7) // 8))
         self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=self.dev).contiguous()
-        self.packed = torch.empty(off, dtype=torch.float32, device=self.dev)
+        self.packed = torch.empty(off, dtype=self.adt, device=self.dev)
 
     def _packed(self, kind, name, shape):
         o, n = self.packed_views[(kind, name)]
@@ -418,12 +481,12 @@ class TrunkTrainer:
         lib, P, m, b, st = self.lib, self.P, self.model, self.buf, N.stream_ptr()
         self.stats = {}
         self.src, self.snippet_stride = src, snippet_stride
-        N.check(lib.orcai_pack_weights(P.w.data_ptr(), self.pack_desc.data_ptr(), int(self.pack_desc.shape[0]), self.packed.data_ptr(), st), "pack_weights")
+        N.check(self._fn("pack_weights")(P.w.data_ptr(), self.pack_desc.data_ptr(), int(self.pack_desc.shape[0]), self.packed.data_ptr(), st), "pack_weights")
         H, W = m.input_hw
         k = self.k
         shapes = m.stage_shapes()
-        N.check(lib.orcai_conv0_affine(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
-                                       0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
+        N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                         0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
         self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
         prev, c = b["y0"], 16
         res_in = prev
@@ -434,15 +497,15 @@ class TrunkTrainer:
             self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
             for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], None, 0)):
                 name = f"b{i}/sep_{tag}"
-                self.dwl[name] = self._packed(0, name + "/depthwise", (-1,))
-                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], P.W(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
+                self.dwl[name] = self._w_dw(name)
+                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
                 # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
                 self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None)
             # the residual branch reads the block input BEFORE the previous block's Dropout (architectures.py:88-97)
             bmean, bvar = self.stats[f"b{i}/bn_b"]
-            N.check(lib.orcai_pool_res_add_bn(b[f"vb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, P.W(f"b{i}/res/kernel").data_ptr(),
-                                              P.W(f"b{i}/res/bias").data_ptr(), b[f"prev{i}"].data_ptr(), 0, bmean.data_ptr(), bvar.data_ptr(),
-                                              P.W(f"b{i}/bn_b/gamma").data_ptr(), P.W(f"b{i}/bn_b/beta").data_ptr(), BN_EPS, st), "orcai_pool_res_add_bn")
+            N.check(self._fn("pool_res_add_bn")(b[f"vb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, self._w_pw(f"b{i}/res/kernel").data_ptr(),
+                                                P.W(f"b{i}/res/bias").data_ptr(), b[f"prev{i}"].data_ptr(), 0, bmean.data_ptr(), bvar.data_ptr(),
+                                                P.W(f"b{i}/bn_b/gamma").data_ptr(), P.W(f"b{i}/bn_b/beta").data_ptr(), BN_EPS, st), "orcai_pool_res_add_bn")
             prev, c = b[f"prev{i}"], f
             res_in = prev
             if self.block_masks is not None:  # ResNet1DConv: Dropout after every block; the dropped tensor feeds the next separable conv only
@@ -451,9 +514,9 @@ class TrunkTrainer:
                         "mask_scale")
                 prev = dropped
         h, w, _ = shapes[-1]
-        self.dwl["sep_f"] = self._packed(0, "sep_f/depthwise", (-1,))
+        self.dwl["sep_f"] = self._w_dw("sep_f")
         featv = torch.empty((B, h, w * FINAL_FILTERS), dtype=torch.float32, device=self.dev)
-        self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], P.W("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1, u_out=b["u_f"])
+        self._sep(prev, c, h, w, k, 0, self.dwl["sep_f"], self._w_pw("sep_f/pointwise"), P.W("sep_f/bias"), FINAL_FILTERS, featv, layout=1, u_out=b["u_f"])
         self.final_in = prev
         return featv
 
@@ -469,8 +532,8 @@ class TrunkTrainer:
         then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
-        wt = self._packed(2, name + "/pointwise", (Cout, Cin))  # pointwise^T [Cout][Cin]
-        N.check(lib.orcai_bn_bwd_pointwise(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+        wt = self._w_pwT(name + "/pointwise", Cin, Cout)  # pointwise^T [Cout][Cin]
+        N.check(self._fn("bn_bwd_pointwise")(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
         self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True)
@@ -482,15 +545,15 @@ class TrunkTrainer:
         # d loss / d bias = sum_pixels dv, and dv is the gradient through a BatchNormalization of batch statistics: that sum is
         # identically zero (the bias shifts the batch mean, which BN subtracts), so the gradient buffer keeps its zero.
         # u = dw(relu?(x)) was stored by the forward pass.
-        N.check(lib.orcai_outer_reduce(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
-                                       self.partials.numel(), st), "outer_reduce")
+        N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                         self.partials.numel(), st), "outer_reduce")
         if not have_du:  # du = Wpw dv   (pointwise conv with the transposed weights)
-            wt = self._packed(2, name + "/pointwise", (Cout, Cin))
-            self._sep(dv, Cout, H, W, 1, 0, self._ones(4 * ((Cout + 3) // 4)), wt, self._zeros(64), Cin, du)
+            wt = self._w_pwT(name + "/pointwise", Cin, Cout)
+            self._sep(dv, Cout, H, W, 1, 0, self._w_ones_dw(Cout), wt, self._zeros(64), Cin, du)
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
-        N.check(lib.orcai_dw_wgrad(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
+        N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
         # dr = depthwise conv of du with the flipped taps (identity pointwise)
-        self._sep(du, Cin, H, W, k, 0, self._packed(1, name + "/depthwise", (-1,)), self._eye(Cin), self._zeros(64), Cin, dr)
+        self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
 
     def backward(self, dfeatv: torch.Tensor) -> None:
         """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
@@ -498,7 +561,7 @@ class TrunkTrainer:
         shapes = m.stage_shapes()
         L = len(m.filters)
         h, w, c = shapes[-1]
-        N.check(lib.orcai_feat_to_planes(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
+        N.check(self._fn("feat_to_planes")(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
         dprev = b["dprev_f"]
         self._sep_backward("sep_f", self.final_in, 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
         for i in range(L, 0, -1):
@@ -511,31 +574,31 @@ class TrunkTrainer:
                         "mask_scale")
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
             # residual 1x1 stride-2 conv: weight / bias gradients
-            N.check(lib.orcai_outer_reduce(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
-                                           self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
-            N.check(lib.orcai_planes_sum(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
+            N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
+                                             self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
+            N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
             # max-pool branch
             dyb = b[f"dyb{i}"]
             bmean, bvar = self.stats[f"b{i}/bn_b"]  # the pooling backward also accumulates bn_b's backward reductions (sum dy, sum dy*xhat)
-            N.check(lib.orcai_pool_bwd_bn(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
-                                          bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
+            N.check(self._fn("pool_bwd_bn")(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
+                                            bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
             dya = b[f"dya{i}"]
             self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1)
             dr = b[f"dr{i}"]
             self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr)
             # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
             if i > 1:  # for block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward applies anyway (mask*mask = mask)
-                N.check(lib.orcai_planes_relu_bwd(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
+                N.check(self._fn("planes_relu_bwd")(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
                 N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")
-            wrt = self._packed(2, f"b{i}/res/kernel", (f, cprev))  # residual weights transposed [f][cprev]
-            self._sep(dout, f, ho, wo, 1, 0, self._ones(4 * ((f + 3) // 4)), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
+            wrt = self._w_pwT(f"b{i}/res/kernel", cprev, f)  # residual weights transposed [f][cprev]
+            self._sep(dout, f, ho, wo, 1, 0, self._w_ones_dw(f), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
             dprev = dr
         H, W = m.input_hw
         mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
-        N.check(lib.orcai_conv0_bn_bwd(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
-                                       P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
-                                       P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
+        N.check(self._fn("conv0_bn_bwd")(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
+                                         P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
+                                         P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
         # conv0/bias feeds bn0: zero gradient (see _sep_backward)
 
 
@@ -548,9 +611,19 @@ class Trainer:
         self.model = model
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.P = FlatParams(model, self.dev)
-        self.trunk = TrunkTrainer(model, self.P)
+        # model.precision "f16": activations / activation gradients in f16 octet planes, contractions on f16 MFMA, f32 master weights,
+        # f32 gradients and Adam, static loss scale (orcai_amd/half.py; BASELINE configs[4])
+        self.half = getattr(model, "precision", "f32") == "f16"
+        if self.half:
+            from orcai_amd.half import LOSS_SCALE
+
+            self.grad_scale = LOSS_SCALE
+        else:
+            self.grad_scale = 1.0
+        self.trunk = TrunkTrainer(model, self.P, half=self.half)
         self.conv1d = getattr(model, "architecture", "") == "ResNet1DConv"
-        self.head = Conv1DHeadTrainer(model, self.P) if self.conv1d else HeadTrainer(model, self.P)
+        self.head = Conv1DHeadTrainer(model, self.P) if self.conv1d else HeadTrainer(model, self.P, half=self.half, grad_scale=self.grad_scale)
+        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.dev)  # f16 path: steps whose gradients overflowed (zeroed, counted)
         self.lr = float(learning_rate)
         self.step_count = 0
         self.seed = int(seed)
@@ -623,7 +696,11 @@ class Trainer:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 self.P.g.copy_(g)
         self.step_count += 1
-        adam_step(self.P, self.lr, self.step_count, gscale=1.0 / world_size)
+        if self.half:  # a non-finite value anywhere (f16 overflow under the static loss scale) voids the step's gradients
+            ok = torch.isfinite(self.P.g).all()
+            self.P.g.copy_(torch.where(ok, self.P.g, torch.zeros_like(self.P.g)))
+            self.skipped += (~ok).to(torch.int64)
+        adam_step(self.P, self.lr, self.step_count, gscale=1.0 / (world_size * self.grad_scale))
         self.trunk.update_moving_stats()
         self.head.update_moving_stats()
 
