@@ -126,10 +126,11 @@ def measured_traffic(symbol: str):
 
 WORKLOADS = {"frontend": FrontendWorkload}
 try:
-    from bench_predict import PredictWorkload, TrainWorkload
+    from bench_predict import HpsearchWorkload, PredictWorkload, TrainWorkload
 
     WORKLOADS["predict"] = PredictWorkload
     WORKLOADS["train"] = TrainWorkload
+    WORKLOADS["hpsearch"] = HpsearchWorkload
 except ImportError:
     pass
 
@@ -177,6 +178,51 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
                        "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"}}
 
 
+def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
+    """BASELINE configs[4] attached to the default line as `secondary2`: the three width variants of the hyper-parameter sweep trained
+    data parallel on the f16 path (HpsearchWorkload), timed like every other number here (warm-up, barrier + synchronize on both
+    sides, MAX over ranks).  The 200-step f16-vs-f32 loss comparison belongs to `--workload hpsearch` (it takes a minute)."""
+    ok, err, hw = 1, None, None
+    try:
+        hw = WORKLOADS["hpsearch"](device, rank)
+        hw.world = 1
+        hw.step(False)  # probe without collectives
+        hw.world = world
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        ok, err = 0, repr(e)
+    if dist:
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        return {"metric": "snippets_per_s", "error": err or "the probe step failed on another rank"}
+    for _ in range(warmup):
+        hw.step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hw.step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = {"metric": hw.metric, "value": round(hw.units_per_step * steps * world / elapsed, 1), "unit": hw.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": hw.dtype, "data": "synthetic",
+           "config": {"workload": hw.name, "units_per_step_per_gpu": hw.units_per_step, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket per variant)"}}
+    if rank == 0:
+        out["roofline"] = hw.roofline()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +231,8 @@ def main():
     ap.add_argument("--workload", default="predict" if "predict" in WORKLOADS else "frontend", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the training-throughput measurement attached to the predict line")
+    ap.add_argument("--no-loss-curves", action="store_true", help="hpsearch workload: skip the 200-step f16-vs-f32 loss comparison")
+    ap.add_argument("--curve-steps", type=int, default=200)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,8 +272,11 @@ def main():
         elapsed = float(t.item())
 
     secondary = None
+    secondary2 = None
     if args.workload == "predict" and "train" in WORKLOADS and not args.no_secondary:
         secondary = measure_secondary(device, rank, world, dist)
+        torch.cuda.empty_cache()
+        secondary2 = measure_sweep(device, rank, world, dist)
 
     if rank == 0:
         value = wl.units_per_step * args.steps * world / elapsed
@@ -238,11 +289,15 @@ def main():
         }
         if secondary is not None:
             line["secondary"] = secondary
+        if secondary2 is not None:
+            line["secondary2"] = secondary2
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
-        if args.workload == "train":
+        if args.workload in ("train", "hpsearch"):
             line["scaling"] = "weak"
             line["config"]["parallelism"] = f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"
+        if args.workload == "hpsearch" and world == 1 and not args.no_loss_curves:
+            line["loss_curves_f16_vs_f32"] = wl.loss_curves(args.curve_steps)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

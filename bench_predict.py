@@ -219,8 +219,10 @@ class _TimedLib:
     ~300 short launches, so bracketing all of them would slow the step by 20 %.  mode "all": every orcai_* launcher (used for two
     extra steps AFTER the timed region to report where the time goes)."""
 
-    def __init__(self, lib):
+    def __init__(self, lib, is_dominant=None):
         self._lib, self.events, self.mode = lib, None, "dominant"
+        if is_dominant is not None:
+            self.is_dominant = is_dominant
 
     @staticmethod
     def is_dominant(name, args):
@@ -353,3 +355,150 @@ class TrainWorkload:
         dt = time.perf_counter() - t0
         return {"value": round(done / dt, 2), "unit": self.unit, "cores": cores, "kind": "port",
                 "sample": f"oracle.train_ref.loss_and_grads (torch-CPU autograd forward+backward, fp32, {cores} threads) on {done} snippets in batches of {n}: {dt:.1f} s"}
+
+
+HPS_FILTER_SETS = {"set1": [10, 20, 30, 40], "set2": [20, 30, 40, 50], "set3": [30, 40, 50, 60]}  # reference defaults/default_hps_parameter.json:2-25
+
+
+def _train_flops_per_snippet(filters, k=3, units=128, H=736, W=171):
+    """Forward MACs of a ResNetLSTM width variant (the SURVEY 8a row B3 count, generalised), x 2 FLOP x 3 (fwd + bwd)."""
+    mac = H * W * k * k * 16
+    c, h, w = 16, H, W
+    for f in filters:
+        mac += h * w * (k * k * c + c * f + k * k * f + f * f)
+        h2, w2 = -(-h // 2), -(-w // 2)
+        mac += h2 * w2 * c * f
+        c, h, w = f, h2, w2
+    mac += h * w * (k * k * c + c * 36)
+    feat = w * 36
+    mac += h * 2 * (feat * 4 * units + units * 4 * units) + h * 2 * (2 * units * 4 * units + units * 4 * units) + h * (2 * units * 128 + 128 * 7)
+    return 6.0 * mac
+
+
+class HpsearchWorkload:
+    """BASELINE configs[4]: the three CNN width variants of the reference's hyper-parameter file (lstm_units 128, kernel 3, dropout
+    0.5), batch 64 per GPU, data parallel (one RCCL all-reduce of each variant's flat gradient bucket per step), on the f16 path:
+    f16 octet-plane activations and gradients, v_mfma_f32_16x16x32_f16 contractions, f32 master weights + Adam.  One step = one
+    training step of EACH variant (3 x 64 snippets per GPU); metric snippets/s over the sweep."""
+
+    name = "hpsearch sweep: width variants set1/set2/set3 (default_hps_parameter.json), lstm 128, k 3, dropout 0.5, batch 64 per GPU, f16 MFMA path"
+    metric = "snippets_per_s"
+    unit = "snippets/s"
+    dtype = "f16"
+
+    def __init__(self, device, rank, precision="f16", variants=("set1", "set2", "set3")):
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.training import Trainer
+
+        self.B = int(os.environ.get("ORCAI_BENCH_BATCH", "64"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device, self.rank, self.precision = device, rank, precision
+        g = torch.Generator(device=device)
+        g.manual_seed(5 + rank)
+        self.x = torch.rand((self.B, 736, 171), device=device, generator=g).view(-1)
+        self.y = (torch.rand((self.B, 46, 7), device=device, generator=g) > 0.7).float()
+        self.variants = list(variants)
+        self.trainers, self.timed = {}, {}
+
+        def dominant(name, args):  # the f16 separable convolutions of block 1 (k = 3 taps, two output tiles or the widest plane)
+            return name == "orcai_h_sepconv" and args[6] == 3 and args[3] >= 736
+
+        for v in self.variants:
+            model = ResNetLSTM((736, 171, 1), 7, HPS_FILTER_SETS[v], 3, 0.5, 128, seed=1, precision=precision)
+            tr = Trainer(model, 1e-4, seed=rank)
+            tl = _TimedLib(tr.trunk.lib, dominant)
+            tr.trunk.lib = tl
+            tr.head.lib = tl
+            self.trainers[v], self.timed[v] = tr, tl
+        self.units_per_step = float(self.B * len(self.variants))
+        self.ev = {v: [] for v in self.variants}
+
+    def step(self, timed: bool):
+        for v in self.variants:
+            tr = self.trainers[v]
+            if timed:
+                if self.timed[v].events is None:
+                    self.timed[v].events = {}
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            tr.train_step(self.x, 736 * 171, self.B, self.y, world_size=self.world)
+            if timed:
+                e1.record()
+                self.ev[v].append((e0, e1))
+
+    def per_variant(self):
+        out = {}
+        for v in self.variants:
+            ms = float(np.mean([a.elapsed_time(b) for a, b in self.ev[v]])) if self.ev[v] else None
+            out[v] = {"filters": HPS_FILTER_SETS[v], "ms_per_step": None if ms is None else round(ms, 3),
+                      "snippets_per_s_per_gpu": None if ms is None else round(self.B / (ms * 1e-3), 1),
+                      "step_tflops": None if ms is None else round(_train_flops_per_snippet(HPS_FILTER_SETS[v]) * self.B / (ms * 1e-3) / 1e12, 2)}
+        return out
+
+    def roofline(self):
+        """Dominant kernel symbol of the sweep: the f16 separable-convolution kernel on block-1 planes (sepconv_h_kernel<3, MT>):
+        HIP events around its launches inside the timed steps; algorithmic bytes = f16 tensors read / written once per launch."""
+        t, by, n = 0.0, 0.0, 0
+        for v in self.variants:
+            for a, b, args in (self.timed[v].events or {}).get("orcai_h_sepconv", []):
+                B, Cin, H, W, Cout, layout, u_out = args[1], args[2], args[3], args[4], args[12], args[14], args[18]
+                t += a.elapsed_time(b)
+                by += 2.0 * B * H * W * (Cin + Cout + (Cin if u_out else 0))
+                n += 1
+        out = {"bound": "hbm", "kernel": "sepconv_h_kernel<3, MT> on block-1 planes (736 x 171), all variants", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        if n:
+            ach = by / (t * 1e-3) / 1e9
+            out.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_ms": round(t / n, 4), "launches": n,
+                        "algorithmic_bytes_per_launch": round(by / n)})
+        out["variants"] = self.per_variant()
+        return out
+
+    def loss_curves(self, steps=200):
+        """fp16-vs-fp32 loss deviation: every variant trained `steps` steps on the same 4 synthetic batches with
+        the same initial weights and dropout masks in both precisions (outside the timed region)."""
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.training import Trainer
+
+        g = torch.Generator(device=self.device)
+        g.manual_seed(99)
+        xs = torch.rand((4, self.B, 736, 171), device=self.device, generator=g)
+        band = xs.view(4, self.B, 46, 16, 171)[..., :56].mean(dim=(3, 4))  # a learnable target: mean energy of a band per output step
+        ys = (band[..., None] > band.median()).float().repeat(1, 1, 1, 7)
+        out = {}
+        for v in self.variants:
+            curves = {}
+            for prec in ("f32", "f16"):
+                model = ResNetLSTM((736, 171, 1), 7, HPS_FILTER_SETS[v], 3, 0.5, 128, seed=1, precision=prec)
+                tr = Trainer(model, 1e-3, seed=3)
+                acc = []
+                for s in range(steps):
+                    o = tr.train_step(xs[s % 4].reshape(-1), 736 * 171, self.B, ys[s % 4], world_size=1)
+                    acc.append(o["acc"][:2].clone())
+                a = torch.stack(acc).cpu().numpy()
+                curves[prec] = a[:, 0] / a[:, 1]
+                skipped = int(tr.skipped.item()) if prec == "f16" else 0
+                del tr, model
+                torch.cuda.empty_cache()
+            d = np.abs(curves["f16"] - curves["f32"])
+            out[v] = {"steps": steps, "loss_first": round(float(curves["f32"][0]), 4), "loss_last20_f32": round(float(curves["f32"][-20:].mean()), 4),
+                      "loss_last20_f16": round(float(curves["f16"][-20:].mean()), 4), "max_abs_dev": round(float(d.max()), 4), "mean_abs_dev": round(float(d.mean()), 4),
+                      "overflow_steps": skipped}
+        return out
+
+    def cpu_baseline(self):
+        from oracle import model_ref as M
+        from oracle import train_ref as T
+
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("ORCAI_BENCH_CPU_THREADS", "16")))
+        torch.set_num_threads(cores)
+        rng = np.random.default_rng(0)
+        n, done, t0 = 4, 0, time.perf_counter()
+        x = rng.random((n, 736, 171, 1), dtype=np.float32)
+        y = (rng.random((n, 46, 7)) > 0.7).astype(np.float32)
+        for v in self.variants:
+            p = M.random_params(seed=1, filters=tuple(HPS_FILTER_SETS[v]))
+            T.loss_and_grads(p, x, y, None, 0.0, dtype=torch.float32)
+            done += n
+        dt = time.perf_counter() - t0
+        return {"value": round(done / dt, 2), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"oracle.train_ref.loss_and_grads (torch-CPU autograd, fp32, {cores} threads): one batch of {n} snippets per width variant, {dt:.1f} s"}
