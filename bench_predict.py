@@ -397,7 +397,7 @@ class HpsearchWorkload:
         g.manual_seed(5 + rank)
         self.x = torch.rand((self.B, 736, 171), device=device, generator=g).view(-1)
         self.y = (torch.rand((self.B, 46, 7), device=device, generator=g) > 0.7).float()
-        self.variants = list(variants)
+        self.variants = [v for v in os.environ.get("ORCAI_HPS_VARIANTS", ",".join(variants)).split(",") if v]  # profiling: one variant at a time
         self.trainers, self.timed = {}, {}
 
         def dominant(name, args):  # the f16 separable convolutions of block 1 (k = 3 taps, two output tiles or the widest plane)

@@ -425,39 +425,42 @@ __device__ __forceinline__ float lshf(float v) {
   return __uint_as_float(lane_shift_u<SH>(__float_as_uint(v)));
 }
 
-template <int KS>
+// NCH channels of the octet per block: 8 for k = 3 (72 accumulators per lane), 4 for k = 5, 7 (one block per half octet: 100 / 196).
+template <int KS, int NCH>
 __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__ x, const h16* __restrict__ du, int C, int H, int W, int WP, int RP, int relu_in,
                                                           float* __restrict__ dW /*[KS*KS][C]*/, int tasks, int tasks_per_wave) {
-  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
+  constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS, PARTS = 8 / NCH;
   const int lane = threadIdx.x & 63;
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int co = blockIdx.y >> 1, half = blockIdx.y & 1, b = blockIdx.z;
+  const int co = blockIdx.y / PARTS, c0 = (blockIdx.y % PARTS) * NCH, b = blockIdx.z;
   const int CO = (C + 7) >> 3;
   const int plane = (H + 2 * RP) * WP;
   const int64_t base = ((int64_t)b * CO + co) * plane;
-  float acc[4][KK];
+  float acc[NCH][KK];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
   const bool contributes = lane >= R && lane < 64 - R;
   for (int task = wv * tasks_per_wave; task < (wv + 1) * tasks_per_wave && task < tasks; ++task) {
     const int q = RP * WP + task * VAL - R + lane;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    if (contributes && q < plane) {
-      const O8 g8 = ld8(du, base + q);
+    float g[NCH];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = g8.v[4 * half + j];
+    for (int j = 0; j < NCH; ++j) g[j] = 0.f;
+    if (contributes && q < plane) {
+      const h16x8 g8 = reinterpret_cast<const h16x8*>(du)[base + q];
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) g[j] = (float)g8[c0 + j];
     }
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       int i = q + (dy - R) * WP;
       i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-      const O8 a8 = ld8(x, base + i);
+      h16x8 a8 = reinterpret_cast<const h16x8*>(x)[base + i];
+      if (relu_in) a8 = relu_h(a8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float a = a8.v[4 * half + j];
-        if (relu_in) a = fmaxf(a, 0.0f);
+      for (int j = 0; j < NCH; ++j) {
+        const float a = (float)a8[c0 + j];
         if constexpr (KS == 3) {
           acc[j][dy * 3 + 0] = fmaf(lshf<-1>(a), g[j], acc[j][dy * 3 + 0]);
           acc[j][dy * 3 + 1] = fmaf(a, g[j], acc[j][dy * 3 + 1]);
@@ -480,9 +483,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
       }
     }
   }
-  __shared__ float red[4][4 * KK];
+  __shared__ float red[4][NCH * KK];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       float v = acc[j][t];
@@ -491,9 +494,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
       if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   __syncthreads();
-  if (threadIdx.x < 4 * KK) {
+  if (threadIdx.x < NCH * KK) {
     const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
-    const int c = co * 8 + 4 * half + j;
+    const int c = co * 8 + c0 + j;
     if (c < C) atomicAdd(&dW[t * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
@@ -763,12 +766,13 @@ int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, 
   const int tasks = (H * WP + VAL - 1) / VAL;
   int tpw = (tasks + 7) / 8;
   if (tpw < 8) tpw = 8;
-  dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, 2 * ((C + 7) / 8), B);
+  const int parts = ktap == 3 ? 1 : 2;  // blocks per octet
+  dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, parts * ((C + 7) / 8), B);
   hipStream_t st = (hipStream_t)stream;
   switch (ktap) {
-    case 3: hipLaunchKernelGGL(dw_wgrad_h_kernel<3>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
-    case 5: hipLaunchKernelGGL(dw_wgrad_h_kernel<5>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
-    case 7: hipLaunchKernelGGL(dw_wgrad_h_kernel<7>, grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 3: hipLaunchKernelGGL((dw_wgrad_h_kernel<3, 8>), grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 5: hipLaunchKernelGGL((dw_wgrad_h_kernel<5, 4>), grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 7: hipLaunchKernelGGL((dw_wgrad_h_kernel<7, 4>), grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();

@@ -748,7 +748,8 @@ __global__ __launch_bounds__(256) void relu_bwd4_kernel(const float4* __restrict
 extern "C" {
 
 int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize, double* scratch2C, float* mean, float* var, void* stream) {
-  if (!v || !scratch2C || !mean || !var || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  if (!v || !scratch2C || !mean || !var || B <= 0 || C <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (C > 64) return ORCAI_E_BADARG;  // scratch2C holds 8 doubles per channel quad of at most 64 channels (the caller cannot pass its size)
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
@@ -763,7 +764,7 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
 }
 
 int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratchC, float* out, int accumulate, void* stream) {
-  if (!x || !scratchC || !out || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  if (!x || !scratchC || !out || B <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
@@ -789,7 +790,7 @@ int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize,
 
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                         const float* beta, float eps, int relu, double* scratch2C, float* dbeta, float* dgamma, float* dv, void* stream) {
-  if (!dy || !v || !dv || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  if (!dy || !v || !dv || !scratch2C || !dbeta || !dgamma || B <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
@@ -847,8 +848,9 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
 
 int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
                       const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
-  if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (!dout || !ybn || !dy || B <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   if (bn_sums && (!bn_gamma || !bn_mean || !bn_var)) return ORCAI_E_BADARG;
+  if ((int64_t)B * ((C + 3) / 4) > 65535) return ORCAI_E_UNSUPPORTED;  // grid.y = (snippet, quad)
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
@@ -872,8 +874,12 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
 
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
                        float* workspace, int64_t workspace_floats, void* stream) {
-  if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0) return ORCAI_E_BADARG;
+  if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (workspace_floats < (int64_t)Ca * Cb) return ORCAI_E_BADARG;
+  if (a_stride2 && (Ha < 2 * H - 1 || Wa < 2 * W - 1)) return ORCAI_E_BADARG;  // A is sampled at (2i, 2j)
   const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
+  // dynamic LDS beyond the 64 KiB default (any operand wider than 32 channels) needs the opt-in below: a launch without it was the one
+  // difference between the test shapes that ran and the one that aborted in round 1
   const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * OR_P * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
@@ -894,7 +900,7 @@ int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, i
 }
 
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {
-  if (!x || !du || !dW || B <= 0 || C <= 0) return ORCAI_E_BADARG;
+  if (!x || !du || !dW || B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0 || ktap > ksize_planes) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
   const int VAL = 64 - 2 * (ktap / 2);
   const int tasks = (H * WP + VAL - 1) / VAL;
