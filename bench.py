@@ -162,7 +162,7 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        tw.step(False)
+        tw.step(True)  # brackets only the dominant kernel's launches (HIP events on the launch stream)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -172,10 +172,27 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return {"metric": tw.metric, "value": round(tw.units_per_step * steps * world / elapsed, 1), "unit": tw.unit, "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": tw.dtype, "data": "synthetic",
-            "config": {"workload": tw.name, "units_per_step_per_gpu": tw.units_per_step,
-                       "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"}}
+    out = {"metric": tw.metric, "value": round(tw.units_per_step * steps * world / elapsed, 1), "unit": tw.unit, "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": tw.dtype, "data": "synthetic",
+           "config": {"workload": tw.name, "units_per_step_per_gpu": tw.units_per_step,
+                      "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"}}
+    if dist:  # the one collective of the step, alone: all-reduce of the flat gradient bucket (3.98 MB for orcai-V1) over RCCL / xGMI
+        g = tw.trainer.P.g
+        for _ in range(3):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        out["allreduce_us"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
+        out["allreduce_bytes"] = int(g.numel() * 4)
+    if rank == 0:  # both halves of BASELINE's metric carry a roofline: the step against the f32 MFMA peak, its dominant kernel against HBM
+        r = tw.roofline()
+        r["step_frac_of_f32_mfma_peak"] = round(r["step_tflops"] / MFMA_F32_PEAK_TFLOPS, 4)
+        out["roofline"] = r
+    return out
 
 
 def measure_sweep(device, rank, world, dist, steps=5, warmup=2):

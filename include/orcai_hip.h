@@ -327,6 +327,17 @@ int orcai_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, 
 /* dx = (y > 0) ? dy : 0 on whole plane buffers (n_floats % 4 == 0) */
 int orcai_planes_relu_bwd(const float* dy, const float* y, int64_t n_floats, float* dx, void* stream);
 
+/* Keras LSTM variables <-> the gate-column order of the recurrence kernels (orcai_lstm_recurrent), on the device, once per training
+ * step (replaces the per-step framework index / cat / stack kernels; architectures.py:210-229 define the variables).
+ * orcai_pack_lstm: desc int32[n_desc][7] = {src offset in w (floats), dst offset (elements), rows, units, ld_dst, col_off, mode};
+ *   mode 0: out32[dst + r*ld_dst + col_off + p] = w[src + r*4u + perm(p)];  mode 1: out16[dst + (col_off + p)*ld_dst + r] = (f16) the same
+ *   (transposed, zero-padded copy for orcai_h_gemm_bias_act).  perm(p), p = 32w + 16nt + j: Keras column (2nt + (j>>3))*u + 8w + (j&7).
+ * orcai_unpack_lstm_grad: G[r*4u + perm(p)] = src[r*ld_src + col_off + p] + l2g * W[r*4u + perm(p)]   (W may be NULL).
+ * orcai_ema_update: moving = moving*momentum + batch*(1 - momentum)  (BatchNormalization moving statistics, one flat buffer). */
+int orcai_pack_lstm(const float* w, const int* desc, int n_desc, float* out32, void* out16, void* stream);
+int orcai_unpack_lstm_grad(const float* src, int ld_src, int col_off, int rows, int units, float* G, const float* W, float l2g, void* stream);
+int orcai_ema_update(float* moving, const float* batch, int n, float momentum, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * f16 path (BASELINE configs[4]: the hyper-parameter sweep's width variants on f16 MFMA; hpsearch.py:186-205 x
  * defaults/default_hps_parameter.json:2-25).  Activations are f16 channel-OCTET planes

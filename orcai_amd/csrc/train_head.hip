@@ -652,6 +652,51 @@ __global__ __launch_bounds__(256) void conv1d_dgrad_kernel(const float* __restri
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// ---------------------------------------------------------------- LSTM weights: Keras layout <-> the recurrence kernels' gate-column order
+// Kernel column p = 32 w + 16 nt + j holds Keras column (2 nt + (j >> 3)) u + 8 w + (j & 7)   (architectures.lstm_column_permutation):
+// wave w of lstm_kernel owns all four gates of units [8w, 8w + 8).
+__device__ __forceinline__ int lstm_perm(int p, int u) {
+  const int w = p >> 5, nt = (p >> 4) & 1, j = p & 15;
+  return (2 * nt + (j >> 3)) * u + 8 * w + (j & 7);
+}
+
+// desc[i] = {src offset (floats, into w), dst offset (elements), rows, u, ld_dst, col_off, mode}:
+//   mode 0: f32  dst[r * ld_dst + col_off + p] = src[r * 4u + perm(p)]        (kernel / bias / recurrent matrices for the f32 kernels)
+//   mode 1: f16  dst[(col_off + p) * ld_dst + r] = src[r * 4u + perm(p)]      (TRANSPOSED copy for orcai_h_gemm_bias_act; pad stays zero)
+// One workgroup per (descriptor, row block): replaces the per-step torch index / cat / stack kernels.
+__global__ __launch_bounds__(256) void pack_lstm_kernel(const float* __restrict__ w, const int* __restrict__ desc, float* __restrict__ out32,
+                                                         _Float16* __restrict__ out16) {
+  const int* d = desc + blockIdx.x * 7;
+  const int rows = d[2], u = d[3], ld = d[4], col_off = d[5], mode = d[6];
+  const float* src = w + d[0];
+  const int64_t n = (int64_t)rows * 4 * u;
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) {
+    const int r = (int)(i / (4 * u)), p = (int)(i - (int64_t)r * 4 * u);
+    const float v = src[(int64_t)r * 4 * u + lstm_perm(p, u)];
+    if (mode == 0) out32[d[1] + (int64_t)r * ld + col_off + p] = v;
+    else out16[d[1] + (int64_t)(col_off + p) * ld + r] = (_Float16)v;
+  }
+}
+
+// G[r * 4u + perm(p)] = src[r * ld_src + col_off + p] + l2g * W[r * 4u + perm(p)]: a kernel-order gradient back into the Keras-layout
+// gradient buffer, with the L2 regulariser's term (W may be NULL when l2g == 0).
+__global__ __launch_bounds__(256) void unpack_lstm_grad_kernel(const float* __restrict__ src, int ld_src, int col_off, int rows, int u, float* __restrict__ G,
+                                                                const float* __restrict__ W, float l2g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * 4 * u) return;
+  const int r = (int)(i / (4 * u)), p = (int)(i - (int64_t)r * 4 * u);
+  const int64_t k = (int64_t)r * 4 * u + lstm_perm(p, u);
+  float v = src[(int64_t)r * ld_src + col_off + p];
+  if (W) v = fmaf(l2g, W[k], v);
+  G[k] = v;
+}
+
+// moving = moving * momentum + batch * (1 - momentum) over one flat buffer of all BatchNorm statistics
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ moving, const float* __restrict__ batch, int n, float momentum) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) moving[i] = moving[i] * momentum + batch[i] * (1.0f - momentum);
+}
+
 }  // namespace
 
 extern "C" {
@@ -808,6 +853,24 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
     case 64: hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
+  return (int)hipGetLastError();
+}
+
+int orcai_pack_lstm(const float* w, const int* desc, int n_desc, float* out32, void* out16, void* stream) {
+  if (!w || !desc || n_desc <= 0 || (!out32 && !out16)) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(pack_lstm_kernel, dim3(n_desc, 16), dim3(256), 0, (hipStream_t)stream, w, desc, out32, (_Float16*)out16);
+  return (int)hipGetLastError();
+}
+
+int orcai_unpack_lstm_grad(const float* src, int ld_src, int col_off, int rows, int units, float* G, const float* W, float l2g, void* stream) {
+  if (!src || !G || rows <= 0 || units <= 0 || (units & 7) || col_off < 0 || ld_src < col_off + 4 * units) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(unpack_lstm_grad_kernel, dim3(blocks_for((int64_t)rows * 4 * units)), dim3(256), 0, (hipStream_t)stream, src, ld_src, col_off, rows, units, G, W, l2g);
+  return (int)hipGetLastError();
+}
+
+int orcai_ema_update(float* moving, const float* batch, int n, float momentum, void* stream) {
+  if (!moving || !batch || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, moving, batch, n, momentum);
   return (int)hipGetLastError();
 }
 

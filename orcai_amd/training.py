@@ -36,13 +36,23 @@ class FlatParams:
         self.g = torch.zeros(off, dtype=torch.float32, device=device)
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
-        self.stats = {}  # BN moving mean / var (non-trainable)
+        # BN moving mean / var (non-trainable): views into ONE flat buffer, mirrored by a flat buffer of the current step's batch
+        # statistics in the same order, so that the moving-average update of every BatchNorm is one launch (orcai_ema_update)
+        self.stat_offsets, soff = {}, 0
+        for n, s, t in self.spec:
+            if not t:
+                self.stat_offsets[n] = (soff, int(np.prod(s)))
+                soff += int(np.prod(s))
+        self.stats_flat = torch.zeros(max(soff, 1), dtype=torch.float32, device=device)
+        self.batch_flat = torch.zeros(max(soff, 1), dtype=torch.float32, device=device)
+        self.stats = {n: self.stats_flat[o : o + k] for n, (o, k) in self.stat_offsets.items()}
         for n, s, t in self.spec:
             a = torch.from_numpy(np.ascontiguousarray(model.weights[n])).to(device)
             if t:
                 self.W(n).copy_(a)
             else:
-                self.stats[n] = a.clone()
+                self.stats[n].copy_(a)
+        self.batch_flat.copy_(self.stats_flat)  # a BatchNorm that does not run this step leaves its moving statistics unchanged
 
     def W(self, name) -> torch.Tensor:
         o, n, s = self.offsets[name]
@@ -51,6 +61,15 @@ class FlatParams:
     def G(self, name) -> torch.Tensor:
         o, n, s = self.offsets[name]
         return self.g[o : o + n].view(s)
+
+    def B(self, name) -> torch.Tensor:
+        """This step's batch statistic of a BatchNorm (`<bn>/mean` or `<bn>/var`): the kernels write it here."""
+        o, k = self.stat_offsets[name]
+        return self.batch_flat[o : o + k]
+
+    def ema_all(self, momentum: float) -> None:
+        """moving = moving * momentum + batch * (1 - momentum) for every BatchNorm at once (Keras BatchNormalization, biased variance)."""
+        N.check(N.lib().orcai_ema_update(self.stats_flat.data_ptr(), self.batch_flat.data_ptr(), self.stats_flat.numel(), momentum, N.stream_ptr()), "ema_update")
 
     def to_model(self, model: ResNetLSTM) -> None:
         weights = {}
@@ -78,24 +97,56 @@ class HeadTrainer:
         # half: the forward GEMMs (LSTM input projections, Dense-128) run on f16 MFMA with f32 accumulation (orcai_h_gemm_bias_act);
         # the backward GEMMs stay on the f32 kernels.  grad_scale: static loss scale carried by every gradient (undone in Adam).
         self.half, self.grad_scale = bool(half), float(grad_scale)
+        self._build_lstm_pack()
 
-    def _gemm_fwd(self, x, W, bias, out, M, Nn, K, act):
+    def _build_lstm_pack(self):
+        """Kernel-order copies of the LSTM variables (gate columns permuted, both directions side by side), refreshed by ONE
+        orcai_pack_lstm launch per step: f32 [Fin][8u] input kernels, [8u] biases, [2][u][4u] recurrent kernels, and for the f16 path the
+        transposed, zero-padded f16 [8u][roundup32(Fin)] input kernels orcai_h_gemm_bias_act multiplies with."""
+        P, u, dev = self.P, self.u, self.P.w.device
+        feat = self.model.stage_shapes()[-1][1] * FINAL_FILTERS
+        desc, off32, off16 = [], 0, 0
+        self.lstm_views = {}
+        for layer, fin in ((1, feat), (2, 2 * u)):
+            kp = (fin + 31) // 32 * 32
+            v = {"fin": fin, "Wc": (off32, (fin, 8 * u))}
+            off32 += fin * 8 * u
+            v["bc"] = (off32, (8 * u,))
+            off32 += 8 * u
+            v["Uc"] = (off32, (2, u, 4 * u))
+            off32 += 2 * u * 4 * u
+            v["Wt"] = (off16, (8 * u, kp))
+            off16 += 8 * u * kp
+            for d, name in enumerate(("fwd", "bwd")):
+                desc.append([P.offsets[f"lstm{layer}/{name}/kernel"][0], v["Wc"][0], fin, u, 8 * u, d * 4 * u, 0])
+                desc.append([P.offsets[f"lstm{layer}/{name}/bias"][0], v["bc"][0], 1, u, 8 * u, d * 4 * u, 0])
+                desc.append([P.offsets[f"lstm{layer}/{name}/recurrent"][0], v["Uc"][0] + d * u * 4 * u, u, u, 4 * u, 0, 0])
+                if self.half:
+                    desc.append([P.offsets[f"lstm{layer}/{name}/kernel"][0], v["Wt"][0], fin, u, kp, d * 4 * u, 1])
+            self.lstm_views[layer] = v
+        self.lstm_desc = torch.tensor(desc, dtype=torch.int32, device=dev).contiguous()
+        self.lstm32 = torch.empty(off32, dtype=torch.float32, device=dev)
+        self.lstm16 = torch.zeros(off16 if self.half else 8, dtype=torch.float16, device=dev)  # the k padding stays zero
+
+    def _lv(self, layer, key):
+        o, shape = self.lstm_views[layer][key]
+        buf = self.lstm16 if key == "Wt" else self.lstm32
+        return buf[o : o + int(np.prod(shape))].view(shape)
+
+    def _gemm_fwd(self, x, W, bias, out, M, Nn, K, act, Wt=None):
         """out = act(x W + bias): f32 MFMA, or (half) f16 MFMA on a transposed, zero-padded f16 copy of W made here."""
         st = N.stream_ptr()
         if not self.half:
             N.check(self.lib.orcai_gemm_bias_act(x.data_ptr(), W.data_ptr(), bias.data_ptr(), None, None, out.data_ptr(), M, Nn, K, act, st), "gemm")
             return
-        Wt = torch.zeros((Nn, (K + 31) // 32 * 32), dtype=torch.float16, device=W.device)
-        Wt[:, :K] = W.t()
+        if Wt is None:
+            Wt = torch.zeros((Nn, (K + 31) // 32 * 32), dtype=torch.float16, device=W.device)
+            Wt[:, :K] = W.t()
         N.check(self.lib.orcai_h_gemm_bias_act(x.data_ptr(), Wt.data_ptr(), bias.data_ptr(), None, None, out.data_ptr(), M, Nn, K, act, st), "h_gemm")
 
-    # -- kernel-layout LSTM weights from the flat master copy (tiny device-side index ops)
     def _lstm_weights(self, layer):
-        P = self.P
-        Wc = torch.cat([P.W(f"lstm{layer}/fwd/kernel")[:, self.perm], P.W(f"lstm{layer}/bwd/kernel")[:, self.perm]], dim=1).contiguous()
-        bc = torch.cat([P.W(f"lstm{layer}/fwd/bias")[self.perm], P.W(f"lstm{layer}/bwd/bias")[self.perm]]).contiguous()
-        Uc = torch.stack([P.W(f"lstm{layer}/fwd/recurrent")[:, self.perm], P.W(f"lstm{layer}/bwd/recurrent")[:, self.perm]]).contiguous()
-        return Wc, bc, Uc
+        """Views of this step's kernel-order copies (made by the orcai_pack_lstm launch at the start of forward)."""
+        return self._lv(layer, "Wc"), self._lv(layer, "bc"), self._lv(layer, "Uc")
 
     def forward(self, featv: torch.Tensor, masks: dict | None, rate: float) -> torch.Tensor:
         """featv: f32 cuda [n][T][W*36] = pre-BN output of the final separable conv.  Returns probabilities [n][T][labels]."""
@@ -107,8 +158,9 @@ class HeadTrainer:
         keep = 1.0 - rate
         c = {"featv": featv, "n": n, "T": T, "rate": rate, "masks": masks}
         f32 = dict(dtype=torch.float32, device=dev)
+        N.check(lib.orcai_pack_lstm(P.w.data_ptr(), self.lstm_desc.data_ptr(), int(self.lstm_desc.shape[0]), self.lstm32.data_ptr(), self.lstm16.data_ptr(), st), "pack_lstm")
         # BN (batch statistics over snippet, time, frequency) + ReLU
-        c["f_mean"], c["f_var"] = torch.empty(FINAL_FILTERS, **f32), torch.empty(FINAL_FILTERS, **f32)
+        c["f_mean"], c["f_var"] = P.B("bn_f/mean"), P.B("bn_f/var")
         N.check(lib.orcai_bn_rows_stats(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), st), "bn_rows_stats")
         x1 = torch.empty_like(featv)
         N.check(lib.orcai_bn_rows_apply(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), P.W("bn_f/gamma").data_ptr(),
@@ -118,7 +170,7 @@ class HeadTrainer:
         for layer in (1, 2):
             Wc, bc, Uc = self._lstm_weights(layer)
             xz = torch.empty((n, T, 2, 4 * u), **f32)
-            self._gemm_fwd(x, Wc, bc, xz, M, 8 * u, fin, 0)
+            self._gemm_fwd(x, Wc, bc, xz, M, 8 * u, fin, 0, Wt=self._lv(layer, "Wt") if self.half else None)
             h = torch.empty((n, T, 2 * u), **f32)
             gates = torch.empty((n, T, 2, 4 * u), **f32)
             cs = torch.empty((n, T, 2, u), **f32)
@@ -134,7 +186,7 @@ class HeadTrainer:
         pre1 = torch.empty((n, T, DENSE_UNITS), **f32)
         self._gemm_fwd(x, P.W("dense1/kernel"), P.W("dense1/bias"), pre1, M, DENSE_UNITS, 2 * u, 1)
         c["pre1"] = pre1
-        c["d_mean"], c["d_var"] = torch.empty(DENSE_UNITS, **f32), torch.empty(DENSE_UNITS, **f32)
+        c["d_mean"], c["d_var"] = P.B("bn_d/mean"), P.B("bn_d/var")
         N.check(lib.orcai_bn_rows_stats(pre1.data_ptr(), M, DENSE_UNITS, DENSE_UNITS, c["d_mean"].data_ptr(), c["d_var"].data_ptr(), st), "bn_rows_stats")
         d1 = torch.empty_like(pre1)
         N.check(lib.orcai_bn_rows_apply(pre1.data_ptr(), M, DENSE_UNITS, DENSE_UNITS, c["d_mean"].data_ptr(), c["d_var"].data_ptr(), P.W("bn_d/gamma").data_ptr(),
@@ -214,10 +266,11 @@ class HeadTrainer:
             for d, name in enumerate(("fwd", "bwd")):
                 dU = torch.empty((u, 4 * u), **f32)
                 _gemm(lib, hp.view(-1)[d * u :], 1, 2 * u, dxz.view(-1)[d * 4 * u :], 8 * u, 1, dU, u, 4 * u, M)
-                P.G(f"lstm{layer}/{name}/recurrent").copy_(dU[:, self.inv_perm])
                 Wk = P.W(f"lstm{layer}/{name}/kernel")
-                P.G(f"lstm{layer}/{name}/kernel").copy_(dWc[:, d * 4 * u : (d + 1) * 4 * u][:, self.inv_perm] + l2g * Wk)
-                P.G(f"lstm{layer}/{name}/bias").copy_(dbc[d * 4 * u : (d + 1) * 4 * u][self.inv_perm])
+                # kernel-order gradients back into the Keras-layout gradient buffer (+ the L2 term of the input kernel), one launch each
+                N.check(lib.orcai_unpack_lstm_grad(dU.data_ptr(), 4 * u, 0, u, u, P.G(f"lstm{layer}/{name}/recurrent").data_ptr(), None, 0.0, st), "unpack")
+                N.check(lib.orcai_unpack_lstm_grad(dWc.data_ptr(), 8 * u, d * 4 * u, fin, u, P.G(f"lstm{layer}/{name}/kernel").data_ptr(), Wk.data_ptr(), l2g, st), "unpack")
+                N.check(lib.orcai_unpack_lstm_grad(dbc.data_ptr(), 8 * u, d * 4 * u, 1, u, P.G(f"lstm{layer}/{name}/bias").data_ptr(), None, 0.0, st), "unpack")
                 N.check(lib.orcai_l2_value(Wk.data_ptr(), Wk.numel(), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_value")
             dx = torch.empty((M, fin), **f32)
             _gemm(lib, dxz, 8 * u, 1, lc["Wc"], 1, 8 * u, dx, M, fin, 8 * u)
@@ -247,7 +300,7 @@ class Conv1DHeadTrainer:
         f32 = dict(dtype=torch.float32, device=featv.device)
         keep = 1.0 - rate
         c = {"featv": featv, "n": n, "T": T, "rate": rate, "masks": masks, "Wd": Wd}
-        c["f_mean"], c["f_var"] = torch.empty(FINAL_FILTERS, **f32), torch.empty(FINAL_FILTERS, **f32)
+        c["f_mean"], c["f_var"] = P.B("bn_f/mean"), P.B("bn_f/var")
         N.check(lib.orcai_bn_rows_stats(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), st), "bn_rows_stats")
         x1 = torch.empty_like(featv)
         N.check(lib.orcai_bn_rows_apply(featv.data_ptr(), M, cols, FINAL_FILTERS, c["f_mean"].data_ptr(), c["f_var"].data_ptr(), P.W("bn_f/gamma").data_ptr(),
@@ -379,8 +432,7 @@ class TrunkTrainer:
     def _bn_fwd(self, v, bn, C, H, W, relu, y):
         """Batch statistics of v; y = [relu](BN(v)) is materialised unless y is None (the consumer applies BN on the fly)."""
         lib, P, st = self.lib, self.P, N.stream_ptr()
-        mean = torch.empty(C, dtype=torch.float32, device=self.dev)
-        var = torch.empty(C, dtype=torch.float32, device=self.dev)
+        mean, var = P.B(bn + "/mean"), P.B(bn + "/var")  # this step's batch statistics live in the flat buffer the EMA update reads
         N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
         self.stats[bn] = (mean, var)
         if y is None:
@@ -701,8 +753,7 @@ class Trainer:
             self.P.g.copy_(torch.where(ok, self.P.g, torch.zeros_like(self.P.g)))
             self.skipped += (~ok).to(torch.int64)
         adam_step(self.P, self.lr, self.step_count, gscale=1.0 / (world_size * self.grad_scale))
-        self.trunk.update_moving_stats()
-        self.head.update_moving_stats()
+        self.P.ema_all(BN_MOMENTUM)  # every BatchNorm's moving statistics in one launch
 
     def sync_model(self) -> None:
         """Copy the flat device parameters (and BN moving statistics) back into the model object (for predict / save)."""
