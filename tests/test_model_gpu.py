@@ -326,3 +326,42 @@ def test_fused_entry_random_shapes():
                 lib.orcai_entry_windows(prev)
             assert torch.equal(a, a_ref), (case, H, W, Cout, nw)
             assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :]), (case, H, W, Cout, nw)
+
+
+def test_forward_is_hip_graph_capturable():
+    """include/orcai_hip.h promises that nothing in the C ABI allocates, frees or synchronises, so a sequence of calls can be captured
+    into a hipGraph.  Proof: front end + ResNetLSTM forward + overlap average of a recording captured ONCE on a side stream (after a
+    warm-up that sizes the workspaces) and replayed on new audio written into the same input buffer, bit-identical to eager."""
+    from orcai_amd import _native as N
+    from orcai_amd.frontend import get_frontend
+    from orcai_amd.synthetic import pcm16_to_float, synth_recording
+
+    model, _ = make_model(3, input_shape=(64, 171, 1), filters=(12, 20), kernel_size=3, lstm_units=64, num_labels=3)
+    sp = {"sampling_rate": 48000, "nfft": 512, "n_overlap": 256, "freq_range": [0, 16000], "quantiles": [0.01, 0.999]}
+    fe = get_frontend()
+    clips = [torch.from_numpy(pcm16_to_float(synth_recording(1.5, 48000, seed=s))).cuda() for s in (1, 2, 3)]
+    static_in = clips[0].clone()
+
+    def run():
+        spec = fe.make_spectrogram(static_in, sp)
+        return model.predict_spectrogram(spec)
+
+    eager = []
+    for c in clips:
+        static_in.copy_(c)
+        eager.append(run().clone())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        static_in.copy_(clips[0])
+        run()  # warm-up on the capture stream
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(g, stream=side):
+            assert N.stream_ptr() == side.cuda_stream  # the launchers are handed the capturing stream
+            static_out = run()
+    for c, want in zip(clips, eager):
+        static_in.copy_(c)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_out, want)
