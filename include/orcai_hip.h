@@ -125,9 +125,6 @@ int orcai_padded_width(int W, int ksize);
  * one-window-per-wave kernel everywhere.  Both variants perform the same arithmetic in the same order (bit-identical
  * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_stream_windows(int windows_per_wave);
-/* Experiment knob (default 0 = off): k = 3 layers with 17..32 output channels and 5..8 input quads run the row-marching kernel
- * (sepconv_rows_kernel: every input row loaded once per wave) with this many image rows per wave.  Returns the previous value. */
-int orcai_sepconv_rows(int rows_per_wave);
 
 /* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current
  * one is computed).  Returns the previous value; values outside [1, 64] only query. */

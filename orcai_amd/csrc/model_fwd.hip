@@ -15,7 +15,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <type_traits>
 
 #include "orcai_hip.h"
 
@@ -718,164 +717,6 @@ __global__ __launch_bounds__(256, MT <= 2 ? (NS == 2 ? 5 : 4) : (MT == 3 ? (NS =
 }
 
 // =========================================================================================
-// sepconv_rows: the arithmetic of sepconv_kernel<3, MT> with every input row loaded ONCE per wave (the PMC data of
-// on b1/sep_b the L1 fill path is the busiest unit because the streaming kernel's windows fetch every row three times).
-// A wave owns a 64-lane column strip (VAL = 64 - 2 lo output columns) and marches down NR image rows.  Row r arrives once, as CQ
-// dwordx4 loads, and is folded at once into the two output rows that are still open: with hf_dy(a) = w[dy][0] a(x-1) + w[dy][1] a(x) +
-// w[dy][2] a(x+1) (two DPP lane shifts per channel),
-//     out(r-1) = sa + hf_2(a_r)  -> complete: transposes + MFMAs + epilogue;      sa <- sb + hf_1(a_r);      sb <- hf_0(a_r)
-// so the state carried from row to row is two partial depthwise outputs per quad (8 VGPRs), not three raw rows.  The next NS stream
-// elements (row, quad) are always in flight in a register ring; all steady-state memory instructions are unconditional (dead lanes
-// store to a padding pixel), so the wait counts are exact.  Price: NR + 2 rows are read and filtered for NR rows of output, strips
-// of 60 / 62 columns tile the row pitch with a remainder, and the sums associate differently from sepconv_kernel (same terms, the
-// vertical sum is taken after the horizontal one): results agree to rounding, not bit for bit.
-// =========================================================================================
-template <int MT, int CQ, bool XP, bool RELU, int NS>
-__global__ __launch_bounds__(256, 2) void sepconv_rows_kernel(const float* __restrict__ in /*[B][CQr][HP][WP][4]*/, int Cin, int H, int W, int WP,
-                                                             const float* __restrict__ dw /*[CQr][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                             float* __restrict__ out, int tasks, int strips, int NR) {
-  static_assert(CQ % NS == 0, "the ring phase must repeat every row");
-  constexpr int R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
-  __shared__ float pw_s[CQ * 4 * 16 * MT];
-  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
-  const int lane = threadIdx.x & 63;
-  int bx, b;
-  xcd_remap(bx, b);
-  const int task = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));  // wave-uniform: the row loop and its offsets stay scalar
-  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 256) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
-  }
-  if (threadIdx.x < MT * 16) {
-    const int co = threadIdx.x;
-    sc_s[co] = co < Cout ? scale[co] : 0.0f;
-    sh_s[co] = co < Cout ? shift[co] : 0.0f;
-  }
-  __syncthreads();  // the only barrier
-  if (task >= tasks) return;
-  const int lk = lane >> 4, lj = lane & 15;
-  const int rb = task / strips, sx = task - rb * strips;
-  const int y0 = rb * NR, y1 = min(y0 + NR, H);
-  const int colbase = sx * VAL - lo;  // image column of lane 0 (even for the x-pooled variant: column parity = lane parity)
-  const int plane = (H + 2 * R) * WP;
-  const int CQo = (Cout + 3) >> 2, CQr = (Cin + 3) >> 2;
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQr * plane;
-  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
-  float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
-  const int dump = XP ? WPx - 1 : 0;
-  const float lo_out = relu_out ? 0.0f : -INFINITY;
-  // byte offset of this lane's pixel in padded row yp of a quad plane (clamped: only lanes whose outputs are discarded leave the plane)
-  auto row_off = [&](int yp) {
-    const int i = yp * WP + colbase + lane;
-    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
-  };
-  auto load_q = [&](int e, uint32_t off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)(e < CQr ? e : CQr - 1) * plane) + off);
-  };
-  float4 ring[NS];  // stream elements in flight
-  uint32_t off_cur = row_off(y0 - 1 + R), off_nxt = row_off(y0 + R);
-#pragma unroll
-  for (int e = 0; e < NS; ++e) ring[e] = load_q(e, off_cur);
-
-  f32x2 sa01[CQ], sa23[CQ], sb01[CQ], sb23[CQ];
-#pragma unroll
-  for (int cq = 0; cq < CQ; ++cq) { sa01[cq] = sa23[cq] = sb01[cq] = sb23[cq] = (f32x2){0.f, 0.f}; }
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // one arriving row: fold it into the open outputs; EMIT: out(r - 1) is complete -> contraction + epilogue for image row r - 1
-  auto arrive = [&](int r, auto emit_tag) {
-    constexpr bool EMIT = decltype(emit_tag)::value;
-#pragma unroll
-    for (int cq = 0; cq < CQ; ++cq) {
-      // the quad's 36 taps are fetched through the scalar cache HERE: an opaque offset per quad keeps the compiler from hoisting all
-      // CQ * 36 scalar loads to the top of the row (they do not fit the SGPR file and come back as v_readlane / v_writelane spills)
-      int opaque_zero = 0;
-      asm volatile("" : "+s"(opaque_zero));
-      const float* dww = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
-      const float4 a4 = ring[cq % NS];
-      {  // refill the slot with stream element cq + NS: a later quad of this row, or an early quad of the next row
-        const int e = cq + NS;
-        ring[cq % NS] = (e < CQ) ? load_q(e, off_cur) : load_q(e - CQ, off_nxt);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const f32x2 a01 = {RELU ? relu1(a4.x) : a4.x, RELU ? relu1(a4.y) : a4.y}, a23 = {RELU ? relu1(a4.z) : a4.z, RELU ? relu1(a4.w) : a4.w};
-      const f32x2 m01 = {lane_shift<-1>(a01.x), lane_shift<-1>(a01.y)}, m23 = {lane_shift<-1>(a23.x), lane_shift<-1>(a23.y)};  // a(x - 1)
-      const f32x2 p01 = {lane_shift<1>(a01.x), lane_shift<1>(a01.y)}, p23 = {lane_shift<1>(a23.x), lane_shift<1>(a23.y)};      // a(x + 1)
-      const float* wq = dww + (cq < CQr ? cq : CQr - 1) * 36;
-      auto hf = [&](int dy, f32x2 s01, f32x2 s23, f32x2& o01, f32x2& o23) {
-        const float* w = wq + dy * 12;
-        const f32x2 wl01 = {w[0], w[1]}, wl23 = {w[2], w[3]}, wc01 = {w[4], w[5]}, wc23 = {w[6], w[7]}, wr01 = {w[8], w[9]}, wr23 = {w[10], w[11]};
-        o01 = p01 * wr01 + (a01 * wc01 + (m01 * wl01 + s01));
-        o23 = p23 * wr23 + (a23 * wc23 + (m23 * wl23 + s23));
-      };
-      f32x2 d01, d23;
-      if constexpr (EMIT) hf(2, sa01[cq], sa23[cq], d01, d23);
-      hf(1, sb01[cq], sb23[cq], sa01[cq], sa23[cq]);
-      hf(0, (f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}, sb01[cq], sb23[cq]);
-      if constexpr (EMIT) {
-        float afrag[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
-        float d[4] = {d01.x, d01.y, d23.x, d23.y};
-        swap32(d[0], d[2]);
-        swap32(d[1], d[3]);
-        swap16(d[0], d[1]);
-        swap16(d[2], d[3]);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // one quad at a time: interleaving quads only raises the register pressure
-    }
-    if constexpr (EMIT) {
-      const int y = r - 1;  // image row of the finished outputs
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int wl = 16 * tt + lj;
-        const int x = colbase + wl;
-        const bool live = wl >= lo && wl < 64 - lo && x >= 0 && x < W && (!XP || (x & 1) == 0);
-        const bool pair_ok = x + 1 < W;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
-          float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[q] = max2(v[q], lo_out);
-            if (XP) {
-              const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[q]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
-              v[q] = max2(v[q], pair_ok ? other : v[q]);
-            }
-          }
-          const int oq = m * 4 + lk;
-          const bool ok = live && oq < CQo;
-          const int idx = XP ? ((oq * H + y) * WPx + (x >> 1)) : (oq * plane + (y + R) * WP + x);
-          const float4 val = (XP || ok) ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(reinterpret_cast<char*>(outb) + (uint32_t)(ok ? idx : dump) * 16u) = val;
-          acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // rows y0 - 1 and y0 open the first two outputs (nothing to emit yet); rows y0 + 1 .. y1 each complete one output row
-  arrive(y0 - 1, std::false_type{});
-  off_cur = off_nxt; off_nxt = row_off(y0 + 1 + R);
-  arrive(y0, std::false_type{});
-#pragma unroll 1
-  for (int r = y0 + 1; r <= y1; ++r) {
-    off_cur = off_nxt; off_nxt = row_off(r + 1 + R);
-    arrive(r, std::true_type{});
-  }
-}
-
-// =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
 // Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
 // (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
@@ -1407,28 +1248,6 @@ int g_stream_windows = 1;  // windows per wave of sepconv_stream_kernel; 0 = use
                            // bytes); with 2 the second window re-reads them one window-time later, after the XCD has streamed three times
                            // its L2 through, and FETCH_SIZE doubles at equal speed
 
-int g_rows_ring = 8;      // stream elements in flight per wave of sepconv_rows_kernel (4 or 8)
-int g_rows_per_wave = 0;  // > 0: two-output-tile k = 3 layers run sepconv_rows_kernel with this many image rows per wave (experiment, off)
-
-template <int MT, int CQ, int NS>
-int launch_sepconv_rows(hipStream_t st, const SepArgs& a) {
-  const int lo = a.out_layout == 2 ? 2 : 1, VAL = 64 - 2 * lo;
-  const int strips = (a.W + VAL - 1) / VAL;  // columns [0, W) only: the right pad is never an output
-  const int NR = g_rows_per_wave < a.H ? g_rows_per_wave : a.H;
-  const int tasks = strips * ((a.H + NR - 1) / NR);
-  dim3 grid((tasks + 3) / 4, a.B);
-#define ORCAI_ROWS_LAUNCH(XP, RELU)                                                                                                        \
-  hipLaunchKernelGGL((sepconv_rows_kernel<MT, CQ, XP, RELU, NS>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
-                     a.Cout, a.relu_out, a.out, tasks, strips, NR)
-  if (a.out_layout == 2) {
-    if (a.relu_in) ORCAI_ROWS_LAUNCH(true, true); else ORCAI_ROWS_LAUNCH(true, false);
-  } else {
-    if (a.relu_in) ORCAI_ROWS_LAUNCH(false, true); else ORCAI_ROWS_LAUNCH(false, false);
-  }
-#undef ORCAI_ROWS_LAUNCH
-  return (int)hipGetLastError();
-}
-
 template <int MT, int CQ, int NS>
 int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
   // windows per wave: the knob for two output tiles (block 1: one window keeps the row re-reads in L2); twice that for three and
@@ -1463,7 +1282,6 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
       // quads (orcai-V1 b2/sep_b, b3/sep_b: -9 % against the four-set kernel with 12 / 16 quads; at equal quad counts four sets win),
       // and for two output tiles, where they fit 96 VGPRs = five waves per SIMD (b1/sep_b -6 % against four sets at four waves)
       if constexpr (MT == 2) {
-        if (g_rows_per_wave > 0 && CQ > 4 && CQ <= 8) return g_rows_ring == 4 ? launch_sepconv_rows<2, 8, 4>(st, a) : launch_sepconv_rows<2, 8, 8>(st, a);
         if (CQ <= 4) return launch_sepconv_stream<2, 4, 2>(st, a, tasks);
         if (CQ <= 8) return launch_sepconv_stream<2, 8, 2>(st, a, tasks);
       } else if constexpr (MT == 3) {
@@ -1517,13 +1335,6 @@ int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 int orcai_entry_windows(int windows_per_wave) {
   const int prev = g_entry_windows;
   if (windows_per_wave >= 1 && windows_per_wave <= 64) g_entry_windows = windows_per_wave;
-  return prev;
-}
-
-int orcai_sepconv_rows(int rows_per_wave) {
-  const int prev = g_rows_per_wave;
-  if (rows_per_wave >= 0 && rows_per_wave <= 4096) g_rows_per_wave = rows_per_wave;
-  else if (rows_per_wave == -4 || rows_per_wave == -8) g_rows_ring = -rows_per_wave;  // experiment: ring depth
   return prev;
 }
 
