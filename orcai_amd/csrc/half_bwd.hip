@@ -332,19 +332,33 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
 }
 
 // ---------------------------------------------------------------- D[ca][cb] += sum_pixels A[ca][p] * Bq[cb][p]   (pointwise / residual weight gradients)
-// 256 pixels per pass go through LDS as [channel][pixel] f16 (pitch 264 halves = 132 dwords = 4 mod 64: the 16 channel rows of a
-// fragment read hit 16 distinct 16-byte bank slots), so that a lane's 16-byte LDS read is 8 consecutive PIXELS of one channel = one
-// operand fragment of v_mfma_f32_16x16x32_f16 with k = pixel.  Per-workgroup partial products + an add kernel (train_trunk.hip).
-constexpr int ORH_P = 264;
+// The contraction index is the PIXEL, but a 16-byte vector of the planes holds 8 channels of one pixel.  256 pixels per pass are staged
+// in LDS exactly as they arrive -- image [pixel][channel], one ds_write_b128 per octet -- and the MFMA operands are fetched with the
+// hardware transposing read ds_read_b64_tr_b16: a 16-lane group reads a block of 4 pixels x 16 channels and lane i receives channel
+// i's four pixels, so two reads give a lane the 8 consecutive pixels of one channel that v_mfma_f32_16x16x32_f16 wants with k = pixel
+// (the first version wrote the image transposed with eight 2-byte stores per octet: 1.15 ms per step for the 13 launches).
+// Row pitch = 16-byte multiple (16 channels per tile row + one 16-byte pad).  Per-workgroup partial products + an add kernel.
+typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ h16x8 tr_fragment(const h16* img, int pitch_h, int pix0, int col0, int lj) {
+  // block rows = pixels pix0 + {0..3} and pix0 + 4 + {0..3}, columns col0 .. col0 + 15; lane 4q + p of the group addresses row q, columns 4p..4p+3
+  const h16* a = img + (pix0 + (lj >> 2)) * pitch_h + col0 + 4 * (lj & 3);
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)a);
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * pitch_h));
+  typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+  const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(h16x8, both);
+}
 
 __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restrict__ A, int Ca, const h16* __restrict__ Bq, int Cb, int H, int W, int WP, int R, int B,
                                                               int a_mode, int Ha, int WPa, float* __restrict__ part, uint32_t magic_WP) {
   extern __shared__ __attribute__((aligned(16))) h16 smem_h[];
   const int COa = (Ca + 7) >> 3, COb = (Cb + 7) >> 3;
   const int MT = (Ca + 15) >> 4, NT = (Cb + 15) >> 4, ntile = MT * NT;
-  h16* As = smem_h;                      // [MT*16][ORH_P]
-  h16* Bs = smem_h + MT * 16 * ORH_P;    // [NT*16][ORH_P]
-  for (int i = threadIdx.x; i < (MT + NT) * 16 * ORH_P / 2; i += 256) reinterpret_cast<uint32_t*>(smem_h)[i] = 0u;
+  const int pa_h = MT * 16 + 8, pb_h = NT * 16 + 8;  // row pitches in halves (16-byte multiples)
+  h16* As = smem_h;                 // [256 pixels][pa_h]
+  h16* Bs = smem_h + 256 * pa_h;    // [256 pixels][pb_h]
+  for (int i = threadIdx.x; i < 256 * (pa_h + pb_h) / 2; i += 256) reinterpret_cast<uint32_t*>(smem_h)[i] = 0u;  // channel columns past C stay zero
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
   const int plane = (H + 2 * R) * WP;
@@ -367,27 +381,20 @@ __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restri
       pa = ain ? (2 * i + R) * WPa + 2 * x : 0;
     }
     __syncthreads();  // the previous pass's MFMA reads are done (and the zero fill is visible)
-    for (int q = 0; q < COa; ++q) {
-      const h16x8 v = ain ? reinterpret_cast<const h16x8*>(A)[((int64_t)b * COa + q) * plane_a + pa] : zero_h();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) As[(8 * q + e) * ORH_P + tid] = v[e];
-    }
-    for (int q = 0; q < COb; ++q) {
-      const h16x8 v = pin ? reinterpret_cast<const h16x8*>(Bq)[((int64_t)b * COb + q) * plane + p] : zero_h();
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Bs[(8 * q + e) * ORH_P + tid] = v[e];
-    }
+    for (int q = 0; q < COa; ++q)
+      *reinterpret_cast<h16x8*>(As + tid * pa_h + 8 * q) = ain ? reinterpret_cast<const h16x8*>(A)[((int64_t)b * COa + q) * plane_a + pa] : zero_h();
+    for (int q = 0; q < COb; ++q)
+      *reinterpret_cast<h16x8*>(Bs + tid * pb_h + 8 * q) = pin ? reinterpret_cast<const h16x8*>(Bq)[((int64_t)b * COb + q) * plane + p] : zero_h();
     __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const int tile = wave + 4 * ti;
-      if (tile < ntile) {  // wave-uniform
+      if (tile < ntile) {  // wave-uniform: EXEC stays all ones inside, as the transposing read requires
         const int mt = tile / NT, nt = tile - mt * NT;
-        const h16* ar = As + (mt * 16 + lj) * ORH_P + 8 * lk;  // A[row = ca][k = pixel 8 lk + e]
-        const h16* br = Bs + (nt * 16 + lj) * ORH_P + 8 * lk;  // B[k = pixel][col = cb]
         f32x4 c0 = acc[ti];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) c0 = mfma_h(*reinterpret_cast<const h16x8*>(ar + 32 * s), *reinterpret_cast<const h16x8*>(br + 32 * s), c0);
+        for (int s = 0; s < 8; ++s)  // A[row = ca][k = pixel 32 s + 8 lk + e], B[k = the same pixel][col = cb]
+          c0 = mfma_h(tr_fragment(As, pa_h, 32 * s + 8 * lk, 16 * mt, lj), tr_fragment(Bs, pb_h, 32 * s + 8 * lk, 16 * nt, lj), c0);
         acc[ti] = c0;
       }
     }
@@ -503,28 +510,28 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
 
 // ---------------------------------------------------------------- entry conv weight gradient with bn0 (+ReLU) backward on the fly
 // dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) is formed per pixel from (dy, v, sums) and consumed at once (never written).
-// Block (bx, cq): quad cq of the 16 entry channels = half (cq & 1) of octet (cq >> 1).
-template <int KS>
+// Block (bx, co): octet co of the 16 entry channels (8 x k x k accumulators per lane for k = 3; two blocks per octet for k = 5, 7).
+template <int KS, int NCH>
 __global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __restrict__ in, int64_t snippet_stride, const h16* __restrict__ dy,
                                                                 const h16* __restrict__ v /*[B][2][HP][WP][8]*/, int H, int W, int WP, int B,
                                                                 const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, const double* __restrict__ dbeta,
                                                                 const double* __restrict__ dgamma, float inv_count, float* __restrict__ dW /*[KS*KS][16]*/) {
-  constexpr int R = KS / 2, KK = KS * KS;
-  __shared__ float red[4][4 * KK];
+  constexpr int R = KS / 2, KK = KS * KS, PARTS = 8 / NCH;
+  __shared__ float red[4][NCH * KK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cq = blockIdx.y, co = cq >> 1, half = cq & 1;
+  const int co = blockIdx.y / PARTS, c0 = (blockIdx.y % PARTS) * NCH;
   const int plane = (H + 2 * R) * WP;
-  float mu[4], inv[4], g[4], bt[4], c1[4], c2[4];
+  float mu[NCH], inv[NCH], g[NCH], bt[NCH], c1[NCH], c2[NCH];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = cq * 4 + k;
+  for (int k = 0; k < NCH; ++k) {
+    const int c = co * 8 + c0 + k;
     mu[k] = mean[c]; inv[k] = rsqrtf(var[c] + eps); g[k] = gamma[c]; bt[k] = beta[c];
     c1[k] = (float)dbeta[c] * inv_count; c2[k] = (float)dgamma[c] * inv_count;
   }
-  float acc[4][KK];
+  float acc[NCH][KK];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
   const int total = H * W;
@@ -533,12 +540,12 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __re
     const int64_t base = ((int64_t)b * 2 + co) * plane;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
       const int y = p / W, x = p - y * W;
-      const O8 d8 = ld8(dy, base + (y + R) * WP + x), v8 = ld8(v, base + (y + R) * WP + x);
-      float gq[4];
+      const h16x8 d8 = reinterpret_cast<const h16x8*>(dy)[base + (y + R) * WP + x], v8 = reinterpret_cast<const h16x8*>(v)[base + (y + R) * WP + x];
+      float gq[NCH];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float xh = (v8.v[4 * half + k] - mu[k]) * inv[k];
-        const float de = (fmaf(xh, g[k], bt[k]) > 0.0f) ? d8.v[4 * half + k] : 0.0f;
+      for (int k = 0; k < NCH; ++k) {
+        const float xh = ((float)v8[c0 + k] - mu[k]) * inv[k];
+        const float de = (fmaf(xh, g[k], bt[k]) > 0.0f) ? (float)d8[c0 + k] : 0.0f;
         gq[k] = g[k] * inv[k] * (de - c1[k] - xh * c2[k]);
       }
 #pragma unroll
@@ -548,12 +555,12 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __re
           const int yy = y + dyy - R, xx = x + dx - R;
           const float a = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[yy * W + xx] : 0.0f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j][dyy * KS + dx] = fmaf(a, gq[j], acc[j][dyy * KS + dx]);
+          for (int j = 0; j < NCH; ++j) acc[j][dyy * KS + dx] = fmaf(a, gq[j], acc[j][dyy * KS + dx]);
         }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       float s2 = acc[j][t];
@@ -562,9 +569,9 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __re
       if (lane == 0) red[wave][j * KK + t] = s2;
     }
   __syncthreads();
-  if (threadIdx.x < 4 * KK) {
+  if (threadIdx.x < NCH * KK) {
     const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
-    atomicAdd(&dW[t * 16 + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    atomicAdd(&dW[t * 16 + co * 8 + c0 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
 }
 
@@ -740,7 +747,7 @@ int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, i
                          int64_t workspace_floats, void* stream) {
   if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0 || workspace_floats < (int64_t)Ca * Cb) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
-  const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * ORH_P * sizeof(h16);
+  const size_t lds = (size_t)256 * (((Ca + 15) / 16) * 16 + 8 + ((Cb + 15) / 16) * 16 + 8) * sizeof(h16);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)outer_reduce_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -794,11 +801,11 @@ int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy
   double* dg = scratch2C + 8 * CO;
   hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, 1, db, dg);
   const float inv_count = (float)(1.0 / ((double)B * H * W));
-  dim3 grid(256, 4);
+  dim3 grid(256, ksize == 3 ? 2 : 4);  // k = 3: one block column per octet; k = 5, 7: per half octet (accumulator registers)
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
-    case 5: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
-    case 7: hipLaunchKernelGGL(conv0_bn_wgrad_h_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 3: hipLaunchKernelGGL((conv0_bn_wgrad_h_kernel<3, 8>), grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 5: hipLaunchKernelGGL((conv0_bn_wgrad_h_kernel<5, 4>), grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
+    case 7: hipLaunchKernelGGL((conv0_bn_wgrad_h_kernel<7, 4>), grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);

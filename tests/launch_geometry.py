@@ -196,7 +196,9 @@ def outer_reduce(B, Ca, Cb, H, W, k, a_stride2=False, Ha=0, Wa=0, workspace_floa
     for cg in (0, CGb - 1):
         t.add("B", (b * CGb + cg) * plane + p, pin)
     t.add("workspace", np.array([0, grid * Ca * Cb - 1]))
-    return t.r, {"grid": grid, "lds_bytes": ((Ca + 15) // 16 + (Cb + 15) // 16) * 16 * (258 * 4 if G == 4 else 264 * 2)}
+    tiles = (Ca + 15) // 16 + (Cb + 15) // 16
+    lds = tiles * 16 * 258 * 4 if G == 4 else 256 * (tiles * 16 + 16) * 2  # f32: [channel][pixel] image; f16: [pixel][channel] image
+    return t.r, {"grid": grid, "lds_bytes": lds}
 
 
 # ------------------------------------------------------------------------------------------------ dw_wgrad_kernel<KS>
