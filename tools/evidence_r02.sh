@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-2 evidence: the bench lines, rocprofv3 kernel-trace statistics of the same commands, and the PMC passes (FETCH_SIZE / WRITE_SIZE /
+# MFMA counters, each in its own run, never combined with a trace domain other than --kernel-trace).  Outputs under gpurun_out/ev2.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/ev2
+rm -rf $O && mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_predict.json 2> $O/bench_predict.err && echo bench-predict-ok && \
+python3 $R/bench.py --workload frontend > $O/bench_frontend.json 2> $O/bench_frontend.err && echo bench-frontend-ok && \
+python3 $R/bench.py --workload train > $O/bench_train.json 2> $O/bench_train.err && echo bench-train-ok && \
+python3 $R/bench.py --workload hpsearch --steps 10 --warmup 3 > $O/bench_hpsearch.json 2> $O/bench_hpsearch.err && echo bench-hpsearch-ok && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_predict -- python3 $R/bench.py > $O/prof_predict.log 2>&1 && echo predict-trace-ok && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --workload train --no-cpu-baseline > $O/prof_train.log 2>&1 && echo train-trace-ok && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_frontend -- python3 $R/bench.py --workload frontend --no-cpu-baseline > $O/prof_frontend.log 2>&1 && echo frontend-trace-ok && \
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_hpsearch -- python3 $R/bench.py --workload hpsearch --steps 10 --warmup 3 --no-cpu-baseline --no-loss-curves > $O/prof_hpsearch.log 2>&1 && echo hpsearch-trace-ok && \
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_fetch.log 2>&1 && echo fetch-ok && \
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_write.log 2>&1 && echo write-ok && \
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_mfma.log 2>&1 && echo mfma-ok && \
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_fe -- python3 $R/bench.py --workload frontend --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_fe.log 2>&1 && \
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_fe -- python3 $R/bench.py --workload frontend --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_fe.log 2>&1 && echo fe-pmc-ok && \
+ORCAI_HPS_VARIANTS=set3 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_h -- python3 $R/bench.py --workload hpsearch --steps 1 --warmup 1 --no-cpu-baseline --no-loss-curves > $O/pmc_fetch_h.log 2>&1 && \
+ORCAI_HPS_VARIANTS=set3 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_h -- python3 $R/bench.py --workload hpsearch --steps 1 --warmup 1 --no-cpu-baseline --no-loss-curves > $O/pmc_write_h.log 2>&1 && echo hps-pmc-ok
+for d in predict train frontend hpsearch; do f=$(find $O/prof_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${d}_kernel_stats.csv; done
+# the raw kernel traces are large: keep the statistics and the counter collections only
+find $O -name "*kernel_trace.csv" -path "*prof_*" -delete
+du -sh $O

@@ -11,7 +11,27 @@ import sys
 from collections import defaultdict
 
 
+_DEMANGLED = {}
+
+
+def demangle(name: str) -> str:
+    """rocprofv3 leaves symbols with _Float16 parameters mangled: run them through llvm-cxxfilt when it is there."""
+    if not name.startswith("_Z"):
+        return name
+    if name not in _DEMANGLED:
+        import shutil
+        import subprocess
+
+        tool = shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+        try:
+            _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, check=True).stdout.strip() or name
+        except (OSError, subprocess.CalledProcessError):
+            _DEMANGLED[name] = name
+    return _DEMANGLED[name]
+
+
 def short(name: str) -> str:
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([\w:]+(<[^>(]*>)?)", name)
