@@ -135,6 +135,17 @@ except ImportError:
     pass
 
 
+def _reduce(dist, t, op):
+    """all_reduce of a small device tensor: in place over RCCL; staged through the host for the gloo rehearsal backend."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t, op=op)
+        return t
+    h = t.cpu()
+    dist.all_reduce(h, op=op)
+    t.copy_(h)
+    return t
+
+
 def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     """BASELINE.json's metric has a second half -- training snippets/s at 1/2/4/8 GPUs -- that a single JSON line cannot carry as
     `value`.  After the headline measurement every rank also times the training step (configs[3]: batch 64 per GPU, data parallel,
@@ -150,7 +161,7 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
         ok, err = 0, repr(e)
     if dist:
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _reduce(dist, flag, dist.ReduceOp.MIN)
         ok = int(flag.item())
     if not ok:
         return {"metric": "snippets_per_s", "error": err or "the probe step failed on another rank"}
@@ -170,7 +181,7 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = {"metric": tw.metric, "value": round(tw.units_per_step * steps * world / elapsed, 1), "unit": tw.unit, "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": tw.dtype, "data": "synthetic",
@@ -179,12 +190,12 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     if dist:  # the one collective of the step, alone: all-reduce of the flat gradient bucket (3.98 MB for orcai-V1) over RCCL / xGMI
         g = tw.trainer.P.g
         for _ in range(3):
-            dist.all_reduce(g)
+            _reduce(dist, g, dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
         for _ in range(20):
-            dist.all_reduce(g)
+            _reduce(dist, g, dist.ReduceOp.SUM)
         torch.cuda.synchronize()
         out["allreduce_us"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
         out["allreduce_bytes"] = int(g.numel() * 4)
@@ -210,7 +221,7 @@ def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
         ok, err = 0, repr(e)
     if dist:
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _reduce(dist, flag, dist.ReduceOp.MIN)
         ok = int(flag.item())
     if not ok:
         return {"metric": "snippets_per_s", "error": err or "the probe step failed on another rank"}
@@ -230,7 +241,7 @@ def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = {"metric": hw.metric, "value": round(hw.units_per_step * steps * world / elapsed, 1), "unit": hw.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": hw.dtype, "data": "synthetic",
@@ -249,6 +260,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the training-throughput measurement attached to the predict line")
     ap.add_argument("--no-loss-curves", action="store_true", help="hpsearch workload: skip the 200-step f16-vs-f32 loss comparison")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1; gloo + --one-device rehearses the multi-rank control flow on a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (never a measurement)")
     ap.add_argument("--curve-steps", type=int, default=200)
     args = ap.parse_args()
 
@@ -257,6 +271,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -264,7 +280,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload](device, rank)
     if hasattr(wl, "events"):
@@ -285,7 +304,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     secondary = None

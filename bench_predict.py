@@ -328,8 +328,8 @@ class TrainWorkload:
         out["step_tflops"] = round(flops / (ms * 1e-3) / 1e12, 2)
         # where the time goes: two more steps with every launcher bracketed (outside the timed region; the brackets slow the step)
         self.timed.mode, self.timed.events = "all", {}
-        for _ in range(2):
-            self.trainer.train_step(self.x, 736 * 171, self.B, self.y, world_size=self.world)
+        for _ in range(2):  # rank-local instrumentation: NO collective here (only rank 0 calls roofline(); an all-reduce would wait for ever)
+            self.trainer.train_step(self.x, 736 * 171, self.B, self.y, world_size=1)
         torch.cuda.synchronize()
         per = {k: sum(a.elapsed_time(b) for a, b, _ in v) / 2 for k, v in self.timed.events.items()}
         out["launcher_ms_per_step_instrumented"] = {k: round(v, 3) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]}
