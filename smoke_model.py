@@ -48,3 +48,9 @@ def run() -> None:
     gerr = float(np.abs(g - gref).max())
     assert gerr <= 5e-4 * max(1e-3, float(np.abs(gref).max())), gerr
     print(f"smoke: training step loss {loss:.6f} vs autograd oracle {ref['loss']:.6f}; d loss / d conv0 kernel max|delta| = {gerr:.2e}")
+    # the f16 path (BASELINE configs[4]) on the same small network: forward against the fp32 oracle
+    half = ResNetLSTM(cfg["input_shape"], 3, [10, 20], 3, 0.0, 64, precision="f16")
+    half.set_weights_dict(p)
+    herr = float(np.abs(half.predict(x) - M.forward_ref(p, x)).max())
+    assert herr <= 5e-3, herr
+    print(f"smoke: f16 path forward max|delta p| vs fp32 oracle = {herr:.2e}")
