@@ -138,9 +138,15 @@ __global__ __launch_bounds__(256) void sepconv_h_kernel(const h16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  h16x8 nxt[KS];
+  // register pipeline two octets deep (as sepconv_kernel of the f32 path): the rows of octets o + 1 and o + 2 are in flight while
+  // octet o is being processed
+  h16x8 nxt[KS], nx2[KS];
 #pragma unroll
   for (int dy = 0; dy < KS; ++dy) nxt[dy] = src[ridx[dy]];
+  if (CO > 1) {
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) nx2[dy] = src[plane + ridx[dy]];
+  }
   const int urow = (int)__umulhi((uint32_t)q, magic_WP);
   const bool u_live = u_out && lane >= lo && lane < 64 - lo && (q - urow * WP) < W && urow < R + H;
 
@@ -152,11 +158,11 @@ __global__ __launch_bounds__(256) void sepconv_h_kernel(const h16* __restrict__ 
       if (o < CO) {  // wave-uniform
         h16x8 cur[KS];
 #pragma unroll
-        for (int dy = 0; dy < KS; ++dy) cur[dy] = nxt[dy];
-        if (o + 1 < CO) {
-          const h16x8* pn = src + (int64_t)(o + 1) * plane;
+        for (int dy = 0; dy < KS; ++dy) { cur[dy] = nxt[dy]; nxt[dy] = nx2[dy]; }
+        if (o + 2 < CO) {
+          const h16x8* pn = src + (int64_t)(o + 2) * plane;
 #pragma unroll
-          for (int dy = 0; dy < KS; ++dy) nxt[dy] = pn[ridx[dy]];
+          for (int dy = 0; dy < KS; ++dy) nx2[dy] = pn[ridx[dy]];
         }
         const h16x8 dd = relu_in ? dw_octet<KS, true>(cur, dw + (int64_t)o * KK * 8) : dw_octet<KS, false>(cur, dw + (int64_t)o * KK * 8);
         if (u_live) reinterpret_cast<h16x8*>(u_out)[((int64_t)b * CO + o) * plane + q] = dd;
