@@ -327,6 +327,16 @@ int orcai_feat_to_planes(const float* f, int B, int C, int H, int W, int ksize, 
 /* dx = (y > 0) ? dy : 0 on whole plane buffers (n_floats % 4 == 0) */
 int orcai_planes_relu_bwd(const float* dy, const float* y, int64_t n_floats, float* dx, void* stream);
 
+/* Step state in DEVICE memory, so that a whole training step can be captured into a hipGraph and replayed (kernel arguments are baked
+ * into a captured graph; what changes from step to step must be read from memory):
+ *   counter          uint64[1], the number of optimisation steps applied so far; orcai_counter_advance adds 1 at the end of a step;
+ *   orcai_dropout_mask_dev   as orcai_dropout_mask with seed = seed_add + counter[0] * 0xD1B54A32D192ED03;
+ *   orcai_adam_step_dev      as orcai_adam_step with step = counter[0] + 1 and the learning rate lr[0] (callbacks change it between steps). */
+int orcai_dropout_mask_dev(float* mask, int64_t n, const uint64_t* counter, uint64_t seed_add, float keep, void* stream);
+int orcai_adam_step_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
+                        void* stream);
+int orcai_counter_advance(uint64_t* counter, void* stream);
+
 /* Keras LSTM variables <-> the gate-column order of the recurrence kernels (orcai_lstm_recurrent), on the device, once per training
  * step (replaces the per-step framework index / cat / stack kernels; architectures.py:210-229 define the variables).
  * orcai_pack_lstm: desc int32[n_desc][7] = {src offset in w (floats), dst offset (elements), rows, units, ld_dst, col_off, mode};

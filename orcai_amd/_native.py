@@ -95,6 +95,9 @@ _SIGNATURES = {
     "orcai_h_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_h_feat_to_planes": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "orcai_h_planes_relu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
+    "orcai_dropout_mask_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
+    "orcai_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
+    "orcai_counter_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orcai_pack_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_unpack_lstm_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),

@@ -382,6 +382,44 @@ __global__ __launch_bounds__(256) void bce_grad_kernel(const float* __restrict__
   dz[i] = g * grad_scale;  // grad_scale: static loss scale of the f16 path (1 otherwise)
 }
 
+// The same mask with its seed taken from DEVICE memory: seed = seed_add + counter[0] * golden ratio.  A captured hipGraph bakes kernel
+// arguments in, so the per-step part of the seed (and Adam's step number below) must live in a buffer the graph reads at replay time.
+__global__ __launch_bounds__(256) void dropout_mask_dev_kernel(float* __restrict__ mask, int64_t n, const uint64_t* __restrict__ counter, uint64_t seed_add,
+                                                                float keep) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t seed = seed_add + counter[0] * 0xD1B54A32D192ED03ull;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  mask[i] = u < keep ? 1.0f : 0.0f;
+}
+
+// Adam with the step number and the learning rate read from device memory (step = counter[0] + 1): alpha is formed once per block.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        const float* __restrict__ lr, float b1, float b2, float eps, const uint64_t* __restrict__ counter, float gscale) {
+  __shared__ float alpha_s;
+  if (threadIdx.x == 0) {
+    const double t = (double)(counter[0] + 1);
+    alpha_s = (float)((double)lr[0] * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+  const float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+  m[i] = mi;
+  v[i] = vi;
+  w[i] = w[i] - alpha_s * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void counter_advance_kernel(uint64_t* counter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1;
+}
+
 // sum of squares (L2 penalty value): out += lambda * sum w^2
 __global__ __launch_bounds__(256) void l2_value_kernel(const float* __restrict__ w, int64_t n, float lambda, double* __restrict__ out) {
   __shared__ double s[256];
@@ -797,6 +835,25 @@ int orcai_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* 
 int orcai_dropout_mask(float* mask, int64_t n, uint64_t seed, float keep, void* stream) {
   if (!mask || n <= 0) return ORCAI_E_BADARG;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, keep);
+  return (int)hipGetLastError();
+}
+
+int orcai_dropout_mask_dev(float* mask, int64_t n, const uint64_t* counter, uint64_t seed_add, float keep, void* stream) {
+  if (!mask || !counter || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(dropout_mask_dev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, counter, seed_add, keep);
+  return (int)hipGetLastError();
+}
+
+int orcai_adam_step_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
+                        void* stream) {
+  if (!w || !g || !m || !v || !lr || !counter || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr, b1, b2, eps, counter, gscale);
+  return (int)hipGetLastError();
+}
+
+int orcai_counter_advance(uint64_t* counter, void* stream) {
+  if (!counter) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
   return (int)hipGetLastError();
 }
 

@@ -676,11 +676,25 @@ class Trainer:
         self.conv1d = getattr(model, "architecture", "") == "ResNet1DConv"
         self.head = Conv1DHeadTrainer(model, self.P) if self.conv1d else HeadTrainer(model, self.P, half=self.half, grad_scale=self.grad_scale)
         self.skipped = torch.zeros(1, dtype=torch.int64, device=self.dev)  # f16 path: steps whose gradients overflowed (zeroed, counted)
+        # Step state the kernels read from DEVICE memory (so that a captured hipGraph of the step stays valid from replay to replay):
+        # the number of applied steps (dropout seeds, Adam's bias correction) and the learning rate (callbacks change it between steps)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.lr = float(learning_rate)
         self.step_count = 0
         self.seed = int(seed)
         self.rank = 0
+        self._graph = None
         self.broadcast_parameters()
+
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        self._lr = float(value)
+        self.lr_dev.fill_(self._lr)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Data parallel replicas must START from the same weights (the reference's MirroredStrategy creates the variables once and
@@ -718,8 +732,8 @@ class Trainer:
             todo = [("drop1", (n, T, 2 * self.model.lstm_units)), ("drop2", (n, T, 2 * self.model.lstm_units)), ("drop3", (n, T, DENSE_UNITS))]
         for idx, (j, shape) in enumerate(todo):
             mk = torch.empty(shape, dtype=torch.float32, device=self.dev)
-            seed = (self.seed * 1000003 + self.rank * 0x9E3779B1 + self.step_count * 16 + idx + 1) & 0xFFFFFFFFFFFFFFFF
-            N.check(lib.orcai_dropout_mask(mk.data_ptr(), mk.numel(), seed, 1.0 - rate, st), "dropout_mask")
+            seed = (self.seed * 1000003 + self.rank * 0x9E3779B1 + idx + 1) & 0xFFFFFFFFFFFFFFFF  # + the step counter, on the device
+            N.check(lib.orcai_dropout_mask_dev(mk.data_ptr(), mk.numel(), self.counter.data_ptr(), seed, 1.0 - rate, st), "dropout_mask")
             out[j] = mk
         return out
 
@@ -752,8 +766,11 @@ class Trainer:
             ok = torch.isfinite(self.P.g).all()
             self.P.g.copy_(torch.where(ok, self.P.g, torch.zeros_like(self.P.g)))
             self.skipped += (~ok).to(torch.int64)
-        adam_step(self.P, self.lr, self.step_count, gscale=1.0 / (world_size * self.grad_scale))
+        P, st = self.P, N.stream_ptr()
+        N.check(N.lib().orcai_adam_step_dev(P.w.data_ptr(), P.g.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.n_trainable, self.lr_dev.data_ptr(), 0.9, 0.999, 1e-7,
+                                            self.counter.data_ptr(), 1.0 / (world_size * self.grad_scale), st), "adam_step_dev")
         self.P.ema_all(BN_MOMENTUM)  # every BatchNorm's moving statistics in one launch
+        N.check(N.lib().orcai_counter_advance(self.counter.data_ptr(), st), "counter_advance")
 
     def sync_model(self) -> None:
         """Copy the flat device parameters (and BN moving statistics) back into the model object (for predict / save)."""
@@ -768,8 +785,39 @@ class Trainer:
         for k, t in s["stats"].items():
             self.P.stats[k].copy_(t)
         self.step_count, self.lr = s["step"], s["lr"]
+        self.counter.fill_(int(self.step_count))
 
     def train_step(self, src, snippet_stride, B, labels, world_size: int = 1, loss_weight=None) -> dict:
         out = self.forward_backward(src, snippet_stride, B, labels, loss_weight=loss_weight)
         self.apply(world_size)
         return out
+
+    def train_step_graphed(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor) -> dict:
+        """The whole single-GPU step -- dropout masks, forward, loss, backward, Adam, moving statistics, step counter -- as ONE
+        hipGraph: captured on the first call for this batch geometry (after two eager warm-up steps that size every workspace),
+        replayed afterwards on the batch copied into the graph's input buffers.  The C ABI's promise (nothing allocates, frees or
+        synchronises; include/orcai_hip.h) is what makes the capture legal; what changes per step lives in device memory
+        (self.counter, self.lr_dev).  Returns the graph's output tensors: valid until the next replay."""
+        key = (int(snippet_stride), int(B), tuple(labels.shape))
+        if self._graph is None or self._graph["key"] != key:
+            x_in = src[: (B - 1) * snippet_stride + self.model.input_hw[0] * self.model.input_hw[1]].clone()
+            y_in = labels.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up: allocate workspaces, instantiate kernels (hipFuncSetAttribute and friends happen here)
+                    self.train_step(x_in, snippet_stride, B, y_in)
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    out = self.train_step(x_in, snippet_stride, B, y_in)
+            torch.cuda.current_stream().wait_stream(side)
+            # the warm-up and the capture pass each advanced the host mirror of the step counter; only the two warm-up steps ran
+            self.step_count -= 1
+            self._graph = {"key": key, "graph": g, "x": x_in, "y": y_in, "out": out}
+        G = self._graph
+        G["x"].copy_(src[: G["x"].numel()])
+        G["y"].copy_(labels)
+        G["graph"].replay()
+        self.step_count += 1
+        return G["out"]
