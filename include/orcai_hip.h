@@ -126,6 +126,12 @@ int orcai_padded_width(int W, int ksize);
  * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_stream_windows(int windows_per_wave);
 
+/* Second knob for the same launcher: 1 (default) = planes at least two 64-column strips wide with two output tiles (Cout in 17..32)
+ * and <= 8 input quads run on the LDS-tile variant (sepconv_tile_kernel: a workgroup owns 8 image rows x 64 columns, the tile's 10
+ * input rows per quad are fetched once by LDS-DMA and shared by its 8 waves; it also stores the depthwise output of the training
+ * forward); 0 = never.  Same arithmetic in the same order, bit-identical results.  Returns the previous value; other values only query. */
+int orcai_sepconv_tile_mode(int mode);
+
 /* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current
  * one is computed).  Returns the previous value; values outside [1, 64] only query. */
 int orcai_entry_windows(int windows_per_wave);

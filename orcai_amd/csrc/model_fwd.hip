@@ -717,6 +717,146 @@ __global__ __launch_bounds__(256, MT <= 2 ? (NS == 2 ? 5 : 4) : (MT == 3 ? (NS =
 }
 
 // =========================================================================================
+// sepconv_tile: the arithmetic of sepconv_kernel<3, MT> / sepconv_stream_kernel with the window rows shared through LDS, for planes
+// several windows wide (block 1).  A workgroup of TR waves owns a 2-D tile of TR image rows x 64 columns (one row per wave); per
+// input quad the tile's TR + 2 rows are fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
+// lane-linear in LDS, no VGPR destination) into one of two slots, and every wave reads its three rows back with ds_read_b128.
+// L1 sees TR + 2 row requests per quad and tile instead of the 3 TR of independent windows -- the L1 fill path is the busiest
+// unit of the one-window kernels -- and with no row registers the kernel fits 64 VGPRs = 8 waves per SIMD.
+// One raw s_barrier per quad; the DMA of the next quad is issued right behind it (asm-issued, so the compiler's wait bookkeeping
+// neither sees nor drains it; the wait in front of the barrier is a counted vmcnt that leaves the depthwise-output store of the
+// training forward outstanding).  Ring depths of 3 and 4 slots measured equal to 2: the other 7 waves of the SIMD cover the latency.
+// Same fma chains in the same order as the other two kernels: bit-identical results.
+// =========================================================================================
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {  // this wave's DMAs of the current quad have landed -> everybody's have after the barrier
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT>
+__global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+                                                             const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                             float* __restrict__ out, int nstrip, float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/) {
+  constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  static_assert(TR == 4 || TR == 8, "rows (= waves) per workgroup");
+  static_assert(!(XP && UOUT), "the training forward writes planes");
+  __shared__ __attribute__((aligned(16))) float rows_s[2][TR + 2][256];  // [slot][tile row][lane][4]
+  __shared__ float pw_s[CQ * 4 * 16 * MT];                               // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
+  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int rg = bx / nstrip, strip = bx - rg * nstrip;  // strips of a row group are neighbours in launch order: halo rows and columns hit L2
+  const int r0 = rg * TR, c0 = strip * VAL;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int CQo = (Cout + 3) >> 2;
+  const int CQr = (Cin + 3) >> 2;  // real input quads (<= CQ; the launcher picks CQ = 4 or 8)
+  const char* src = reinterpret_cast<const char*>(in) + (int64_t)b * CQr * plane * 16;
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
+
+  // tile row j (0 .. TR+1) is padded-plane row r0 + j; this wave fetches row `wave`, waves 0 and 1 also rows TR and TR + 1.
+  // Offsets are clamped into the quad plane: only lanes / rows whose outputs are discarded can leave it.
+  auto goff = [&](int j) {
+    const int i = (r0 + j) * WP + c0 - lo + lane;
+    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+  };
+  const uint32_t off0 = goff(wave), off1 = goff(TR + (wave & 1));
+  const uint32_t lds0 = (uint32_t)(uintptr_t)&rows_s[0][0][0];
+  const bool two = wave < 2;
+  auto issue = [&](int e) {
+    const char* base = src + (int64_t)e * plane * 16;
+    const uint32_t slot = lds0 + (uint32_t)((e & 1) * (TR + 2) * 1024);
+    glds16(base + off0, slot + (uint32_t)wave * 1024u);
+    if (two) glds16(base + off1, slot + (uint32_t)(TR + wave) * 1024u);
+  };
+  issue(0);
+
+  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 64 * TR) {
+    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
+  }
+  if (threadIdx.x < MT * 16) {
+    const int co = threadIdx.x;
+    sc_s[co] = co < Cout ? scale[co] : 0.0f;
+    sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  __syncthreads();
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+  const int row = r0 + wave;  // this wave's image row
+  const int xl = c0 - lo + lane;
+  const bool u_live = UOUT && lane >= lo && lane < 64 - lo && xl < W && row < H;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int cq = 0; cq < CQ; ++cq) {
+    if (cq < CQr) {  // workgroup-uniform
+      // outstanding, oldest first: the DMA(s) of quad cq, then (UOUT, cq > 0, a wave on an image row: lane `lo` is always live, so
+      // the store was issued) the depthwise-output store of quad cq - 1, which may stay in flight
+      if (UOUT && cq > 0 && row < H) wait_vm_barrier<1>(); else wait_vm_barrier<0>();
+      if (cq + 1 < CQr) issue(cq + 1);  // into the slot every wave finished reading before this barrier
+      float4 rows[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&rows_s[cq & 1][wave + dy][lane * 4]);
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
+      float d[4];
+      dw_quad_impl<3, RELU>(rows, dw + cq * 4 * KK, d);
+      if (UOUT) {
+        if (u_live) reinterpret_cast<float4*>(u_out)[((int64_t)b * CQr + cq) * plane + (R + row) * WP + xl] = make_float4(d[0], d[1], d[2], d[3]);
+      }
+      swap32(d[0], d[2]);
+      swap32(d[1], d[3]);
+      swap16(d[0], d[1]);
+      swap16(d[2], d[3]);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
+    }
+  }
+  // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> tile column 16*tt + lj]
+  if (row >= H) return;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int wl = 16 * tt + lj;
+    const int x = c0 - lo + wl;
+    const bool live = wl >= lo && wl < 64 - lo && x < W && (!XP || (x & 1) == 0);
+    const bool pair_ok = x + 1 < W;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
+      float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = max2(v[r], lo_out);
+        if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
+          const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+          v[r] = max2(v[r], pair_ok ? other : v[r]);
+        }
+      }
+      const int oq = m * 4 + lk;
+      if (live && oq < CQo) {
+        const int idx = XP ? ((oq * H + row) * WPx + (x >> 1)) : (oq * plane + (R + row) * WP + x);
+        outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
 // Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
 // (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
@@ -1266,6 +1406,27 @@ int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
   return (int)hipGetLastError();
 }
 
+int g_tile_mode = 1;  // 1: sepconv_tile_kernel where it applies (two output tiles, <= 8 input quads, planes >= 2 strips wide that the
+                      // 64-column strips cover with <= 15 % waste); 0: never
+
+template <int MT, int CQ>
+int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
+  constexpr int TR = 8;
+  dim3 grid(nstrip * ((a.H + TR - 1) / TR), a.B);
+#define ORCAI_TILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
+  hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
+                     a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
+  if (a.out_layout == 2) {
+    if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
+  } else if (a.u_out) {
+    if (a.relu_in) ORCAI_TILE_LAUNCH(false, true, true); else ORCAI_TILE_LAUNCH(false, false, true);
+  } else {
+    if (a.relu_in) ORCAI_TILE_LAUNCH(false, true, false); else ORCAI_TILE_LAUNCH(false, false, false);
+  }
+#undef ORCAI_TILE_LAUNCH
+  return (int)hipGetLastError();
+}
+
 template <int KS, int MT>
 int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   const int lo = (a.out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
@@ -1274,6 +1435,12 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
   if constexpr (KS == 3 && MT >= 2) {
     const int CQ = (a.Cin + 3) / 4, CQo = (a.Cout + 3) / 4, Wx = (a.W + 1) / 2;
+    if constexpr (MT == 2) {  // wide planes (block 1): rows shared through LDS
+      const int VALt = a.out_layout == 2 ? 60 : 62, nstrip = (a.W + VALt - 1) / VALt;
+      if (g_tile_mode && a.RP == 1 && CQ <= 8 && (a.out_layout == 2 || a.out_layout == 0) && !(a.u_out && a.out_layout != 0) && nstrip >= 2 &&
+          a.W * 100 >= nstrip * VALt * 85 && (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 27))
+        return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
+    }
     const bool shape_ok = a.RP == 1 && !a.u_out && ((uintptr_t)a.dw & 15) == 0 && (a.out_layout == 0 || (a.out_layout == 2 && ((Wx + 3) & ~3) > Wx)) &&
                           (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 28);
     if (g_stream_windows > 0 && shape_ok) {  // the kernel is instantiated for the quad count rounded up to a multiple of 4
@@ -1335,6 +1502,12 @@ int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 int orcai_entry_windows(int windows_per_wave) {
   const int prev = g_entry_windows;
   if (windows_per_wave >= 1 && windows_per_wave <= 64) g_entry_windows = windows_per_wave;
+  return prev;
+}
+
+int orcai_sepconv_tile_mode(int mode) {
+  const int prev = g_tile_mode;
+  if (mode == 0 || mode == 1) g_tile_mode = mode;
   return prev;
 }
 

@@ -192,8 +192,9 @@ def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, re
     Wx = (W + 1) // 2
     oshape = (B, CQo, H + 2, WP, 4) if layout == 0 else (B, CQo, H, (Wx + 3) // 4 * 4, 4)
 
-    def run(nw):
+    def run(nw, tile=0):
         prev = lib.orcai_sepconv_stream_windows(nw)
+        prev_tile = lib.orcai_sepconv_tile_mode(tile)
         try:
             out = torch.zeros(oshape, device=dev)
             rc = lib.orcai_sepconv_bn(N.ptr(planes), B, Cin, H, W, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, relu_out, layout,
@@ -203,15 +204,53 @@ def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, re
             return out
         finally:
             lib.orcai_sepconv_stream_windows(prev)
+            lib.orcai_sepconv_tile_mode(prev_tile)
 
     ref = run(0)
     assert float(ref.abs().max()) > 0
-    for nw in (1, 2, 5):
-        out = run(nw)
+    for nw, tile in ((1, 0), (2, 0), (5, 0), (1, 1), (0, 1)):  # tile: the LDS-tile variant where the launcher picks it (two output tiles, wide planes)
+        out = run(nw, tile)
         if layout == 0:
-            assert torch.equal(out, ref), nw
+            assert torch.equal(out, ref), (nw, tile)
         else:  # padding columns of the x-pooled buffer are never read and may hold anything
-            assert torch.equal(out[:, :, :, :Wx], ref[:, :, :, :Wx]), nw
+            assert torch.equal(out[:, :, :, :Wx], ref[:, :, :, :Wx]), (nw, tile)
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,relu_in", [(16, 30, 736, 171, 0), (30, 30, 736, 171, 1), (29, 32, 33, 118, 1), (9, 17, 5, 130, 0)])
+def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in):
+    """Training forward (the depthwise output u is stored next to the pre-BN output): the LDS-tile kernel against sepconv_kernel,
+    both tensors equal bit for bit, pads of both stay zero."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(Cin * 100 + Cout)
+    B, CQ, CQo, WP = 2, (Cin + 3) // 4, (Cout + 3) // 4, lib.orcai_padded_width(W, 3)
+    x = torch.zeros(B, CQ * 4, H + 2, WP)
+    x[:, :Cin, 1:H + 1, :W] = torch.randn(B, Cin, H, W, generator=g)
+    planes = x.view(B, CQ, 4, H + 2, WP).permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    dw = torch.randn(CQ, 9, 4, generator=g).to(dev)
+    pw = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    scale, shift = torch.ones(Cout).to(dev), torch.randn(Cout, generator=g).to(dev)
+
+    def run(tile):
+        prev = lib.orcai_sepconv_tile_mode(tile)
+        try:
+            out = torch.zeros((B, CQo, H + 2, WP, 4), device=dev)
+            u = torch.zeros((B, CQ, H + 2, WP, 4), device=dev)
+            rc = lib.orcai_sepconv_planes_u(N.ptr(planes), B, Cin, H, W, 3, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, 0, 0, 0, 0,
+                                            N.ptr(out), N.ptr(u), N.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            return out, u
+        finally:
+            lib.orcai_sepconv_tile_mode(prev)
+
+    ref, uref = run(0)
+    out, u = run(1)
+    assert float(uref.abs().max()) > 0 and float(ref.abs().max()) > 0
+    assert torch.equal(out, ref) and torch.equal(u, uref)
+    assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])

@@ -1,5 +1,6 @@
 """A/B of the streaming separable-conv variant against the one-window-per-wave kernel: bit equality of the model output and
-per-layer times (HIP events) on the same spectrogram.  usage: ab_stream.py [seconds] [chunk] [nw ...]"""
+per-layer times (HIP events) on the same spectrogram.  usage: ab_stream.py [seconds] [chunk] [nw ...]
+A value >= 100 runs (value - 100) windows per wave with the LDS-tile variant switched off (the default has it on)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +20,8 @@ model.prepare()
 lib = N.lib()
 ref = None
 for nw in nws + [nws[0]]:
-    lib.orcai_sepconv_stream_windows(nw)
+    lib.orcai_sepconv_stream_windows(nw - 100 if nw >= 100 else nw)
+    lib.orcai_sepconv_tile_mode(0 if nw >= 100 else 1)
     for it in range(3):
         model.kernel_events = {}
         pred = model.predict_spectrogram(spec, chunk=chunk)
