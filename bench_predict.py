@@ -120,19 +120,21 @@ class PredictWorkload:
         if blk in couts and op in ("sep_a", "sep_b"):
             cin, cout = (cins[blk] if op == "sep_a" else couts[blk]), couts[blk]
             mt, cqr = (cout + 15) // 16, (cin + 3) // 4
-            ns = 2 if mt == 2 or (mt, cqr) in ((4, 13), (4, 14)) or (mt == 3 and cqr in (9, 10) and op == "sep_b") else 4  # row sets (launch_sepconv_impl)
-            cq = (cqr + ns - 1) // ns * ns
-            wx = (widths[blk] + 1) // 2
-            streams = N.lib().orcai_sepconv_stream_windows(-1) > 0 and mt >= 2 and cq <= {2: 8, 3: 12, 4: 16}[mt] and (op == "sep_a" or (wx + 3) // 4 * 4 > wx)
-            if streams:  # streaming variant <MT, input quads rounded up to the row-set count, x-pooled output, ReLU on load, row sets>
-                return f"sepconv_stream_kernel<{mt}, {cq}, {'true' if op == 'sep_b' else 'false'}, {'true' if op == 'sep_a' else 'false'}, {ns}>"
+            mode = N.lib().orcai_sepconv_tile_mode(-1)
+            xp, relu = ("true", "false") if op == "sep_b" else ("false", "true")  # sep_b: x-pooled output; sep_a: ReLU on load
+            val = 60 if op == "sep_b" else 62
+            nstrip = -(-widths[blk] // val)
+            if mode == 1 and mt == 2 and cqr <= 8 and nstrip >= 2 and widths[blk] * 100 >= nstrip * val * 85:  # launch_sepconv_impl's rule
+                return f"sepconv_tile_kernel<2, {4 if cqr <= 4 else 8}, {xp}, {relu}, 8, false>"
+            if mode >= 1:
+                return f"sepconv_ftile_kernel<{mt}, {xp}, {relu}, false, 8>"
             return f"sepconv_kernel<3, {mt}>"
         if blk in couts and op == "pool_res":
             return f"pool_res_add_kernel<{(couts[blk] + 15) // 16}>"
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
-    # (sepconv_stream_kernel<2, 8, true, false, 2>) is the top symbol of rocprofv3 --stats for this workload
+    # (sepconv_tile_kernel<2, 8, true, false, 8, false>) is the top symbol of rocprofv3 --stats for this workload
     DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
 
     def roofline(self):
@@ -214,9 +216,10 @@ class PredictWorkload:
 
 class _TimedLib:
     """Wraps the ctypes library handle of a trainer (bench instrumentation only; the product path calls the handle directly).
-    mode "dominant": only the launches of the step's dominant kernel symbol, sepconv_kernel<3, 2> (the four block-1 separable-conv
-    passes), are bracketed by HIP events on the launch stream -- an event pair costs ~15 us of queue time, and a training step has
-    ~300 short launches, so bracketing all of them would slow the step by 20 %.  mode "all": every orcai_* launcher (used for two
+    mode "dominant": only the launches of the step's dominant kernel symbol -- outer_reduce_kernel, the pointwise / residual weight
+    gradients (13 launches per step), the top row of rocprofv3 --stats since the block-1 separable convolutions moved to the LDS-tile
+    kernels -- are bracketed by HIP events on the launch stream: an event pair costs ~15 us of queue time, and a training step has
+    ~250 short launches, so bracketing all of them would slow the step by 20 %.  mode "all": every orcai_* launcher (used for two
     extra steps AFTER the timed region to report where the time goes)."""
 
     def __init__(self, lib, is_dominant=None):
@@ -226,11 +229,7 @@ class _TimedLib:
 
     @staticmethod
     def is_dominant(name, args):
-        if not (name == "orcai_sepconv_planes_u" and args[6] == 3 and (args[12] + 15) // 16 == 2):  # ktap 3, ceil(Cout/16) = 2
-            return False
-        # ... and not one of the launches the launcher hands to sepconv_stream_kernel (no depthwise-output store, plane or x-pooled
-        # output, 4 or 8 input quads), which rocprofv3 lists under another symbol
-        return bool(args[18]) or args[14] not in (0, 2) or (args[2] + 3) // 4 not in (4, 8)
+        return name == "orcai_outer_reduce"
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -310,17 +309,18 @@ class TrainWorkload:
             self.ev.append((e0, e1))
 
     def roofline(self):
-        """Dominant kernel symbol of the training step (sepconv_kernel<3, 2>, as rocprofv3 --stats ranks it): average launch duration
-        from HIP events around its launches inside the timed steps; achieved = algorithmic bytes per launch / that duration."""
+        """Dominant kernel symbol of the training step (outer_reduce_kernel, as rocprofv3 --stats ranks it): average launch duration
+        from HIP events around its launches inside the timed steps (a bracket also covers the launcher's 3-5 us add_partials_kernel);
+        achieved = algorithmic bytes per launch (both operands read once at their true channel count) / that duration."""
         ms = float(np.mean([a.elapsed_time(b) for a, b in self.ev]))
         n_steps = len(self.ev)
-        calls = (self.timed.events or {}).get("orcai_sepconv_planes_u", [])
+        calls = (self.timed.events or {}).get("orcai_outer_reduce", [])
         out = {}
         if calls:
             t = sum(a.elapsed_time(b) for a, b, _ in calls)
-            by = sum(_train_call_bytes("orcai_sepconv_planes_u", args) for _, _, args in calls)
+            by = sum(_train_call_bytes("orcai_outer_reduce", args) for _, _, args in calls)
             ach = by / (t * 1e-3) / 1e9
-            out = {"bound": "hbm", "kernel": "sepconv_kernel<3, 2>", "layers": "separable convs of the step with 17..32 output channels that keep the depthwise output or have 10 input quads: block 1 forward (2), block 2 input gradient (1)",
+            out = {"bound": "hbm", "kernel": "outer_reduce_kernel", "layers": "pointwise and residual-conv weight gradients of the step (13 launches: final conv, 4 blocks x (residual, sep_b, sep_a))",
                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                    "kernel_ms": round(t / len(calls), 4), "launches_per_step": len(calls) // max(1, n_steps), "algorithmic_bytes_per_launch": round(by / len(calls))}
         flops = 3.0 * FWD_FLOP_PER_SNIPPET * self.B  # fwd + bwd ~ 3x forward (SURVEY 8a row C5)

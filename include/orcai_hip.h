@@ -120,16 +120,13 @@ int orcai_make_spectrogram(const float* pcm, int64_t n_samples, int n_fft, int h
  * never write the pads, so "same" zero padding costs no bounds checks and every tile halo is one contiguous run. */
 int orcai_padded_width(int W, int ksize);
 
-/* Tuning knob of the separable-conv launcher: windows per wave of the streaming variant (sepconv_stream_kernel, used for
- * k = 3, Cout in 17..64, Cin <= 16*ceil(Cout/16), plane or x-pooled output, no depthwise-output store); 0 selects the
- * one-window-per-wave kernel everywhere.  Both variants perform the same arithmetic in the same order (bit-identical
- * results).  Returns the previous value; values outside [0, 64] only query.  Process-wide, not thread-safe. */
-int orcai_sepconv_stream_windows(int windows_per_wave);
-
-/* Second knob for the same launcher: 1 (default) = planes at least two 64-column strips wide with two output tiles (Cout in 17..32)
- * and <= 8 input quads run on the LDS-tile variant (sepconv_tile_kernel: a workgroup owns 8 image rows x 64 columns, the tile's 10
- * input rows per quad are fetched once by LDS-DMA and shared by its 8 waves; it also stores the depthwise output of the training
- * forward); 0 = never.  Same arithmetic in the same order, bit-identical results.  Returns the previous value; other values only query. */
+/* Knob of the separable-conv launcher for k = 3 launches with plane or x-pooled output (the inference trunk, the training forward
+ * with its depthwise-output store, the input-gradient passes).  1 (default): the LDS-shared-row kernels -- sepconv_tile_kernel (a
+ * workgroup of 8 waves owns 8 image rows x 64 columns; the tile's 10 input rows per channel quad are fetched once by LDS-DMA) for
+ * planes at least two strips wide with Cout in 17..32 and <= 8 input quads, sepconv_ftile_kernel (8 consecutive windows of the flat
+ * plane share one contiguous range of rows) for the rest; 2: sepconv_ftile_kernel for all of them; 0: the one-window-per-wave
+ * sepconv_kernel everywhere.  All three perform the same arithmetic in the same order (bit-identical results).  Returns the previous
+ * value; values outside [0, 2] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_tile_mode(int mode);
 
 /* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current

@@ -547,177 +547,7 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 }
 
 // =========================================================================================
-// sepconv_stream: the same arithmetic as sepconv_kernel<3, MT> for the layers that dominate inference (k = 3, plane or
-// x-pooled output, CQ input quads with CQ % 4 == 0), organised so that a wave's output stores drain while it is already
-// computing its next window.  Measured on sepconv_kernel: a wave holds its slot until its stores are acknowledged, so kernel
-// time was (loads + arithmetic) + writes.  Here one wave walks NW consecutive windows as ONE linear
-// stream of (window, quad) elements with the rows of the next three elements always in flight in four rotating register sets
-// (CQ % 4 == 0 keeps the rotation phase equal at every window boundary, so no register copies of in-flight loads).  vmcnt
-// retires in order on gfx9, so the epilogue's stores sit between the next window's first three row loads and its fourth:
-// the waits for quads 0..2 of the next window leave the stores outstanding (vmcnt(9 + S)), only quad 3's wait drains them.
-// Every memory instruction of the steady state is unconditional -- dead lanes store zeros to a padding pixel, the stream
-// tail re-loads clamped rows, the prologue issues S dummy stores -- so that the compiler's wait-count bookkeeping sees one
-// straight-line body whose entry state equals its back-edge state and emits exact partial waits instead of vmcnt(0).
-// Pointwise weights and the folded BN scale/shift come from LDS (no global load behind the row prefetches).
-// =========================================================================================
-template <int MT, int CQ, bool XP, bool RELU, int NS>
-__global__ __launch_bounds__(256, MT <= 2 ? (NS == 2 ? 5 : 4) : (MT == 3 ? (NS == 2 ? 4 : 3) : (NS == 2 ? 3 : 2))) void sepconv_stream_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
-                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
-                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                              float* __restrict__ out, int tasks, uint32_t magic_WP, int NW) {
-  static_assert((NS == 2 || NS == 4) && CQ % NS == 0 && CQ >= NS, "NS rotating row sets: the rotation phase must be equal at every window boundary");
-  constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
-  __shared__ float pw_s[CQ * 4 * 16 * MT];  // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
-  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
-  const int lane = threadIdx.x & 63;
-  int bx, b;
-  xcd_remap(bx, b);
-  // window w of this wave is task t0 + 4w: the four waves of a workgroup advance side by side through 4*NW consecutive
-  // windows, so vertically adjacent windows are in flight at the same time on one CU (row re-reads hit L1/L2 while hot)
-  const int t0 = bx * 4 * NW + (threadIdx.x >> 6);
-  const int lk = lane >> 4, lj = lane & 15;
-  const int plane = (H + 2 * R) * WP;
-  const int CQo = (Cout + 3) >> 2;
-  const int CQr = (Cin + 3) >> 2;  // real input quads; CQ - CQr < 4 dummy quads (zero pointwise weights, rows of the last quad re-read)
-  const float4* src = reinterpret_cast<const float4*>(in) + (int64_t)b * CQr * plane;
-  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
-  float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
-  const int dump = XP ? WPx - 1 : 0;  // a padding pixel of the snippet's first output plane (zero before and after)
-
-  // byte offsets of the three window rows inside a quad plane (clamped: only lanes whose outputs are discarded can leave
-  // the plane); 32-bit, so a load is "uniform quad base + lane offset" and needs one address register
-  auto row_index = [&](int t, uint32_t (&ri)[3]) {
-    const int q = R * WP + t * VAL - lo + lane;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int i = q + (dy - 1) * WP;
-      ri[dy] = (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
-    }
-  };
-  // DERIVE (x-pooled two-output-tile instantiations, which run at five waves per SIMD = 96 VGPRs): keep only the centre row's flat
-  // pixel per window and derive the three offsets at each load (a few VALU) instead of holding 3 + 3 offset registers, and compute
-  // the next window's pixel where it is first needed.  The other instantiations allocate better with the offsets precomputed.
-  constexpr bool DERIVE = MT == 2 && XP;
-  auto derived_offset = [&](int q, int dy) {
-    const int i = q + (dy - 1) * WP;
-    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
-  };
-  auto load_row = [&](int e, uint32_t off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src + (int64_t)(e < CQr ? e : CQr - 1) * plane) + off);
-  };
-
-  // The first three stream elements are requested before the LDS fill: the fill's own loads are younger, so its wait
-  // retires these too and the loop is entered with nothing outstanding (the state the steady-state wait counts assume).
-  float4 rows[NS][3];  // NS - 1 stream elements in flight
-  uint32_t rc[3];
-  row_index(min(t0, tasks - 1), rc);
-  int qc = R * WP + min(t0, tasks - 1) * VAL - lo + lane;  // DERIVE: this window's centre-row pixel
-#pragma unroll
-  for (int e = 0; e < NS - 1; ++e)
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) rows[e][dy] = load_row(e, DERIVE ? derived_offset(qc, dy) : rc[dy]);
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 256) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
-  }
-  if (threadIdx.x < MT * 16) {
-    const int co = threadIdx.x;
-    sc_s[co] = co < Cout ? scale[co] : 0.0f;
-    sh_s[co] = co < Cout ? shift[co] : 0.0f;
-  }
-  __syncthreads();  // the only barrier; waves are independent from here on
-  if (t0 >= tasks) return;
-  const int nw = min(NW, (tasks - t0 + 3) >> 2);
-  const float lo_out = relu_out ? 0.0f : -INFINITY;
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 1
-  for (int w = 0; w < nw; ++w) {
-    const int t = t0 + 4 * w;
-    uint32_t rn[3];
-    if (!DERIVE) row_index(min(t + 4, tasks - 1), rn);
-    int qn = 0;
-    // the depthwise taps are re-read through the scalar cache every window: hoisted out of this loop, the CQ*36 scalars do
-    // not fit the SGPR file and come back as one v_readlane per tap
-    int opaque_zero = 0;
-    asm volatile("" : "+s"(opaque_zero));
-    const float* dww = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
-#pragma unroll
-    for (int cq = 0; cq < CQ; ++cq) {
-      {  // stream element cq + NS - 1: a quad of this window, or one of the next window's first NS - 1 quads
-        const int e = cq + NS - 1;
-        if (DERIVE && e == CQ) qn = R * WP + min(t + 4, tasks - 1) * VAL - lo + lane;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          if constexpr (DERIVE) rows[e % NS][dy] = (e < CQ) ? load_row(e, derived_offset(qc, dy)) : load_row(e - CQ, derived_offset(qn, dy));
-          else rows[e % NS][dy] = (e < CQ) ? load_row(e, rc[dy]) : load_row(e - CQ, rn[dy]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // the row loads are issued before any of the quad's arithmetic
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
-      float d[4];
-      dw_quad_impl<3, RELU>(rows[cq % NS], dww + (cq < CQr ? cq : CQr - 1) * 4 * KK, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
-    }
-    // ---- epilogue (see sepconv_kernel): D[row = 4*lk + r -> cout][col = lj -> pixel 16*tt + lj of the window]
-    // Written for VALU issue: single-instruction max, the column pair through a DPP quad permute, folded BN from LDS.
-    const int qbase = R * WP + t * VAL - lo;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int wl = 16 * tt + lj;
-      const int flat = qbase + wl;
-      const int row = (int)__umulhi((uint32_t)flat, magic_WP);
-      const int x = flat - row * WP;
-      const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H && (!XP || (x & 1) == 0);
-      const bool pair_ok = x + 1 < W;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
-        float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = max2(v[r], lo_out);
-          if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
-            const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
-            v[r] = max2(v[r], pair_ok ? other : v[r]);
-          }
-        }
-        const int oq = m * 4 + lk;
-        const bool ok = live && oq < CQo;
-        const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
-        // dead lanes: zeros to the padding pixel (plane output) / anything to the never-read padding column (x-pooled output)
-        const float4 val = (XP || ok) ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(outb) + (uint32_t)(ok ? idx : dump) * 16u) = val;
-        acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DERIVE) qc = qn;
-    else {
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) rc[dy] = rn[dy];
-    }
-  }
-}
-
-// =========================================================================================
-// sepconv_tile: the arithmetic of sepconv_kernel<3, MT> / sepconv_stream_kernel with the window rows shared through LDS, for planes
+// sepconv_tile: the arithmetic of sepconv_kernel<3, MT> with the window rows shared through LDS, for planes
 // several windows wide (block 1).  A workgroup of TR waves owns a 2-D tile of TR image rows x 64 columns (one row per wave); per
 // input quad the tile's TR + 2 rows are fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
 // lane-linear in LDS, no VGPR destination) into one of two slots, and every wave reads its three rows back with ds_read_b128.
@@ -850,6 +680,145 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
       const int oq = m * 4 + lk;
       if (live && oq < CQo) {
         const int idx = XP ? ((oq * H + row) * WPx + (x >> 1)) : (oq * plane + (R + row) * WP + x);
+        outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// =========================================================================================
+// sepconv_ftile: the LDS-shared rows of sepconv_tile for ANY plane width.  The NWV waves of a workgroup own NWV consecutive 64-pixel
+// windows of the flat padded plane (the mapping of sepconv_kernel: no strip waste on narrow planes); the rows above and below are
+// the same flat range shifted by -WP / +WP, so the three rows of all NWV windows are ONE contiguous range of
+// (NWV - 1) * VAL + 64 + 2 * WP pixels, fetched once per quad by LDS-DMA in 1-KiB chunks (chunk c by wave c % NWV) -- 14 chunks for
+// 8 windows of a 176-pixel-wide plane, 8 chunks at width 44, against 24 row loads of independent windows.  Input quads are a run-time
+// count (no dummy quads).  Two LDS slots, one raw barrier per quad, waits as in sepconv_tile.  Bit-identical to sepconv_kernel<3, MT>.
+// =========================================================================================
+template <int MT, bool XP, bool RELU, bool UOUT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
+                                                               const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                               float* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk,
+                                                               float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/) {
+  constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  static_assert(!(XP && UOUT), "the training forward writes planes");
+  extern __shared__ __attribute__((aligned(16))) float smem_ft[];
+  const int CQr = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
+  float* rows_s = smem_ft;                      // [2][nchunk][64][4]
+  float* pw_s = smem_ft + 2 * nchunk * 256;     // [(ci * 16 + lj)][m]
+  float* sc_s = pw_s + CQr * 64 * MT;           // [MT * 16]
+  float* sh_s = sc_s + MT * 16;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const char* src = reinterpret_cast<const char*>(in) + (int64_t)b * CQr * plane * 16;
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float4* outb = reinterpret_cast<float4*>(out) + (XP ? (int64_t)b * CQo * H * WPx : (int64_t)b * CQo * plane);
+
+  // flat pixel of LDS position 0: lane 0 of the workgroup's first window, one row up (R * WP + first * VAL - lo - WP with R = 1)
+  const int s0 = bx * NWV * VAL - lo;
+  auto goff = [&](int c) {  // clamped into the quad plane: only lanes whose outputs are discarded can leave it
+    const int i = s0 + 64 * c + lane;
+    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+  };
+  const uint32_t off0 = goff(wave), off1 = goff(wave + NWV), off2 = goff(wave + 2 * NWV);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)rows_s;
+  const int mine = wave < nchunk ? (wave + NWV < nchunk ? (wave + 2 * NWV < nchunk ? 3 : 2) : 1) : 0;  // chunks this wave fetches (wave-uniform)
+  auto issue = [&](int e) {
+    const char* base = src + (int64_t)e * plane * 16;
+    const uint32_t slot = lds0 + (uint32_t)((e & 1) * nchunk * 1024);
+    if (mine > 0) glds16(base + off0, slot + (uint32_t)wave * 1024u);
+    if (mine > 1) glds16(base + off1, slot + (uint32_t)(wave + NWV) * 1024u);
+    if (mine > 2) glds16(base + off2, slot + (uint32_t)(wave + 2 * NWV) * 1024u);
+  };
+  issue(0);
+
+  for (int i = threadIdx.x; i < CQr * 64 * MT; i += 64 * NWV) {
+    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
+  }
+  if (threadIdx.x < MT * 16) {
+    const int co = threadIdx.x;
+    sc_s[co] = co < Cout ? scale[co] : 0.0f;
+    sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  __syncthreads();
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+  const int task = bx * NWV + wave;
+  const bool wave_live = task < tasks;
+  const int qbase = R * WP + task * VAL - lo;  // flat padded-plane pixel of lane 0 of this wave's window
+  const int q = qbase + lane;
+  bool u_live = false;
+  if (UOUT) {
+    const int urow = (int)__umulhi((uint32_t)q, magic_WP);
+    const int ux = q - urow * WP;
+    u_live = wave_live && lane >= lo && lane < 64 - lo && ux < W && urow < R + H;
+  }
+  // (wave_live: the window starts inside the image rows, so its lane `lo` ... not necessarily on an image column: the store may be
+  // skipped by a whole wave whose live lanes all sit in the padding columns -> such waves wait for vmcnt(0), see below)
+  const bool u_any = UOUT && __builtin_amdgcn_readfirstlane((int)(__ballot(u_live) != 0ull)) != 0;
+  const float* rbase = rows_s + (wave * VAL + lane) * 4;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+  for (int cq = 0; cq < CQr; ++cq) {
+    // outstanding, oldest first: this wave's DMAs of quad cq, then (UOUT, cq > 0, a wave that stores) the depthwise-output store of
+    // quad cq - 1, which may stay in flight
+    if (u_any && cq > 0) wait_vm_barrier<1>(); else wait_vm_barrier<0>();
+    if (cq + 1 < CQr) issue(cq + 1);  // into the slot every wave finished reading before this barrier
+    const float* rs = rbase + (cq & 1) * nchunk * 256;
+    float4 rows[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(rs + dy * WP * 4);
+    float afrag[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
+    float d[4];
+    dw_quad_impl<3, RELU>(rows, dw + cq * 4 * KK, d);
+    if (UOUT) {
+      if (u_live) reinterpret_cast<float4*>(u_out)[((int64_t)b * CQr + cq) * plane + q] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
+  }
+  // ---- epilogue (see sepconv_kernel): D[row = 4*lk + r -> cout][col = lj -> pixel 16*tt + lj of the window]
+  if (!wave_live) return;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int wl = 16 * tt + lj;
+    const int flat = qbase + wl;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+    const int x = flat - row * WP;
+    const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H && (!XP || (x & 1) == 0);
+    const bool pair_ok = x + 1 < W;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
+      float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = max2(v[r], lo_out);
+        if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
+          const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+          v[r] = max2(v[r], pair_ok ? other : v[r]);
+        }
+      }
+      const int oq = m * 4 + lk;
+      if (live && oq < CQo) {
+        const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
         outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
@@ -1383,31 +1352,9 @@ struct SepArgs {
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
-int g_stream_windows = 1;  // windows per wave of sepconv_stream_kernel; 0 = use sepconv_kernel everywhere.  1: rows re-read by vertically
-                           // adjacent windows are requested at the same time by neighbouring waves and hit L2 (PMC: FETCH_SIZE = input
-                           // bytes); with 2 the second window re-reads them one window-time later, after the XCD has streamed three times
-                           // its L2 through, and FETCH_SIZE doubles at equal speed
-
-template <int MT, int CQ, int NS>
-int launch_sepconv_stream(hipStream_t st, const SepArgs& a, int tasks) {
-  // windows per wave: the knob for two output tiles (block 1: one window keeps the row re-reads in L2); twice that for three and
-  // four tiles, whose planes are small (b2/sep_b -5 %, b3/sep_b -10 % with two windows)
-  const int NW = g_stream_windows * (MT >= 3 ? 2 : 1);
-  dim3 grid((tasks + 4 * NW - 1) / (4 * NW), a.B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
-#define ORCAI_STREAM_LAUNCH(XP, RELU)                                                                                                 \
-  hipLaunchKernelGGL((sepconv_stream_kernel<MT, CQ, XP, RELU, NS>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift, \
-                     a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), NW)
-  if (a.out_layout == 2) {
-    if (a.relu_in) ORCAI_STREAM_LAUNCH(true, true); else ORCAI_STREAM_LAUNCH(true, false);
-  } else {
-    if (a.relu_in) ORCAI_STREAM_LAUNCH(false, true); else ORCAI_STREAM_LAUNCH(false, false);
-  }
-#undef ORCAI_STREAM_LAUNCH
-  return (int)hipGetLastError();
-}
-
-int g_tile_mode = 1;  // 1: sepconv_tile_kernel where it applies (two output tiles, <= 8 input quads, planes >= 2 strips wide that the
-                      // 64-column strips cover with <= 15 % waste); 0: never
+int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
+                      // >= 2 strips that cover the width with <= 15 % waste) and sepconv_ftile_kernel otherwise; 2 = sepconv_ftile_kernel for
+                      // all of them; 0 = sepconv_kernel everywhere (the reference the bit-identity tests compare with)
 
 template <int MT, int CQ>
 int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
@@ -1427,39 +1374,49 @@ int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
   return (int)hipGetLastError();
 }
 
+template <int MT>
+int launch_sepconv_ftile(hipStream_t st, const SepArgs& a, int tasks) {
+  constexpr int NWV = 8;
+  const int lo = a.out_layout == 2 ? 2 : 1, VAL = 64 - 2 * lo;
+  const int nchunk = ((NWV - 1) * VAL + 64 + 2 * a.WP + 63) / 64;
+  const int CQr = (a.Cin + 3) / 4;
+  const size_t lds = (size_t)(2 * nchunk * 256 + CQr * 64 * MT + 2 * MT * 16) * sizeof(float);
+  if (nchunk > 3 * NWV || lds > 64 * 1024) return -1;  // planes wider than ~500 pixels: not this kernel's shape, the caller falls back
+  dim3 grid((tasks + NWV - 1) / NWV, a.B);
+#define ORCAI_FTILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
+  hipLaunchKernelGGL((sepconv_ftile_kernel<MT, XP, RELU, UOUT, NWV>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
+                     a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
+  if (a.out_layout == 2) {
+    if (a.relu_in) ORCAI_FTILE_LAUNCH(true, true, false); else ORCAI_FTILE_LAUNCH(true, false, false);
+  } else if (a.u_out) {
+    if (a.relu_in) ORCAI_FTILE_LAUNCH(false, true, true); else ORCAI_FTILE_LAUNCH(false, false, true);
+  } else {
+    if (a.relu_in) ORCAI_FTILE_LAUNCH(false, true, false); else ORCAI_FTILE_LAUNCH(false, false, false);
+  }
+#undef ORCAI_FTILE_LAUNCH
+  return (int)hipGetLastError();
+}
+
 template <int KS, int MT>
 int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
   const int lo = (a.out_layout == 2) ? ((KS / 2 + 1) & ~1) : KS / 2;  // x-pooled output: windows start on an even pixel
   const int VAL = 64 - 2 * lo;
   const int tasks = (a.H * a.WP + VAL - 1) / VAL;  // 64-pixel windows covering the H image rows of a plane
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
-  if constexpr (KS == 3 && MT >= 2) {
-    const int CQ = (a.Cin + 3) / 4, CQo = (a.Cout + 3) / 4, Wx = (a.W + 1) / 2;
-    if constexpr (MT == 2) {  // wide planes (block 1): rows shared through LDS
-      const int VALt = a.out_layout == 2 ? 60 : 62, nstrip = (a.W + VALt - 1) / VALt;
-      if (g_tile_mode && a.RP == 1 && CQ <= 8 && (a.out_layout == 2 || a.out_layout == 0) && !(a.u_out && a.out_layout != 0) && nstrip >= 2 &&
-          a.W * 100 >= nstrip * VALt * 85 && (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 27))
-        return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
-    }
-    const bool shape_ok = a.RP == 1 && !a.u_out && ((uintptr_t)a.dw & 15) == 0 && (a.out_layout == 0 || (a.out_layout == 2 && ((Wx + 3) & ~3) > Wx)) &&
-                          (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 28);
-    if (g_stream_windows > 0 && shape_ok) {  // the kernel is instantiated for the quad count rounded up to a multiple of 4
-      // <MT, quads rounded up to a multiple of NS, NS row sets>: four sets = three quads in flight.  Two sets (one quad in flight,
-      // 24 VGPRs fewer: one more wave per SIMD at three / four output tiles) where they save two dummy quads: 10 and 13-14 input
-      // quads (orcai-V1 b2/sep_b, b3/sep_b: -9 % against the four-set kernel with 12 / 16 quads; at equal quad counts four sets win),
-      // and for two output tiles, where they fit 96 VGPRs = five waves per SIMD (b1/sep_b -6 % against four sets at four waves)
+  if constexpr (KS == 3) {
+    // k = 3, plane or x-pooled output (optionally with the depthwise-output store of the training forward): the LDS-shared-row kernels.
+    // Wide planes with two output tiles (orcai-V1 block 1) take the 2-D strip tiles, which fetch 10 rows per 8 windows; everything else
+    // the flat-range tiles (b1/sep_b: strip 3.3 ms, flat 3.45 ms per 611 snippets; the one-window kernels 3.8 ms).
+    const int CQ = (a.Cin + 3) / 4, CQo = (a.Cout + 3) / 4;
+    if (g_tile_mode && a.RP == 1 && (a.out_layout == 0 || (a.out_layout == 2 && !a.u_out)) && (int64_t)CQo * (a.H + 2) * a.WP < (1ll << 27) &&
+        (int64_t)CQ * (a.H + 2) * a.WP < (1ll << 27)) {
       if constexpr (MT == 2) {
-        if (CQ <= 4) return launch_sepconv_stream<2, 4, 2>(st, a, tasks);
-        if (CQ <= 8) return launch_sepconv_stream<2, 8, 2>(st, a, tasks);
-      } else if constexpr (MT == 3) {
-        if (CQ > 4 && CQ <= 8) return launch_sepconv_stream<3, 8, 4>(st, a, tasks);
-        if (CQ > 8 && CQ <= 10 && a.out_layout == 2 && !a.relu_in) return launch_sepconv_stream<3, 10, 2>(st, a, tasks);  // (its other variants spill)
-        if (CQ > 10 && CQ <= 12) return launch_sepconv_stream<3, 12, 4>(st, a, tasks);
-      } else {
-        if (CQ > 8 && CQ <= 12) return launch_sepconv_stream<4, 12, 4>(st, a, tasks);
-        if (CQ > 12 && CQ <= 14) return launch_sepconv_stream<4, 14, 2>(st, a, tasks);
-        if (CQ > 14 && CQ <= 16) return launch_sepconv_stream<4, 16, 4>(st, a, tasks);
+        const int VALt = a.out_layout == 2 ? 60 : 62, nstrip = (a.W + VALt - 1) / VALt;
+        if (g_tile_mode == 1 && CQ <= 8 && nstrip >= 2 && a.W * 100 >= nstrip * VALt * 85)
+          return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
       }
+      const int rc = launch_sepconv_ftile<MT>(st, a, tasks);
+      if (rc >= 0) return rc;
     }
   }
   dim3 grid((tasks + 3) / 4, a.B);
@@ -1507,13 +1464,7 @@ int orcai_entry_windows(int windows_per_wave) {
 
 int orcai_sepconv_tile_mode(int mode) {
   const int prev = g_tile_mode;
-  if (mode == 0 || mode == 1) g_tile_mode = mode;
-  return prev;
-}
-
-int orcai_sepconv_stream_windows(int windows_per_wave) {
-  const int prev = g_stream_windows;
-  if (windows_per_wave >= 0 && windows_per_wave <= 64) g_stream_windows = windows_per_wave;
+  if (mode >= 0 && mode <= 2) g_tile_mode = mode;
   return prev;
 }
 

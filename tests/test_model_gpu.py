@@ -165,18 +165,21 @@ def test_resnet_1dconv_forward(input_shape, filters, k):
     (16, 30, 736, 171, 0, 1, 1),   # orcai-V1 b1/sep_a
     (30, 30, 736, 171, 2, 0, 0),   # orcai-V1 b1/sep_b (x-pooled output, odd W)
     (13, 17, 9, 70, 0, 0, 1),      # ragged channels, few rows (tail windows), window crossing rows
-    (32, 32, 5, 64, 2, 1, 0),      # even W; Wx % 4 == 0 -> no padding column -> must fall back to the one-window kernel
+    (32, 32, 5, 64, 2, 1, 0),      # even W; Wx % 4 == 0 -> the x-pooled buffer has no padding column
     (29, 32, 33, 118, 2, 1, 1),
     (32, 20, 2, 61, 0, 1, 0),
     (30, 40, 368, 86, 0, 1, 1),    # orcai-V1 b2/sep_a: three output tiles
-    (40, 40, 64, 86, 2, 0, 0),     # b2/sep_b: 10 input quads, streamed as 12 (two dummy quads)
-    (50, 50, 40, 43, 2, 0, 0),     # b3/sep_b: 13 quads as 16, four output tiles
-    (60, 60, 46, 22, 2, 0, 1),     # b4/sep_b: 15 quads as 16
+    (40, 40, 64, 86, 2, 0, 0),     # b2/sep_b: 10 input quads
+    (50, 50, 40, 43, 2, 0, 0),     # b3/sep_b: 13 quads, four output tiles
+    (60, 60, 46, 22, 2, 0, 1),     # b4/sep_b: 15 quads
     (37, 64, 7, 100, 0, 1, 1),
+    (16, 16, 20, 171, 0, 0, 0),    # one output tile (input-gradient pass of b1/sep_a)
+    (7, 9, 3, 300, 0, 1, 0),       # 21 row chunks per quad: three LDS-DMAs per wave
 ])
-def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, relu_out):
-    """sepconv_stream_kernel (several windows per wave, rows prefetched three quads deep) performs the arithmetic of
-    sepconv_kernel in the same order: outputs are equal bit for bit, plane pads stay zero, for every windows-per-wave setting."""
+def test_tile_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, relu_out):
+    """The LDS-shared-row kernels (sepconv_tile_kernel: 8-row x 64-column strip tiles; sepconv_ftile_kernel: 8 consecutive flat windows)
+    perform the arithmetic of sepconv_kernel in the same order: outputs are equal bit for bit and plane pads stay zero, with the
+    launcher's own choice (mode 1) and with the flat-range kernel forced for every shape (mode 2)."""
     from orcai_amd import _native as N
 
     lib = N.lib()
@@ -192,8 +195,7 @@ def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, re
     Wx = (W + 1) // 2
     oshape = (B, CQo, H + 2, WP, 4) if layout == 0 else (B, CQo, H, (Wx + 3) // 4 * 4, 4)
 
-    def run(nw, tile=0):
-        prev = lib.orcai_sepconv_stream_windows(nw)
+    def run(tile):
         prev_tile = lib.orcai_sepconv_tile_mode(tile)
         try:
             out = torch.zeros(oshape, device=dev)
@@ -203,17 +205,13 @@ def test_streaming_sepconv_is_bit_identical(Cin, Cout, H, W, layout, relu_in, re
             torch.cuda.synchronize()
             return out
         finally:
-            lib.orcai_sepconv_stream_windows(prev)
             lib.orcai_sepconv_tile_mode(prev_tile)
 
     ref = run(0)
     assert float(ref.abs().max()) > 0
-    for nw, tile in ((1, 0), (2, 0), (5, 0), (1, 1), (0, 1)):  # tile: the LDS-tile variant where the launcher picks it (two output tiles, wide planes)
-        out = run(nw, tile)
-        if layout == 0:
-            assert torch.equal(out, ref), (nw, tile)
-        else:  # padding columns of the x-pooled buffer are never read and may hold anything
-            assert torch.equal(out[:, :, :, :Wx], ref[:, :, :, :Wx]), (nw, tile)
+    for tile in (1, 2):
+        out = run(tile)
+        assert torch.equal(out, ref), tile  # planes: pads included; x-pooled: the padding columns are never written either
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W,relu_in", [(16, 30, 736, 171, 0), (30, 30, 736, 171, 1), (29, 32, 33, 118, 1), (9, 17, 5, 130, 0)])
@@ -247,10 +245,11 @@ def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in
             lib.orcai_sepconv_tile_mode(prev)
 
     ref, uref = run(0)
-    out, u = run(1)
     assert float(uref.abs().max()) > 0 and float(ref.abs().max()) > 0
-    assert torch.equal(out, ref) and torch.equal(u, uref)
-    assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
+    for mode in (1, 2):
+        out, u = run(mode)
+        assert torch.equal(out, ref) and torch.equal(u, uref), mode
+        assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])
@@ -291,9 +290,10 @@ def test_fused_entry_convolution_is_bit_identical(shape, filters):
     assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :])
 
 
-def test_streaming_sepconv_random_shapes():
-    """Seeded sweep over shapes the launcher hands to sepconv_stream_kernel (and some it does not): every quad count and output
-    tile count, widths from narrower than a window to several windows per row, one-row planes, both output layouts."""
+def test_tile_sepconv_random_shapes():
+    """Seeded sweep over shapes the launcher hands to the LDS-shared-row kernels: every quad count and output tile count, widths from
+    narrower than a window to several windows per row, one-row planes, both output layouts; launcher's choice and flat-range kernel
+    forced, each against sepconv_kernel."""
     from orcai_amd import _native as N
 
     lib = N.lib()
@@ -301,7 +301,7 @@ def test_streaming_sepconv_random_shapes():
     rng = np.random.default_rng(11)
     g = torch.Generator(device="cpu").manual_seed(11)
     for case in range(24):
-        Cout = int(rng.integers(17, 65))
+        Cout = int(rng.integers(1, 65))
         Cin = int(rng.integers(1, 16 * ((Cout + 15) // 16) + 1))
         H, W = int(rng.integers(1, 24)), int(rng.integers(3, 190))
         layout = int(rng.integers(0, 2)) * 2
@@ -316,16 +316,16 @@ def test_streaming_sepconv_random_shapes():
         Wx = (W + 1) // 2
         oshape = (B, CQo, H + 2, WP, 4) if layout == 0 else (B, CQo, H, (Wx + 3) // 4 * 4, 4)
         outs = []
-        for nw in (0, 1, 3):
-            prev = lib.orcai_sepconv_stream_windows(nw)
+        for mode in (0, 1, 2):
+            prev = lib.orcai_sepconv_tile_mode(mode)
             try:
                 out = torch.zeros(oshape, device=dev)
                 assert lib.orcai_sepconv_bn(N.ptr(planes), B, Cin, H, W, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, relu_out, layout,
                                             N.ptr(out), N.stream_ptr()) == 0
                 torch.cuda.synchronize()
             finally:
-                lib.orcai_sepconv_stream_windows(prev)
-            outs.append(out if layout == 0 else out[:, :, :, :Wx])
+                lib.orcai_sepconv_tile_mode(prev)
+            outs.append(out)
         assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0]), (case, Cin, Cout, H, W, layout)
 
 

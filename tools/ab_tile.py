@@ -1,6 +1,6 @@
-"""A/B of the streaming separable-conv variant against the one-window-per-wave kernel: bit equality of the model output and
-per-layer times (HIP events) on the same spectrogram.  usage: ab_stream.py [seconds] [chunk] [nw ...]
-A value >= 100 runs (value - 100) windows per wave with the LDS-tile variant switched off (the default has it on)."""
+"""A/B of the separable-conv launcher modes (orcai_sepconv_tile_mode: 0 one-window kernel, 1 strip + flat-range LDS tiles, 2 flat-range
+tiles only): bit equality of the model output and per-layer times (HIP events) on the same spectrogram.
+usage: ab_tile.py [seconds] [chunk] [mode ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ from orcai_amd.architectures import ResNetLSTM
 dev = torch.device("cuda", 0)
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-nws = [int(a) for a in sys.argv[3:]] or [0, 2, 4, 8, 16]
+nws = [int(a) for a in sys.argv[3:]] or [0, 1, 2]
 pcm = synth_pcm_device(int(secs * 48000), 3, dev)
 spec = FrontEnd(dev).make_spectrogram(pcm, SPEC_PARAM)
 model = ResNetLSTM((736, 171, 1), 7, [30, 40, 50, 60], 3, 0.0, 128, seed=1)
@@ -20,8 +20,7 @@ model.prepare()
 lib = N.lib()
 ref = None
 for nw in nws + [nws[0]]:
-    lib.orcai_sepconv_stream_windows(nw - 100 if nw >= 100 else nw)
-    lib.orcai_sepconv_tile_mode(0 if nw >= 100 else 1)
+    lib.orcai_sepconv_tile_mode(nw)
     for it in range(3):
         model.kernel_events = {}
         pred = model.predict_spectrogram(spec, chunk=chunk)
@@ -30,5 +29,5 @@ for nw in nws + [nws[0]]:
     if ref is None:
         ref = pred.clone()
     same = bool(torch.equal(pred, ref))
-    print(f"nw={nw:2d} bit-identical={same} maxdiff={float((pred - ref).abs().max()):.3g} total={sum(tot.values()):.2f} ms",
+    print(f"mode={nw:2d} bit-identical={same} maxdiff={float((pred - ref).abs().max()):.3g} total={sum(tot.values()):.2f} ms",
           {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:14]}, flush=True)
