@@ -34,6 +34,8 @@ _SIGNATURES = {
     "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_padded_width": (C.c_int, [C.c_int, C.c_int]),
     "orcai_sepconv_tile_mode": (C.c_int, [C.c_int]),
+    "orcai_sepconv_pool_res": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "orcai_sepconv_pool_rows": (C.c_int, [C.c_int]),
     "orcai_entry_windows": (C.c_int, [C.c_int]),
     "orcai_conv0_sepconv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -139,6 +141,9 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+E_UNSUPPORTED = -2  # ORCAI_E_UNSUPPORTED (include/orcai_hip.h)
 
 
 def check(code: int, what: str) -> None:
