@@ -43,8 +43,6 @@ def kernel_costs():
         costs[f"b{b}/sep_b"] = _sep_cost(f, f, h, w, w_out=wx)
         # pool + residual: read the x-pooled s, read prev at the sampled (2i, 2j) pixels, write out
         costs[f"b{b}/pool_res"] = (4.0 * (h * wx * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
-        # second separable conv + pool + residual in one launch (orcai_sepconv_pool_res): read a, read prev's samples, write out
-        costs[f"b{b}/sep_b+pool_res"] = (4.0 * (h * w * f + ho * wo * cin + ho * wo * f), costs[f"b{b}/sep_b"][1] + costs[f"b{b}/pool_res"][1])
     costs["sep_f"] = _sep_cost(60, 36, 46, 11)
     # fused entry (orcai_conv0_sepconv): read the 1-channel snippet, write a1 and the (2i, 2j) subsample of the entry activation
     costs["conv0+b1/sep_a"] = (4.0 * (736 * 171 * (1 + 30) + 368 * 86 * 16), costs["conv0"][1] + costs["b1/sep_a"][1])
@@ -119,8 +117,6 @@ class PredictWorkload:
         if label == "sep_f":
             return "sepconv_kernel<3, 3>"  # Keras-reshape output layout: not a streaming shape
         blk, _, op = label.partition("/")
-        if blk in couts and op == "sep_b+pool_res":
-            return f"sepconv_pool_tile_kernel<8, false, {N.lib().orcai_sepconv_pool_rows(-1)}>"
         if blk in couts and op in ("sep_a", "sep_b"):
             cin, cout = (cins[blk] if op == "sep_a" else couts[blk]), couts[blk]
             mt, cqr = (cout + 15) // 16, (cin + 3) // 4
@@ -139,7 +135,7 @@ class PredictWorkload:
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
     # (sepconv_tile_kernel<2, 8, true, false, 8, false>) is the top symbol of rocprofv3 --stats for this workload
-    DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b", "b1/sep_b+pool_res")
+    DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
 
     def roofline(self):
         """Dominant kernel SYMBOL (as rocprofv3 names it): average launch duration from HIP events recorded on the launch stream
@@ -147,8 +143,7 @@ class PredictWorkload:
         are bracketed in the timed region (an event pair costs ~15 us of queue time); the per-layer table comes from one more
         step, after the timed region, with every launch bracketed."""
         timed_events = self.events
-        b1 = "b1/sep_b+pool_res" if "b1/sep_b+pool_res" in timed_events else "b1/sep_b"  # one launch per trunk chunk either way
-        n_steps = max(1, len(timed_events.get(b1, [])) // max(1, -(-self.n_snippets // self.chunk)))
+        n_steps = max(1, len(timed_events.get("b1/sep_b", [])) // max(1, -(-self.n_snippets // self.chunk)))
         self.events, self.model.kernel_event_labels = {}, None
         self.step(True)  # all layers bracketed, outside the timed region
         torch.cuda.synchronize()

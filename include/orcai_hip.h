@@ -129,21 +129,6 @@ int orcai_padded_width(int W, int ksize);
  * value; values outside [0, 2] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_tile_mode(int mode);
 
-/* The second separable convolution of a residual block fused with the block's tail (architectures.py:184-196):
- *   out = MaxPooling2D((3,2),2,same)(BN(SepConv3x3([ReLU] in)))  +  Conv2D(1x1, strides 2)(prev) + bias,
- * i.e. orcai_sepconv_bn(..., out_layout 2) followed by orcai_pool_res_add, without the x-pooled activation between them ever
- * reaching HBM (sepconv_pool_tile_kernel; bit-identical to the two-launch sequence).  in: planes [B][ceil(Cin/4)][H+2][WP][4];
- * dw / pw / scale / shift as orcai_sepconv_bn (k = 3); prev: the block input, planes of (H, W) with Cp channels, or with
- * prev_compact != 0 the compact (2i, 2j) subsample orcai_conv0_sepconv writes; wr [Cp][Cout], br [Cout]; out: planes
- * [B][ceil(Cout/4)][ceil(H/2)+2][WPo][4] (pads are not written).  Implemented for Cout in 17..32, Cin <= 32, Cp <= 16 and planes at
- * least two 60-column strips wide (orcai-V1 block 1): ORCAI_E_UNSUPPORTED otherwise and when orcai_sepconv_tile_mode is 0 -- the
- * caller then issues the two launches. */
-int orcai_sepconv_pool_res(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
-                           int Cout, int relu_out, const float* prev, int Cp, int prev_compact, const float* wr, const float* br, float* out, void* stream);
-
-/* Conv rows (= waves) per workgroup of that kernel: 9 (default) or 11.  Returns the previous value; other values only query. */
-int orcai_sepconv_pool_rows(int rows);
-
 /* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current
  * one is computed).  Returns the previous value; values outside [1, 64] only query. */
 int orcai_entry_windows(int windows_per_wave);

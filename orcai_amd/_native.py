@@ -34,8 +34,6 @@ _SIGNATURES = {
     "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_padded_width": (C.c_int, [C.c_int, C.c_int]),
     "orcai_sepconv_tile_mode": (C.c_int, [C.c_int]),
-    "orcai_sepconv_pool_res": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4),
-    "orcai_sepconv_pool_rows": (C.c_int, [C.c_int]),
     "orcai_entry_windows": (C.c_int, [C.c_int]),
     "orcai_conv0_sepconv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),

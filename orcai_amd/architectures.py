@@ -335,28 +335,6 @@ class ResNetLSTM:
         e1.record()
         ev.setdefault(label, []).append((e0, e1))
 
-    fuse_tail = True  # orcai_sepconv_pool_res where it applies (test / A-B switch)
-
-    def _fused_tail(self, lib, b, a, prev, nxt, B, f, c, h, wd, entry, d, st) -> bool:
-        """Try the fused launch for block b; False (nothing launched) when the library reports the shape as unsupported."""
-        pb = f"b{b}/sep_b"
-        label = f"b{b}/sep_b+pool_res"
-        args = (N.ptr(a), B, f, h, wd, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, N.ptr(prev), c,
-                1 if entry else 0, N.ptr(d[f"b{b}/res/w"]), N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), st)
-        ev = self.kernel_events
-        timed = ev is not None and (self.kernel_event_labels is None or label in self.kernel_event_labels)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        rc = lib.orcai_sepconv_pool_res(*args)
-        if rc == N.E_UNSUPPORTED:  # returned before anything was launched
-            return False
-        N.check(rc, "orcai_sepconv_pool_res")
-        if timed:
-            e1.record()
-            ev.setdefault(label, []).append((e0, e1))
-        return True
-
     def trunk_device(self, src: torch.Tensor, snippet_stride: int, B: int, feat: torch.Tensor, keep: dict | None = None, first: int = 0,
                      last: int | None = None, ws: dict | None = None) -> dict:
         """Convolutional trunk for one chunk of B snippets, stages first..last: stage 0 = entry conv, b = residual block b,
@@ -391,10 +369,6 @@ class ResNetLSTM:
             else:
                 self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                              N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
-            # second separable conv + pooling + residual: one launch where the fused kernel has the shape (wide planes, two output tiles:
-            # orcai-V1 block 1; the x-pooled activation then never reaches HBM), else two.  The keep hook wants the intermediate.
-            if k == 3 and keep is None and self.fuse_tail and self._fused_tail(lib, b, a, prev, nxt, B, f, c, h, wd, entry, d, st):
-                continue
             self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
                          N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),

@@ -826,191 +826,6 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
 }
 
 // =========================================================================================
-// sepconv_pool_tile: the second separable convolution of a residual block fused with the block's tail,
-//   SepConv(k = 3) -> BN -> MaxPooling2D((3, 2), 2, same)  +  Conv2D(1x1, strides 2)(prev) + bias      (architectures.py:184-196)
-// on the strip tiles of sepconv_tile_kernel: the x-pooled activation (7.6 MB per orcai-V1 snippet in block 1) is neither written to
-// nor read back from HBM.  A workgroup of TR (odd) waves computes TR consecutive conv rows of a 64-column strip, one per wave, with
-// the input rows shared through LDS as in sepconv_tile_kernel; pooled row p = max over conv rows 2p - pad_top + {0, 1, 2}, so the
-// even-numbered waves (rows shared by two pooling windows) publish their BN'd, column-pair-maxed row through LDS and every
-// odd-numbered wave (the middle row of one pooling window) takes the maximum with its two neighbours, adds the residual
-// convolution of its (TR - 1) / 2 ... pooled pixels (MFMA, lane = pixel as in pool_res_add_x_kernel) and stores the block output.
-// Consecutive tiles overlap by one conv row: (TR - 1) / 2 pooled rows per TR conv rows, a recomputation of 1 / (TR - 1).
-// Same fma / mfma chains in the same order as orcai_sepconv_bn (x-pooled) + orcai_pool_res_add: bit-identical block output.
-// =========================================================================================
-template <int CQ, bool RELU, int TR>
-__global__ __launch_bounds__(64 * TR) void sepconv_pool_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
-                                                                  const float* __restrict__ dw, const float* __restrict__ pw, const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift, int Cout, int relu_out, const float* __restrict__ prev, int Cp,
-                                                                  int prev_compact, const float* __restrict__ wr /*[Cp][Cout]*/, const float* __restrict__ br,
-                                                                  float* __restrict__ out /*[B][CQo][Ho+2][WPo][4]*/, int Ho, int Wo, int WPo, int pad_top, int nstrip) {
-  constexpr int KK = 9, R = 1, lo = 2, VAL = 60, MT = 2, S = TR - 1, CQP = 4;  // CQP: residual input quads (Cp <= 16)
-  static_assert(TR % 2 == 1 && TR >= 3, "an odd number of conv rows: (TR - 1) / 2 pooling windows of stride 2");
-  // [slot][tile row][lane][4] during the convolution; afterwards the same memory holds the published rows,
-  // [wave][(m, tt, lk, lj / 2)][4]: x-pooled BN'd conv rows
-  constexpr int XF = (2 * (TR + 2) > 4 * TR ? 2 * (TR + 2) : 4 * TR) * 256;  // floats: two slots of TR + 2 rows, then TR published rows of 4 KiB
-  __shared__ __attribute__((aligned(16))) float rows_raw[XF];
-  float (*rows_s)[TR + 2][256] = reinterpret_cast<float (*)[TR + 2][256]>(rows_raw);
-  float (*exch_s)[8 * 32 * 4] = reinterpret_cast<float (*)[8 * 32 * 4]>(rows_raw);
-  __shared__ float pw_s[CQ * 4 * 16 * MT];
-  __shared__ float wr_s[CQP * 4 * 16 * MT];  // residual weights, the pointwise layout
-  __shared__ float sc_s[MT * 16], sh_s[MT * 16], br_s[MT * 16];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int bx, b;
-  xcd_remap(bx, b);
-  const int rg = bx / nstrip, strip = bx - rg * nstrip;
-  const int p0 = rg * (S / 2);        // first pooled row of the tile
-  const int y0 = 2 * p0 - pad_top;    // conv row of wave 0 (-1 for the first tile when pad_top = 1)
-  const int c0 = strip * VAL;
-  const int lk = lane >> 4, lj = lane & 15;
-  const int plane = (H + 2 * R) * WP;
-  const int CQo = (Cout + 3) >> 2, CQr = (Cin + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const char* src = reinterpret_cast<const char*>(in) + (int64_t)b * CQr * plane * 16;
-
-  auto goff = [&](int j) {  // tile row j is padded-plane row y0 + j (the image row y0 - 1 + j)
-    const int i = (y0 + j) * WP + c0 - lo + lane;
-    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
-  };
-  const uint32_t off0 = goff(wave), off1 = goff(TR + (wave & 1));
-  const uint32_t lds0 = (uint32_t)(uintptr_t)&rows_s[0][0][0];
-  const bool two = wave < 2;
-  auto issue = [&](int e) {
-    const char* base = src + (int64_t)e * plane * 16;
-    const uint32_t slot = lds0 + (uint32_t)((e & 1) * (TR + 2) * 1024);
-    glds16(base + off0, slot + (uint32_t)wave * 1024u);
-    if (two) glds16(base + off1, slot + (uint32_t)(TR + wave) * 1024u);
-  };
-  issue(0);
-
-  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 64 * TR) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
-  }
-  for (int i = threadIdx.x; i < CQp * 4 * 16 * MT; i += 64 * TR) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    wr_s[i] = (ci < Cp && co < Cout) ? wr[ci * Cout + co] : 0.0f;
-  }
-  if (threadIdx.x < MT * 16) {
-    const int co = threadIdx.x;
-    sc_s[co] = co < Cout ? scale[co] : 0.0f;
-    sh_s[co] = co < Cout ? shift[co] : 0.0f;
-    br_s[co] = co < Cout ? br[co] : 0.0f;
-  }
-  __syncthreads();
-  const float lo_out = relu_out ? 0.0f : -INFINITY;
-
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int cq = 0; cq < CQ; ++cq) {
-    if (cq < CQr) {  // workgroup-uniform
-      wait_vm_barrier<0>();
-      if (cq + 1 < CQr) issue(cq + 1);
-      float4 rows[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&rows_s[cq & 1][wave + dy][lane * 4]);
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
-      float d[4];
-      dw_quad_impl<3, RELU>(rows, dw + cq * 4 * KK, d);
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
-    }
-  }
-  // ---- block tail, shared by all waves: the (TR - 1) / 2 pooling windows x 4 column tiles of the strip are NP pieces, piece n goes
-  // to wave n % TR.  A piece = one pooled row p0 + k, tile columns 16tt .. 16tt + 15, both output channel tiles.
-  constexpr int NP = (S / 2) * 4, PPW = (NP + TR - 1) / TR;  // pieces, pieces per wave
-  // residual operands of this wave's pieces, requested now so that their latency passes behind the BN fold and the row exchange.  B
-  // fragments in their MFMA layout, 4 bytes per lane (lane (lk, lj): channel 4u + lk of the pooled pixel under tile column 16tt + lj;
-  // the two columns of a pair read the same pixel, so one instruction touches one 128-byte line) -- 0.5 MB per snippet.
-  float dres[PPW][4];
-  const int64_t plane_p = prev_compact ? (int64_t)Ho * Wo : (int64_t)plane;
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int n = wave + i * TR, k = n >> 2, tt = n & 3, p = p0 + k;
-    if (n < NP && p < Ho) {  // wave-uniform
-      const int x = c0 - lo + 16 * tt + lj;
-      int j = (x < 0 ? 0 : x) >> 1;
-      j = j < Wo ? j : Wo - 1;
-      const float* q0 = prev + ((int64_t)b * CQp * plane_p + (prev_compact ? (int64_t)p * Wo + j : (int64_t)(2 * p + R) * WP + 2 * j)) * 4 + lk;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dres[i][u] = u < CQp ? q0[(int64_t)u * plane_p * 4] : 0.0f;
-    }
-  }
-  // ---- folded BN + column-pair maximum, published through LDS: row `wave` of exch_s holds channel 16m + 4lk + r of the pooled
-  // column under tile column 16tt + lj (pairs = lanes 2k, 2k+1; the even lane writes)
-  const int y = y0 + wave;                 // this wave's conv row
-  const bool row_ok = y >= 0 && y < H;     // rows outside the image do not take part in a maximum ("same" pads with -inf)
-  const int eidx = ((lk * 8) + (lj >> 1)) * 4;  // + (m * 4 + tt) * 128 floats
-  __syncthreads();  // every wave has read its rows of the last quad: the slots may be overwritten
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int x = c0 - lo + 16 * tt + lj;
-    const bool pair_ok = x + 1 < W;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
-      float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = max2(v[r], lo_out);
-        const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
-        v[r] = max2(v[r], pair_ok ? other : v[r]);
-        v[r] = row_ok ? v[r] : -INFINITY;
-      }
-      if ((lj & 1) == 0) *reinterpret_cast<float4*>(&exch_s[wave][(m * 4 + tt) * 128 + eidx]) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-  __syncthreads();
-  const int plane_o = (Ho + 2 * R) * WPo;
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int n = wave + i * TR, k = n >> 2, tt = n & 3, p = p0 + k;
-    if (n < NP && p < Ho) {
-      const int wl = 16 * tt + lj;
-      const int x = c0 - lo + wl;
-      const bool live = wl >= lo && wl < 64 - lo && x < W && (x & 1) == 0;
-      f32x4 racc[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) racc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u < CQp) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m) racc[m] = mfma16(wr_s[((u * 4 + lk) * 16 + lj) * MT + m], dres[i][u], racc[m]);
-        }
-      float4* outb = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane_o + (R + p) * WPo;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int e = (m * 4 + tt) * 128 + eidx;
-        const float4 r0 = *reinterpret_cast<const float4*>(&exch_s[2 * k][e]);
-        const float4 r1 = *reinterpret_cast<const float4*>(&exch_s[2 * k + 1][e]);
-        const float4 r2 = *reinterpret_cast<const float4*>(&exch_s[2 * k + 2][e]);
-        const float mx[4] = {max2(max2(r0.x, r1.x), r2.x), max2(max2(r0.y, r1.y), r2.y), max2(max2(r0.z, r1.z), r2.z), max2(max2(r0.w, r1.w), r2.w)};
-        const int oq = m * 4 + lk;
-        const float4 bq = reinterpret_cast<const float4*>(br_s)[oq];
-        if (live && oq < CQo) {
-          float o[4] = {mx[0] + (racc[m][0] + bq.x), mx[1] + (racc[m][1] + bq.y), mx[2] + (racc[m][2] + bq.z), mx[3] + (racc[m][3] + bq.w)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < Cout) ? o[r] : 0.0f;
-          outb[(int64_t)oq * plane_o + (x >> 1)] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-      }
-    }
-  }
-}
-
-// =========================================================================================
 // pool_res_add: MaxPooling2D((3,2),2,same)(s) + Conv2D(1x1, strides 2)(prev) + bias   (architectures.py:190-196)
 // Same register-tile scheme as sepconv: one wave owns 64 consecutive flat pixels of the padded OUTPUT plane
 // (lane = pooled pixel).  The strided 1x1 residual convolution is an MFMA contraction: per input quad the lane
@@ -1721,45 +1536,6 @@ int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ks
 int orcai_sepconv_planes(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,
                          const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, void* stream) {
   return orcai_sepconv_planes_u(in, B, Cin, H, W, ksize_planes, ktap, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, H2, W2, out, nullptr, stream);
-}
-
-int g_pool_tile_rows = 9;  // conv rows (= waves) per workgroup of sepconv_pool_tile_kernel: 9 or 11
-
-int orcai_sepconv_pool_rows(int rows) {
-  const int prev = g_pool_tile_rows;
-  if (rows == 7 || rows == 9 || rows == 11) g_pool_tile_rows = rows;
-  return prev;
-}
-
-int orcai_sepconv_pool_res(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
-                           int Cout, int relu_out, const float* prev, int Cp, int prev_compact, const float* wr, const float* br, float* out, void* stream) {
-  if (!in || !dw || !pw || !scale || !shift || !prev || !wr || !br || !out || B <= 0 || Cin <= 0 || Cout <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
-  const int CQ = (Cin + 3) / 4, nstrip = (W + 59) / 60;
-  // the fused kernel's shapes: two output tiles, <= 8 input quads, <= 16 residual input channels, planes the 60-column strips cover
-  // with <= 15 % waste (orcai-V1 block 1); everything else stays on orcai_sepconv_bn + orcai_pool_res_add
-  if (!g_tile_mode || Cout <= 16 || Cout > 32 || CQ > 8 || Cp > 16 || nstrip < 2 || W * 100 < nstrip * 60 * 85) return ORCAI_E_UNSUPPORTED;
-  const int WP = orcai_padded_width(W, 3), Ho = (H + 1) / 2, Wo = (W + 1) / 2, WPo = orcai_padded_width(Wo, 3);
-  if ((int64_t)((Cout + 3) / 4) * (H + 2) * WP >= (1ll << 27) || (int64_t)CQ * (H + 2) * WP >= (1ll << 27)) return ORCAI_E_UNSUPPORTED;
-  int tot_h = (Ho - 1) * 2 + 3 - H;
-  if (tot_h < 0) tot_h = 0;
-  const int TR = g_pool_tile_rows, per = (TR - 1) / 2;
-  dim3 grid(nstrip * ((Ho + per - 1) / per), B);
-  hipStream_t st = (hipStream_t)stream;
-#define ORCAI_POOLTILE_LAUNCH(CQT, RELU, TRT)                                                                                                    \
-  hipLaunchKernelGGL((sepconv_pool_tile_kernel<CQT, RELU, TRT>), grid, dim3(64 * TRT), 0, st, in, Cin, H, W, WP, dw, pw, scale, shift, Cout, relu_out, prev, \
-                     Cp, prev_compact, wr, br, out, Ho, Wo, WPo, tot_h / 2, nstrip)
-#define ORCAI_POOLTILE_ROWS(CQT, RELU)                      \
-  if (TR == 7) ORCAI_POOLTILE_LAUNCH(CQT, RELU, 7);        \
-  else if (TR == 9) ORCAI_POOLTILE_LAUNCH(CQT, RELU, 9);   \
-  else ORCAI_POOLTILE_LAUNCH(CQT, RELU, 11)
-  if (CQ <= 4) {
-    if (relu_in) { ORCAI_POOLTILE_ROWS(4, true); } else { ORCAI_POOLTILE_ROWS(4, false); }
-  } else {
-    if (relu_in) { ORCAI_POOLTILE_ROWS(8, true); } else { ORCAI_POOLTILE_ROWS(8, false); }
-  }
-#undef ORCAI_POOLTILE_ROWS
-#undef ORCAI_POOLTILE_LAUNCH
-  return (int)hipGetLastError();
 }
 
 int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,

@@ -252,72 +252,6 @@ def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in
         assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("Cin,Cout,Cp,H,W,relu_in,compact,rows", [
-    (30, 30, 16, 736, 171, 0, 1, 9),    # orcai-V1 block 1 behind the fused entry kernel
-    (30, 30, 16, 736, 171, 0, 1, 11),
-    (16, 30, 16, 35, 171, 1, 0, 9),     # odd H (pooling pads one row on top), residual input as full planes, 4 input quads
-    (29, 32, 13, 8, 118, 1, 0, 11),     # even W, ragged channels, fewer rows than a tile
-    (20, 17, 7, 1, 115, 0, 1, 7),       # a single image row
-    (30, 30, 16, 60, 171, 0, 1, 7),
-    (32, 31, 16, 19, 240, 0, 0, 9),     # four strips
-])
-def test_fused_block_tail_is_bit_identical(Cin, Cout, Cp, H, W, relu_in, compact, rows):
-    """orcai_sepconv_pool_res (second separable conv + BN + 3x2 max-pool + strided residual conv + add in one launch, the x-pooled
-    activation exchanged through LDS) against orcai_sepconv_bn (x-pooled) + orcai_pool_res_add: block output equal bit for bit,
-    pads of the output planes untouched."""
-    from orcai_amd import _native as N
-
-    lib = N.lib()
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device="cpu").manual_seed(Cin * 1000 + Cout * 10 + H)
-    B, CQ, CQo, CQp, WP = 3, (Cin + 3) // 4, (Cout + 3) // 4, (Cp + 3) // 4, lib.orcai_padded_width(W, 3)
-    Ho, Wo = (H + 1) // 2, (W + 1) // 2
-    WPo = lib.orcai_padded_width(Wo, 3)
-
-    def planes(C, h, w, wp):
-        x = torch.zeros(B, (C + 3) // 4 * 4, h + 2, wp)
-        x[:, :C, 1:h + 1, :w] = torch.randn(B, C, h, w, generator=g)
-        return x.view(B, (C + 3) // 4, 4, h + 2, wp).permute(0, 1, 3, 4, 2).contiguous()
-
-    a = planes(Cin, H, W, WP).to(dev)
-    pfull = planes(Cp, H, W, WP)
-    prev = (pfull[:, :, 1:H + 1:2, 0:W:2, :].contiguous() if compact else pfull).to(dev)
-    assert not compact or prev.shape == (B, CQp, Ho, Wo, 4)
-    dw = torch.randn(CQ, 9, 4, generator=g).to(dev)
-    pw = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
-    scale, shift = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
-    wr = (torch.randn(Cp, Cout, generator=g) / Cp ** 0.5).to(dev)
-    br = torch.randn(Cout, generator=g).to(dev)
-    st = N.stream_ptr()
-    Wx = (W + 1) // 2
-    s = torch.zeros((B, CQo, H, (Wx + 3) // 4 * 4, 4), device=dev)
-    ref = torch.full((B, CQo, Ho + 2, WPo, 4), 7.0, device=dev)  # a sentinel in the pads: neither path may write them
-    out = ref.clone()
-    assert lib.orcai_sepconv_bn(N.ptr(a), B, Cin, H, W, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, 0, 2, N.ptr(s), st) == 0
-    assert lib.orcai_pool_res_add(N.ptr(s), N.ptr(prev), B, Cout, Cp, H, W, 3, N.ptr(wr), N.ptr(br), N.ptr(ref), 3 if compact else 1, st) == 0
-    prev_rows = lib.orcai_sepconv_pool_rows(rows)
-    try:
-        rc = lib.orcai_sepconv_pool_res(N.ptr(a), B, Cin, H, W, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, 0, N.ptr(prev), Cp,
-                                        1 if compact else 0, N.ptr(wr), N.ptr(br), N.ptr(out), st)
-    finally:
-        lib.orcai_sepconv_pool_rows(prev_rows)
-    assert rc == 0
-    torch.cuda.synchronize()
-    assert float(ref[:, :, 1:Ho + 1, :Wo].abs().max()) > 0
-    assert torch.equal(out, ref)
-
-
-def test_fused_block_tail_declines_other_shapes():
-    """Shapes outside the fused kernel's range return ORCAI_E_UNSUPPORTED before anything is launched (the model then issues the two launches)."""
-    from orcai_amd import _native as N
-
-    lib = N.lib()
-    z = torch.zeros(1 << 20, device="cuda")
-    for Cin, Cout, Cp, H, W in ((40, 40, 30, 368, 86), (30, 30, 16, 64, 70), (30, 30, 30, 64, 171), (12, 12, 12, 64, 171)):
-        assert lib.orcai_sepconv_pool_res(N.ptr(z), 1, Cin, H, W, 0, N.ptr(z), N.ptr(z), N.ptr(z), N.ptr(z), Cout, 0, N.ptr(z), Cp, 0, N.ptr(z), N.ptr(z),
-                                          N.ptr(z), N.stream_ptr()) == N.E_UNSUPPORTED
-
-
 @pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])
 def test_fused_entry_convolution_is_bit_identical(shape, filters):
     """orcai_conv0_sepconv (entry convolution computed inside block 1's first separable convolution, compact (2i, 2j) subsample for

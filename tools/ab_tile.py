@@ -1,6 +1,6 @@
 """A/B of the separable-conv launcher modes (orcai_sepconv_tile_mode: 0 one-window kernel, 1 strip + flat-range LDS tiles, 2 flat-range
 tiles only): bit equality of the model output and per-layer times (HIP events) on the same spectrogram.
-usage: ab_tile.py [seconds] [chunk] [mode ...]   (mode + 10: the block tail as two launches; mode + 20 / 30 / 40: fused tail with 11 / 15 / 7-row tiles)"""
+usage: ab_tile.py [seconds] [chunk] [mode ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,10 +20,7 @@ model.prepare()
 lib = N.lib()
 ref = None
 for nw in nws + [nws[0]]:
-    lib.orcai_sepconv_tile_mode(nw % 10)
-    model.fuse_tail = nw < 10  # 1x: block tail as two launches (orcai_sepconv_bn + orcai_pool_res_add)
-    lib.orcai_sepconv_pool_rows({2: 11, 3: 15, 4: 7}.get(nw // 10, 9))
-    model.fuse_tail = nw < 10 or nw >= 20
+    lib.orcai_sepconv_tile_mode(nw)
     for it in range(3):
         model.kernel_events = {}
         pred = model.predict_spectrogram(spec, chunk=chunk)
