@@ -113,7 +113,8 @@ class PredictWorkload:
         if label == "conv0":
             return "conv0_kernel<3>"
         if label == "conv0+b1/sep_a":
-            return "conv0_sep_kernel<2>"
+            tile = N.lib().orcai_entry_tile(-1)
+            return f"conv0_sep_tile_kernel<2, {tile}>" if tile else "conv0_sep_kernel<2>"
         if label == "sep_f":
             return "sepconv_kernel<3, 3>"  # Keras-reshape output layout: not a streaming shape
         blk, _, op = label.partition("/")

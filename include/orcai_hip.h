@@ -133,6 +133,11 @@ int orcai_sepconv_tile_mode(int mode);
  * one is computed).  Returns the previous value; values outside [1, 64] only query. */
 int orcai_entry_windows(int windows_per_wave);
 
+/* orcai_conv0_sepconv on planes at least two 62-column strips wide with Cout in 17..32: waves per workgroup of the strip-tile
+ * variant (conv0_sep_tile_kernel: every entry-activation row is computed once per tile and shared through LDS), 10 (default) or 16;
+ * 0 = conv0_sep_kernel everywhere.  Bit-identical either way.  Returns the previous value; other values only query. */
+int orcai_entry_tile(int waves);
+
 /* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
  *   in              f32, UNPADDED: snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
  *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is

@@ -547,6 +547,139 @@ __global__ __launch_bounds__(256) void conv0_sep_kernel(const float* __restrict_
 }
 
 // =========================================================================================
+// conv0_sep_tile: conv0_sep_kernel on 2-D strip tiles with the entry activation shared through LDS.  conv0_sep_kernel computes the
+// 16-channel entry activation three times (once per row of every window's depthwise stencil); here a workgroup of TRW waves owns
+// TRW - 2 image rows x 64 columns, wave w computes the entry activation of ONE row (tile row w = image row r0 - 1 + w, all 16
+// channels: 1 / 3 of the per-window entry arithmetic, (TRW) / (TRW - 2) rows per output row) from 9 input dwords per lane and
+// writes it to LDS as [row][quad][lane][4]; after one barrier the first TRW - 2 waves run the depthwise / transpose / MFMA
+// pipeline of one output row each, reading their three rows per quad with ds_read_b128.  No register set of in-flight inputs, no
+// per-window recomputation: 64 VGPRs.  Same fma chains in the same order as conv0_kernel + sepconv_kernel: bit-identical.
+// =========================================================================================
+template <int MT, int TRW>
+__global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
+                                                                const float* __restrict__ w0_ /*[9][16]*/, const float* __restrict__ sc0_,
+                                                                const float* __restrict__ sh0_, const float* __restrict__ dw_ /*[4][9][4]*/,
+                                                                const float* __restrict__ pw /*[16][Cout]*/, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int Cout, int relu_out, float* __restrict__ out,
+                                                                float* __restrict__ prev_sub, int nstrip) {
+  constexpr int R = 1, lo = 1, VAL = 62, C0 = 16, TR = TRW - 2;
+  __shared__ __attribute__((aligned(16))) float act_s[TRW][C0 / 4][256];  // entry activation: [tile row][quad][lane][4]
+  __shared__ float pw_s[C0 * 16 * MT];                                     // [(ci * 16 + lj)][m]
+  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int rg = bx / nstrip, strip = bx - rg * nstrip;
+  const int r0 = rg * TR, c0 = strip * VAL;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int CQo = (Cout + 3) >> 2;
+  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+
+  // ---- phase 1: the entry activation of image row e = r0 - 1 + wave at columns x = c0 - 1 + lane.  Inputs through a raw buffer
+  // resource over the snippet's H * W floats: rows outside the snippet and columns outside the image (offset sentinel) read as 0.
+  const int e = r0 - 1 + wave, x = c0 - lo + lane;
+  {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a row pitch
+    const uint32_t center = (uint32_t)((e * W + x) * 4);
+    const bool e_ok = e >= -1 && e <= H;  // beyond that even the neighbouring rows are outside (and center may wrap into range)
+    const uint32_t off[3] = {(e_ok && x >= 1 && x <= W) ? center - 4u : OOB, (e_ok && x >= 0 && x < W) ? center : OOB, (e_ok && x >= -1 && x + 1 < W) ? center + 4u : OOB};
+    f32x2 inp[5];  // input (row d, column j) in half (3d + j) & 1 of pair (3d + j) >> 1 (see conv0_sep_kernel)
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        inp[(3 * d + j) >> 1][(3 * d + j) & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 1) * W * 4), 0, 0));
+    inp[4][1] = 0.0f;
+
+    for (int i = threadIdx.x; i < C0 * 16 * MT; i += 64 * TRW) {
+      const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+      pw_s[i] = co < Cout ? pw[ci * Cout + co] : 0.0f;
+    }
+    if (threadIdx.x < MT * 16) {
+      const int co = threadIdx.x;
+      sc_s[co] = co < Cout ? scale[co] : 0.0f;
+      sh_s[co] = co < Cout ? shift[co] : 0.0f;
+    }
+    const float hi = (x >= 0 && x < W && e >= 0 && e < H) ? INFINITY : 0.0f;  // the activation is zero outside the image: the depthwise padding
+    // the residual branch's (2i, 2j) subsample: written by the row's owner (tile rows 1 .. TR, lanes lo .. 63 - lo)
+    const bool sub_lane = prev_sub && wave >= 1 && wave <= TR && lane >= lo && lane < 64 - lo && x < W && e < H && ((x | e) & 1) == 0;
+    float4* sub = reinterpret_cast<float4*>(prev_sub) + (int64_t)b * (C0 / 4) * Ho * Wo + (e >> 1) * Wo + (x >> 1);
+    const float* w0 = static_cast<const float*>(__builtin_assume_aligned(w0_, 16));
+    const float* sc0 = static_cast<const float*>(__builtin_assume_aligned(sc0_, 16));
+    const float* sh0 = static_cast<const float*>(__builtin_assume_aligned(sh0_, 16));
+#pragma unroll
+    for (int cq = 0; cq < C0 / 4; ++cq) {
+      const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
+      const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
+      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
+          const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
+          const int ii = 3 * dy + dx;
+          a01 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w01, a01) : pk_fma_bcast<0>(inp[ii >> 1], w01, a01));
+          a23 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w23, a23) : pk_fma_bcast<0>(inp[ii >> 1], w23, a23));
+        }
+      a01 = a01 * s01 + h01;
+      a23 = a23 * s23 + h23;
+      const float4 c = make_float4(relu_mask(a01.x, hi), relu_mask(a01.y, hi), relu_mask(a23.x, hi), relu_mask(a23.y, hi));
+      *reinterpret_cast<float4*>(&act_s[wave][cq][lane * 4]) = c;
+      if (sub_lane) sub[(int64_t)cq * Ho * Wo] = c;
+    }
+  }
+  __syncthreads();
+  const int y = r0 + wave;  // this wave's output row
+  if (wave >= TR || y >= H) return;
+
+  // ---- phase 2: depthwise 3x3 over tile rows wave .. wave + 2, pointwise on the MFMA
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* dw = static_cast<const float*>(__builtin_assume_aligned(dw_, 16));
+#pragma unroll
+  for (int cq = 0; cq < C0 / 4; ++cq) {
+    float4 c0r[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) c0r[dy] = *reinterpret_cast<const float4*>(&act_s[wave + dy][cq][lane * 4]);
+    float afrag[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
+    float d[4];
+    dw_quad_impl<3, false>(c0r, dw + cq * 36, d);  // the entry activation is already >= 0: the separable conv's ReLU is the identity
+    swap32(d[0], d[2]);
+    swap32(d[1], d[3]);
+    swap16(d[0], d[1]);
+    swap16(d[2], d[3]);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
+  }
+  float4* outb = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane + (R + y) * WP;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int wl = 16 * tt + lj;
+    const int xx = c0 - lo + wl;
+    const bool live = wl >= lo && wl < 64 - lo && xx < W;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
+      const int oq = m * 4 + lk;
+      if (live && oq < CQo)
+        outb[(int64_t)oq * plane + xx] = make_float4(max2(fmaf(acc[m][tt][0], sc.x, sh.x), lo_out), max2(fmaf(acc[m][tt][1], sc.y, sh.y), lo_out),
+                                                    max2(fmaf(acc[m][tt][2], sc.z, sh.z), lo_out), max2(fmaf(acc[m][tt][3], sc.w, sh.w), lo_out));
+    }
+  }
+}
+
+// =========================================================================================
 // sepconv_tile: the arithmetic of sepconv_kernel<3, MT> with the window rows shared through LDS, for planes
 // several windows wide (block 1).  A workgroup of TR waves owns a 2-D tile of TR image rows x 64 columns (one row per wave); per
 // input quad the tile's TR + 2 rows are fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
@@ -1352,6 +1485,7 @@ struct SepArgs {
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
+int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
                       // >= 2 strips that cover the width with <= 15 % waste) and sepconv_ftile_kernel otherwise; 2 = sepconv_ftile_kernel for
                       // all of them; 0 = sepconv_kernel everywhere (the reference the bit-identity tests compare with)
@@ -1456,6 +1590,12 @@ int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int 
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 
+int orcai_entry_tile(int waves) {
+  const int prev = g_entry_tile;
+  if (waves == 0 || waves == 10 || waves == 16) g_entry_tile = waves;
+  return prev;
+}
+
 int orcai_entry_windows(int windows_per_wave) {
   const int prev = g_entry_windows;
   if (windows_per_wave >= 1 && windows_per_wave <= 64) g_entry_windows = windows_per_wave;
@@ -1495,10 +1635,23 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
   if (Cout > 64 || (int64_t)H * W >= (1ll << 26) || (((uintptr_t)w0 | (uintptr_t)dw | (uintptr_t)scale0 | (uintptr_t)shift0) & 15)) return ORCAI_E_UNSUPPORTED;
   const int WP = orcai_padded_width(W, 3);
   if ((int64_t)((Cout + 3) / 4) * (H + 2) * WP >= (1ll << 28)) return ORCAI_E_UNSUPPORTED;  // 32-bit byte offsets inside a snippet's planes
+  hipStream_t st = (hipStream_t)stream;
+  const int nstrip = (W + 61) / 62;
+  if (g_entry_tile && Cout > 16 && Cout <= 32 && nstrip >= 2 && W * 100 >= nstrip * 62 * 85) {  // wide planes: entry rows shared through LDS
+    if (g_entry_tile == 16) {
+      dim3 grid(nstrip * ((H + 13) / 14), B);
+      hipLaunchKernelGGL((conv0_sep_tile_kernel<2, 16>), grid, dim3(1024), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, Cout,
+                         relu_out, out, prev_sub, nstrip);
+    } else {
+      dim3 grid(nstrip * ((H + 7) / 8), B);
+      hipLaunchKernelGGL((conv0_sep_tile_kernel<2, 10>), grid, dim3(640), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, Cout,
+                         relu_out, out, prev_sub, nstrip);
+    }
+    return (int)hipGetLastError();
+  }
   const int tasks = (H * WP + 61) / 62;
   const int NW = g_entry_windows;
   dim3 grid((tasks + 4 * NW - 1) / (4 * NW), B);  // a workgroup = 4 waves side by side over 4*NW consecutive windows
-  hipStream_t st = (hipStream_t)stream;
 #define ORCAI_C0S(MT) hipLaunchKernelGGL(conv0_sep_kernel<MT>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, \
                                          Cout, relu_out, out, prev_sub, tasks, magic_for(WP), NW)
   switch ((Cout + 15) / 16) {

@@ -340,6 +340,8 @@ def test_fused_entry_random_shapes():
     g = torch.Generator(device="cpu").manual_seed(12)
     for case in range(16):
         H, W, Cout = int(rng.integers(1, 40)), int(rng.integers(2, 200)), int(rng.integers(1, 65))
+        if case % 2 == 0:  # shapes of the strip-tile variant: two output tiles, at least two 62-column strips
+            W, Cout = int(rng.integers(106, 260)), int(rng.integers(17, 33))
         B = 3
         stride = (H // 2 + 1) * W  # overlapping snippets of one long array, as predict uses them
         src = torch.randn((B - 1) * stride + H * W, generator=g).to(dev)
@@ -353,8 +355,9 @@ def test_fused_entry_random_shapes():
         a_ref = torch.zeros((B, CQo, H + 2, WP, 4), device=dev)
         assert lib.orcai_conv0_bn_relu(N.ptr(src), stride, B, H, W, 3, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(prev0), st) == 0
         assert lib.orcai_sepconv_bn(N.ptr(prev0), B, 16, H, W, 3, 1, N.ptr(dw), N.ptr(pw), N.ptr(sc), N.ptr(sh), Cout, relu_out, 0, N.ptr(a_ref), st) == 0
-        for nw in (1, 2, 5):
+        for nw, tile in ((1, 0), (2, 0), (5, 0), (4, 10), (4, 16)):
             prev = lib.orcai_entry_windows(nw)
+            prev_tile = lib.orcai_entry_tile(tile)
             try:
                 a = torch.zeros_like(a_ref)
                 sub = torch.zeros((B, 4, (H + 1) // 2, (W + 1) // 2, 4), device=dev)
@@ -363,8 +366,9 @@ def test_fused_entry_random_shapes():
                 torch.cuda.synchronize()
             finally:
                 lib.orcai_entry_windows(prev)
-            assert torch.equal(a, a_ref), (case, H, W, Cout, nw)
-            assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :]), (case, H, W, Cout, nw)
+                lib.orcai_entry_tile(prev_tile)
+            assert torch.equal(a, a_ref), (case, H, W, Cout, nw, tile)
+            assert torch.equal(sub, prev0[:, :, 1:H + 1:2, 0:W:2, :]), (case, H, W, Cout, nw, tile)
 
 
 def test_forward_is_hip_graph_capturable():
