@@ -45,6 +45,157 @@ def _windows(tasks, lanes=64):
     return np.arange(tasks)[:, None], np.arange(lanes)[None, :]
 
 
+# ------------------------------------------------------------------------------------------------ sepconv_tile_kernel / sepconv_ftile_kernel
+def f32_k3_variant(Cin, Cout, H, W, out_layout, u_out, tile_mode=1):
+    """Which kernel launch_sepconv_impl<3, MT> picks for an f32 k = 3 launch on R = 1 planes (model_fwd.hip): 'tile' (strip tiles),
+    'ftile' (flat-range tiles) or 'window' (sepconv_kernel)."""
+    MT, CQ, CQo = -(-Cout // 16), -(-Cin // 4), -(-Cout // 4)
+    WP = padded_width(W, 3)
+    if not tile_mode or not (out_layout == 0 or (out_layout == 2 and not u_out)):
+        return "window"
+    if CQo * (H + 2) * WP >= 1 << 27 or CQ * (H + 2) * WP >= 1 << 27:
+        return "window"
+    if MT == 2 and tile_mode == 1:
+        VALt = 60 if out_layout == 2 else 62
+        nstrip = -(-W // VALt)
+        if CQ <= 8 and nstrip >= 2 and W * 100 >= nstrip * VALt * 85:
+            return "tile"
+    lo = 2 if out_layout == 2 else 1
+    nchunk = (7 * (64 - 2 * lo) + 64 + 2 * WP + 63) // 64
+    lds = (2 * nchunk * 256 + CQ * 64 * MT + 2 * MT * 16) * 4
+    return "ftile" if nchunk <= 24 and lds <= 64 * 1024 else "window"
+
+
+def sepconv_tile(B, Cin, H, W, Cout, out_layout=0, u_out=False, TR=8):
+    """sepconv_tile_kernel<2, CQ, XP, RELU, 8, UOUT>: 8 image rows x 64 columns per workgroup; global row loads (LDS-DMA sources,
+    clamped into the quad plane), LDS slot offsets in KiB rows, output / depthwise-output stores."""
+    t = Touch()
+    XP = out_layout == 2
+    lo = 2 if XP else 1
+    VAL = 64 - 2 * lo
+    WP = padded_width(W, 3)
+    plane = (H + 2) * WP
+    CQ, CQo = -(-Cin // 4), -(-Cout // 4)
+    nstrip = -(-W // VAL)
+    ngroups = -(-H // TR)
+    lane = np.arange(64)[None, None, :]
+    rg = np.arange(ngroups)[:, None, None]
+    strip = np.arange(nstrip)[None, :, None]
+    r0, c0 = rg * TR, strip * VAL
+    lds_rows = []
+    for wave in range(TR):
+        for j in [wave] + ([TR + wave] if wave < 2 else []):  # tile rows this wave fetches
+            i = np.clip((r0 + j) * WP + c0 - lo + lane, 0, plane - 1)
+            for b in (0, B - 1):
+                for cq in (0, CQ - 1):
+                    t.add("in", (b * CQ + cq) * plane + i)
+            lds_rows.append(j)
+        for dy in range(3):  # rows read back: wave .. wave + 2 of a slot of TR + 2 rows
+            lds_rows.append(wave + dy)
+        row = r0 + wave
+        x = c0 - lo + lane
+        live = (lane >= lo) & (lane < 64 - lo) & (x < W) & (row < H)
+        for b in (0, B - 1):
+            if u_out:
+                for cq in (0, CQ - 1):
+                    t.add("u_out", (b * CQ + cq) * plane + (1 + row) * WP + x, live)
+            for oq in (0, CQo - 1):
+                if XP:
+                    Wx = (W + 1) // 2
+                    WPx = (Wx + 3) & ~3
+                    t.add("out", ((b * CQo + oq) * H + row) * WPx + (x >> 1), live & (x % 2 == 0))
+                else:
+                    t.add("out", (b * CQo + oq) * plane + (1 + row) * WP + x, live)
+    t.add("lds_rows", np.array(lds_rows))
+    return t.r, {"grid": (nstrip * ngroups, B), "lds_rows": TR + 2}
+
+
+def sepconv_ftile(B, Cin, H, W, Cout, out_layout=0, u_out=False, NWV=8):
+    """sepconv_ftile_kernel<MT, XP, RELU, UOUT, 8>: 8 consecutive flat windows per workgroup; the LDS-DMA chunks of the contiguous row
+    range (clamped sources, chunk slots), the three LDS rows every wave reads (in pixels of a slot), output / depthwise-output stores."""
+    t = Touch()
+    XP = out_layout == 2
+    lo = 2 if XP else 1
+    VAL = 64 - 2 * lo
+    WP = padded_width(W, 3)
+    plane = (H + 2) * WP
+    CQ, CQo = -(-Cin // 4), -(-Cout // 4)
+    tasks = (H * WP + VAL - 1) // VAL
+    ngroups = -(-tasks // NWV)
+    nchunk = ((NWV - 1) * VAL + 64 + 2 * WP + 63) // 64
+    lane = np.arange(64)[None, :]
+    bx = np.arange(ngroups)[:, None]
+    s0 = bx * NWV * VAL - lo
+    for c in range(nchunk):
+        i = np.clip(s0 + 64 * c + lane, 0, plane - 1)
+        for b in (0, B - 1):
+            for cq in (0, CQ - 1):
+                t.add("in", (b * CQ + cq) * plane + i)
+    for wave in range(NWV):
+        for dy in range(3):
+            t.add("lds_pixels", wave * VAL + lane + dy * WP)
+        task = bx * NWV + wave
+        q = WP + task * VAL - lo + lane
+        row = q // WP
+        x = q - row * WP
+        live = (task < tasks) & (lane >= lo) & (lane < 64 - lo) & (x < W) & (row < 1 + H)
+        for b in (0, B - 1):
+            if u_out:
+                for cq in (0, CQ - 1):
+                    t.add("u_out", (b * CQ + cq) * plane + q, live)
+            for oq in (0, CQo - 1):
+                if XP:
+                    Wx = (W + 1) // 2
+                    WPx = (Wx + 3) & ~3
+                    t.add("out", ((b * CQo + oq) * H + (row - 1)) * WPx + (x >> 1), live & (x % 2 == 0))
+                else:
+                    t.add("out", (b * CQo + oq) * plane + q, live)
+    return t.r, {"grid": (ngroups, B), "lds_pixels": nchunk * 64, "chunks_per_wave": -(-nchunk // NWV)}
+
+
+def sepconv_f32(B, Cin, H, W, Cout, out_layout=0, u_out=False, tile_mode=1):
+    """The f32 k = 3 launch as the launcher would run it (R = 1 planes)."""
+    v = f32_k3_variant(Cin, Cout, H, W, out_layout, u_out, tile_mode)
+    if v == "tile":
+        r, g = sepconv_tile(B, Cin, H, W, Cout, out_layout, u_out)
+    elif v == "ftile":
+        r, g = sepconv_ftile(B, Cin, H, W, Cout, out_layout, u_out)
+    else:
+        r, g = sepconv(B, Cin, H, W, 3, 3, Cout, out_layout, u_out=u_out, G=4)
+    g["variant"] = v
+    return r, g
+
+
+def conv0_sep_tile(B, H, W, Cout, TRW=10):
+    """conv0_sep_tile_kernel<2, TRW>: output-plane stores, the (2i, 2j) subsample stores, LDS rows (the snippet reads go through a
+    range-checked buffer resource)."""
+    t = Touch()
+    TR, VAL = TRW - 2, 62
+    WP = padded_width(W, 3)
+    plane = (H + 2) * WP
+    CQo = -(-Cout // 4)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    nstrip, ngroups = -(-W // VAL), -(-H // TR)
+    lane = np.arange(64)[None, None, :]
+    r0 = (np.arange(ngroups) * TR)[:, None, None]
+    c0 = (np.arange(nstrip) * VAL)[None, :, None]
+    x = c0 - 1 + lane
+    for wave in range(TRW):
+        e = r0 - 1 + wave
+        sub = (wave >= 1) & (wave <= TR) & (lane >= 1) & (lane < 63) & (x < W) & (e < H) & (((x | e) & 1) == 0)
+        for b in (0, B - 1):
+            for cq in (0, 3):
+                t.add("prev_sub", (b * 4 + cq) * Ho * Wo + (e >> 1) * Wo + (x >> 1), sub)
+        if wave < TR:
+            y = r0 + wave
+            live = (lane >= 1) & (lane < 63) & (x < W) & (y < H)
+            for b in (0, B - 1):
+                for oq in (0, CQo - 1):
+                    t.add("out", (b * CQo + oq) * plane + (1 + y) * WP + x, live)
+            t.add("lds_rows", np.array([wave, wave + 2]))
+    return t.r, {"grid": (nstrip * ngroups, B), "lds_rows": TRW}
+
+
 # ------------------------------------------------------------------------------------------------ sepconv_kernel<KS, MT> / sepconv_h_kernel
 def sepconv(B, Cin, H, W, kplanes, ktap, Cout, out_layout=0, H2=0, W2=0, u_out=False, G=4):
     """model_fwd.hip sepconv_kernel (launch_sepconv_impl): lo / VAL / tasks, clamped row indices, the three plane-shaped output layouts

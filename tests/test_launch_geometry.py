@@ -64,6 +64,13 @@ def test_training_step_addresses_stay_inside_their_operands(hw, filters, k, B, G
         for cin, tag in ((c, "a"), (f, "b")):
             r, _ = LG.sepconv(B, cin, h, w, k, k, f, 0, u_out=True, G=G)
             check(r, {"in": planes(cin, h, w), "out": planes(f, h, w), "u_out": planes(cin, h, w)}, f"b{i}/sep_{tag} forward")
+            if G == 4 and k == 3:  # the f32 launcher hands k = 3 plane launches to the LDS-shared-row kernels
+                r, _ = LG.sepconv_f32(B, cin, h, w, f, 0, True)
+                r.pop("lds_rows", None), r.pop("lds_pixels", None)
+                check(r, {"in": planes(cin, h, w), "out": planes(f, h, w), "u_out": planes(cin, h, w)}, f"b{i}/sep_{tag} forward (tile)")
+                r, _ = LG.sepconv_f32(B, cin, h, w, cin, 0, False)
+                r.pop("lds_rows", None), r.pop("lds_pixels", None)
+                check(r, {"in": planes(cin, h, w), "out": planes(cin, h, w)}, f"b{i}/sep_{tag} input gradient (tile)")
             r, g = LG.planes_sums(B, f, h, w, k, G)
             check(r, {"x": planes(f, h, w)}, f"b{i}/bn_{tag} stats")
             assert g["scratch_doubles"] <= 128 and g["grid"][0] >= 1
@@ -103,6 +110,41 @@ def test_training_step_addresses_stay_inside_their_operands(hw, filters, k, B, G
     check(r, {"in": planes(36, h, w), "out": planes(c, h, w)}, "sep_f pointwise^T")
     r, _ = LG.dw_wgrad(B, c, h, w, k, k, G)
     check(r, {"x": planes(c, h, w), "du": planes(c, h, w)}, "sep_f depthwise weight gradient")
+
+
+def test_tile_kernels_stay_inside_their_operands_and_lds():
+    """The LDS-shared-row kernels of the f32 k = 3 launches (strip tiles, flat-range tiles) and the strip-tile entry kernel over a sweep
+    of widths around the strip / window boundaries, one-row planes, ragged channel counts: clamped LDS-DMA sources inside the input
+    planes, stores inside the output / depthwise-output planes and only on interior pixels, LDS rows / pixels inside a slot, at
+    most three chunks per wave; and the launcher's choice covers all three kernels."""
+    seen = set()
+    for (H, W), (Cin, Cout), layout, u_out in itertools.product(
+            [(1, 3), (5, 61), (7, 62), (9, 63), (8, 106), (13, 118), (16, 171), (33, 124), (3, 250), (2, 500), (4, 520)],
+            [(16, 30), (30, 30), (13, 17), (40, 40), (16, 16), (60, 60), (7, 64)], (0, 2), (False, True)):
+        if u_out and layout == 2:
+            continue
+        B = 2
+        r, g = LG.sepconv_f32(B, Cin, H, W, Cout, layout, u_out)
+        seen.add(g["variant"])
+        WP = LG.padded_width(W, 3)
+        plane = (H + 2) * WP
+        Wx = (W + 1) // 2
+        sizes = {"in": B * -(-Cin // 4) * plane, "u_out": B * -(-Cin // 4) * plane,
+                 "out": B * -(-Cout // 4) * (plane if layout == 0 else H * ((Wx + 3) & ~3))}
+        if g["variant"] == "tile":
+            sizes["lds_rows"] = g["lds_rows"]
+        if g["variant"] == "ftile":
+            sizes["lds_pixels"] = g["lds_pixels"]
+            assert g["chunks_per_wave"] <= 3
+        check(r, sizes, (g["variant"], H, W, Cin, Cout, layout, u_out))
+        if layout == 0:  # stores only on interior pixels: the first / last plane row and the padding columns are never written
+            lo_out, hi_out = r["out"]
+            assert lo_out >= WP and hi_out <= B * -(-Cout // 4) * plane - WP
+    assert seen == {"tile", "ftile", "window"}
+    for (H, W), Cout, trw in itertools.product([(1, 106), (9, 118), (17, 171), (8, 124), (30, 250)], (17, 30, 32), (10, 16)):
+        r, g = LG.conv0_sep_tile(2, H, W, Cout, trw)
+        WP = LG.padded_width(W, 3)
+        check(r, {"out": 2 * -(-Cout // 4) * (H + 2) * WP, "prev_sub": 2 * 4 * ((H + 1) // 2) * ((W + 1) // 2), "lds_rows": g["lds_rows"]}, ("conv0_sep_tile", H, W, Cout, trw))
 
 
 def test_x_pooled_layout_and_window_cover():
