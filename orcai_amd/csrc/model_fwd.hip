@@ -1210,142 +1210,6 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
 }
 
 // =========================================================================================
-// pool_res_march: pool_res_add_x_kernel's arithmetic with every x-pooled input row fetched ONCE.  The flat-window kernel reads the
-// three rows 2i - pad + {0, 1, 2} of every output row; row 2i + 2 is also row 0 of output row i + 1, which a neighbouring wave
-// requests at some other time: PMC shows 1.64 GB fetched per block-1 launch for 0.99 GB of input -- the kernel runs at 5.7 TB/s of
-// actual traffic and wastes a third of it.  Here a wave owns four CHAINS, one per 16-pixel column tile slot t of its MFMA layout:
-// chain = (16 output columns, a run of SEG output rows); it walks down its rows carrying the shared row in registers (the D layout:
-// lane (lk, lj) holds quad 4m + lk of column lj), so a step loads two new rows per (m, t).  The residual 1x1 convolution is the
-// MFMA contraction of the flat kernel with lane = (slot, column) instead of 64 consecutive pixels.  Same max / add expressions in
-// the same order: bit-identical output.
-// =========================================================================================
-template <int MT>
-__global__ __launch_bounds__(256, 2) void pool_res_march_kernel(const float* __restrict__ s /*[B][CQ][H][WPx][4]*/, const float* __restrict__ prev,
-                                                                            int C, int Cp, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top,
-                                                                            const float* __restrict__ wr /*[Cp][C]*/, const float* __restrict__ br,
-                                                                            float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int prev_compact, int NT, int SEG,
-                                                                            int chains) {
-  const int lane = threadIdx.x & 63;
-  int bx, b;
-  xcd_remap(bx, b);
-  const int lk = lane >> 4, lj = lane & 15;
-  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const int WPx = (Wo + 3) & ~3;
-  const int plane_o = (Ho + 2 * R) * WPo;
-  const int64_t plane_p = prev_compact ? (int64_t)Ho * Wo : (int64_t)(H + 2 * R) * WP;
-  __shared__ float wr_s[16 * 4 * 16 * MT];  // residual weights as MFMA A fragments: [(ci * 16 + lj)][m], Cp <= 64
-  for (int i = threadIdx.x; i < CQp * 4 * 16 * MT; i += 256) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    wr_s[i] = (ci < Cp && co < C) ? wr[ci * C + co] : 0.0f;
-  }
-  __syncthreads();  // the only barrier
-  const int c0 = (bx * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 4;  // this wave's first chain (wave-uniform: chain rows and tiles live in SGPRs)
-  if (c0 >= chains) return;
-
-  // slot t of the D layout (pooling operands, output): chain c0 + t
-  int colD[4], rowD[4];
-  bool liveD[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = c0 + t, seg = c / NT, tile = c - seg * NT;
-    colD[t] = 16 * tile + lj;
-    rowD[t] = seg * SEG;
-    liveD[t] = c < chains && colD[t] < Wo;
-    colD[t] = colD[t] < Wo ? colD[t] : Wo - 1;  // dead lanes read a valid pixel and store nothing
-  }
-  // lane = (slot, column) for the residual operand: slot lk, column lj
-  const int cL = c0 + lk, segL = cL / NT, tileL = cL - segL * NT;
-  int colL = 16 * tileL + lj;
-  colL = colL < Wo ? colL : Wo - 1;
-  const int rowL = (cL < chains ? segL : 0) * SEG;
-
-  const char* sbase = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(s) + (int64_t)b * CQ * H * WPx);
-  uint32_t qoff[MT];
-  float br_r[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int oq = m * 4 + lk;
-    qoff[m] = (uint32_t)((oq < CQ ? oq : 0) * H * WPx);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = m * 16 + lk * 4 + r;
-      const float bv = br[co < C ? co : 0];
-      br_r[m][r] = co < C ? bv : 0.0f;
-    }
-  }
-  auto ld = [&](int m, int t, int y) {
-    y = y < 0 ? 0 : (y >= H ? H - 1 : y);  // a duplicated row leaves a maximum unchanged
-    return *reinterpret_cast<const float4*>(sbase + (qoff[m] + (uint32_t)(y * WPx + colD[t])) * 16u);
-  };
-  float4 carry[MT][4];  // row 2i - pad_top of the current output row
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) carry[m][t] = ld(m, t, 2 * rowD[t] - pad_top);
-
-  for (int i = 0; i < SEG; ++i) {
-    // ---- residual branch at the four chains' pixels of this step
-    const int pL = rowL + i < Ho ? rowL + i : Ho - 1;
-    const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane_p + (prev_compact ? pL * Wo + colL : (2 * pL + R) * WP + 2 * colL);
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // every load of the step is requested up front -- 2 MT x 4 pooling rows and the residual input quads (CQP at a time) -- so a
-    // wave has 8 MT + CQP KiB in flight and the step costs one memory latency; two waves per SIMD carry the bandwidth
-    constexpr int CQP = 4;
-    float4 rows[MT][4][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int y = 2 * (rowD[t] + i) - pad_top;
-        rows[m][t][0] = ld(m, t, y + 1);
-        rows[m][t][1] = ld(m, t, y + 2);
-      }
-    for (int c4 = 0; c4 < CQp; c4 += CQP) {
-      float4 pv[CQP];
-#pragma unroll
-      for (int u = 0; u < CQP; ++u) pv[u] = pp[(int64_t)(c4 + u < CQp ? c4 + u : CQp - 1) * plane_p];
-#pragma unroll
-      for (int u = 0; u < CQP; ++u) {
-        if (c4 + u < CQp) {  // wave-uniform
-          float d[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
-          swap32(d[0], d[2]);
-          swap32(d[1], d[3]);
-          swap16(d[0], d[1]);
-          swap16(d[2], d[3]);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(wr_s[(((c4 + u) * 4 + lk) * 16 + lj) * MT + m], d[t], acc[m][t]);
-        }
-      }
-    }
-    // ---- pooling + add + store
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float mx[4] = {carry[m][t].x, carry[m][t].y, carry[m][t].z, carry[m][t].w};
-        mx[0] = fmaxf(mx[0], rows[m][t][0].x); mx[1] = fmaxf(mx[1], rows[m][t][0].y); mx[2] = fmaxf(mx[2], rows[m][t][0].z); mx[3] = fmaxf(mx[3], rows[m][t][0].w);
-        mx[0] = fmaxf(mx[0], rows[m][t][1].x); mx[1] = fmaxf(mx[1], rows[m][t][1].y); mx[2] = fmaxf(mx[2], rows[m][t][1].z); mx[3] = fmaxf(mx[3], rows[m][t][1].w);
-        carry[m][t] = rows[m][t][1];
-        const int p = rowD[t] + i;
-        if (liveD[t] && p < Ho && oq < CQ) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f;
-          reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + (R + p) * WPo + colD[t]] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-      }
-    }
-  }
-}
-
-// =========================================================================================
 // gemm: C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]     (LSTM input projections, Dense-128)
 // 128 x 128 block tile, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (4 x 4 MFMA 16x16x4 tiles).
 // MFMA row = M index, MFMA column = N index.
@@ -1620,7 +1484,6 @@ struct SepArgs {
   float* u_out = nullptr;
 };
 
-int g_pool_march = 1;      // x-pooled pool_res_add with <= 48 channels on pool_res_march_kernel (0: pool_res_add_x_kernel)
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
@@ -1726,12 +1589,6 @@ int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int 
 }
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
-
-int orcai_pool_march(int on) {
-  const int prev = g_pool_march;
-  if (on == 0 || on == 1) g_pool_march = on;
-  return prev;
-}
 
 int orcai_entry_tile(int waves) {
   const int prev = g_entry_tile;
@@ -1849,16 +1706,8 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   dim3 grid((tasks + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t mg = magic_for(WPo);
-  // x-pooled input, up to three output tiles: the row-marching kernel (every input row fetched once); chains of 16 columns x SEG rows
-  const int NT = (Wo + 15) / 16, SEG = Ho / 16 > 8 ? (Ho + 15) / 16 : 8, chains = NT * ((Ho + SEG - 1) / SEG);
-  const bool march = g_pool_march && (xpooled & 1) && !bn_mean && C <= 48 && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28) &&
-                     (int64_t)((C + 3) / 4) * (Ho + 2 * R) * WPo < (1ll << 31);
-  dim3 mgrid((chains + 15) / 16, B);
 #define ORCAI_POOL_LAUNCH(MT)                                                                                                                        \
-  if (march && MT <= 3)                                                                                                                              \
-    hipLaunchKernelGGL(pool_res_march_kernel<(MT <= 3 ? MT : 1)>, mgrid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out,     \
-                       (xpooled >> 1) & 1, NT, SEG, chains);                                                                                         \
-  else if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                \
+  if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                     \
     hipLaunchKernelGGL(pool_res_add_x_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out, (xpooled >> 1) & 1, \
                        tasks, mg);                                                                                                                   \
   else                                                                                                                                               \
