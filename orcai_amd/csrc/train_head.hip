@@ -475,17 +475,22 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __re
   float cst[4] = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   const int unit = wave * 8 + (lj & 7);
-  for (int step = 0; step < T; ++step) {
-    const int t = dir ? (T - 1 - step) : step;
-    const int cur = step & 1;
-    f32x4 acc[2];
+  f32x4 xz_next[2];
+  auto load_xz = [&](int tt) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int bb = b0 + lk * 4 + r;
-        acc[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+        xz_next[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + tt) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
       }
+  };
+  load_xz(dir ? T - 1 : 0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2] = {xz_next[0], xz_next[1]};
+    if (step + 1 < T) load_xz(dir ? (T - 2 - step) : step + 1);  // the next step's input projection is in flight during this step's recurrence
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) {
       const float a = hbuf[cur][lj][kk * 4 + lk];
