@@ -449,21 +449,36 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
   const bool contributes = lane >= R && lane < 64 - R;
-  for (int task = wv * tasks_per_wave; task < (wv + 1) * tasks_per_wave && task < tasks; ++task) {
+  // k = 3: the next window's four loads are requested before the current window's products (unconditional, clamped; the gradient of
+  // a non-contributing lane is zeroed afterwards): two windows in flight per wave, as in the f32 kernel
+  constexpr bool AHEAD = KS == 3;
+  const int task0 = wv * tasks_per_wave, task_end = min((wv + 1) * tasks_per_wave, tasks);
+  h16x8 gn, an[KS];
+  auto request = [&](int task) {
     const int q = RP * WP + task * VAL - R + lane;
-    float g[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) g[j] = 0.f;
-    if (contributes && q < plane) {
-      const h16x8 g8 = reinterpret_cast<const h16x8*>(du)[base + q];
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) g[j] = (float)g8[c0 + j];
-    }
+    gn = reinterpret_cast<const h16x8*>(du)[base + (q < plane ? q : plane - 1)];
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       int i = q + (dy - R) * WP;
       i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-      h16x8 a8 = reinterpret_cast<const h16x8*>(x)[base + i];
+      an[dy] = reinterpret_cast<const h16x8*>(x)[base + i];
+    }
+  };
+  if (AHEAD && task0 < task_end) request(task0);
+  for (int task = task0; task < task_end; ++task) {
+    const int q = RP * WP + task * VAL - R + lane;
+    const bool live = contributes && q < plane;
+    if (!AHEAD) request(task);
+    float g[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) g[j] = live ? (float)gn[c0 + j] : 0.f;
+    h16x8 ac[KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) ac[dy] = an[dy];
+    if (AHEAD && task + 1 < task_end) request(task + 1);
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      h16x8 a8 = ac[dy];
       if (relu_in) a8 = relu_h(a8);
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {

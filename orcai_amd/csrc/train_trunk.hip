@@ -516,16 +516,34 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
   const bool contributes = lane >= R && lane < 64 - R;
-  for (int task = wv * tasks_per_wave; task < (wv + 1) * tasks_per_wave && task < tasks; ++task) {
+  // the next window's KS + 1 loads are requested before the current window's products (unconditional, clamped; the gradient of a
+  // non-contributing lane is zeroed afterwards): two windows in flight per wave
+  const int task0 = wv * tasks_per_wave, task_end = min((wv + 1) * tasks_per_wave, tasks);
+  float4 gn = make_float4(0.f, 0.f, 0.f, 0.f), an[KS];
+  auto request = [&](int task) {
     const int q = RP * WP + task * VAL - R + lane;
-    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (contributes && q < plane) g4 = dp[q];
-    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    gn = dp[q < plane ? q : plane - 1];
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       int i = q + (dy - R) * WP;
       i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
-      const float4 a4 = xp[i];
+      an[dy] = xp[i];
+    }
+  };
+  constexpr bool AHEAD = KS == 3;  // k = 5, 7 hold 100 / 196 accumulators: no room for a second set of rows
+  if (AHEAD && task0 < task_end) request(task0);
+  for (int task = task0; task < task_end; ++task) {
+    const int q = RP * WP + task * VAL - R + lane;
+    const bool live = contributes && q < plane;
+    if (!AHEAD) request(task);
+    const float g[4] = {live ? gn.x : 0.f, live ? gn.y : 0.f, live ? gn.z : 0.f, live ? gn.w : 0.f};
+    float4 ac[KS];
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) ac[dy] = an[dy];
+    if (AHEAD && task + 1 < task_end) request(task + 1);
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy) {
+      const float4 a4 = ac[dy];
       float a[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
