@@ -368,10 +368,14 @@ __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restri
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int chunks_per_plane = (plane + 255) >> 8;
   const int64_t nchunks = (int64_t)B * chunks_per_plane;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  // the next pass's octets are requested into registers before this pass's MFMA phase (as the f32 kernel does): without it every
+  // pass exposed one full memory latency between its two barriers
+  constexpr int MAXO = 8;  // up to 64 channels per operand
+  h16x8 ra[MAXO], rb[MAXO];
+  auto fetch = [&](int64_t ch) {
     const int64_t b = ch / chunks_per_plane;
     const int p = (int)(ch - b * chunks_per_plane) * 256 + tid;
-    const bool pin = p < plane;
+    const bool pin = ch < nchunks && p < plane;
     int pa = p;
     bool ain = pin;
     if (a_mode) {
@@ -380,12 +384,22 @@ __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restri
       ain = pin && i >= 0 && i < H && x < W;
       pa = ain ? (2 * i + R) * WPa + 2 * x : 0;
     }
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+      ra[q] = (q < COa && ain) ? reinterpret_cast<const h16x8*>(A)[((int64_t)b * COa + q) * plane_a + pa] : zero_h();
+      rb[q] = (q < COb && pin) ? reinterpret_cast<const h16x8*>(Bq)[((int64_t)b * COb + q) * plane + p] : zero_h();
+    }
+  };
+  fetch(blockIdx.x);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     __syncthreads();  // the previous pass's MFMA reads are done (and the zero fill is visible)
-    for (int q = 0; q < COa; ++q)
-      *reinterpret_cast<h16x8*>(As + tid * pa_h + 8 * q) = ain ? reinterpret_cast<const h16x8*>(A)[((int64_t)b * COa + q) * plane_a + pa] : zero_h();
-    for (int q = 0; q < COb; ++q)
-      *reinterpret_cast<h16x8*>(Bs + tid * pb_h + 8 * q) = pin ? reinterpret_cast<const h16x8*>(Bq)[((int64_t)b * COb + q) * plane + p] : zero_h();
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+      if (q < COa) *reinterpret_cast<h16x8*>(As + tid * pa_h + 8 * q) = ra[q];
+      if (q < COb) *reinterpret_cast<h16x8*>(Bs + tid * pb_h + 8 * q) = rb[q];
+    }
     __syncthreads();
+    fetch(ch + gridDim.x);  // in flight during the MFMA phase
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const int tile = wave + 4 * ti;
