@@ -138,11 +138,6 @@ int orcai_entry_windows(int windows_per_wave);
  * 0 = conv0_sep_kernel everywhere.  Bit-identical either way.  Returns the previous value; other values only query. */
 int orcai_entry_tile(int waves);
 
-/* orcai_pool_res_add with an x-pooled input (flag 1): 1 (default) = pool_res_ftile_kernel (a band of whole output rows per workgroup,
- * the pooling rows of one quad plane fetched once by LDS-DMA, lane = pixel, 1 KiB contiguous loads and stores); 0 =
- * pool_res_add_x_kernel (independent flat windows).  Bit-identical.  Returns the previous value; other values only query. */
-int orcai_pool_tile(int on);
-
 /* Conv2D(16, k, padding="same") + BN + ReLU on the 1-channel spectrogram (architectures.py:164-168).
  *   in              f32, UNPADDED: snippet b starts at in + b*snippet_stride and is [H][W] row-major.  For the sliding
  *                   50 % overlap view of a [T][W] spectrogram use snippet_stride = (H/2)*W: no snippet copy is

@@ -36,7 +36,6 @@ _SIGNATURES = {
     "orcai_sepconv_tile_mode": (C.c_int, [C.c_int]),
     "orcai_entry_windows": (C.c_int, [C.c_int]),
     "orcai_entry_tile": (C.c_int, [C.c_int]),
-    "orcai_pool_tile": (C.c_int, [C.c_int]),
     "orcai_conv0_sepconv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "orcai_lstm_recurrent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

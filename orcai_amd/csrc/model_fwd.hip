@@ -1210,156 +1210,6 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
 }
 
 // =========================================================================================
-// pool_res_ftile: pool_res_add_x_kernel's arithmetic with the pooling rows shared through LDS and every global access 1 KiB
-// contiguous.  PMC on the flat-window kernel: 1.64 GB fetched per block-1 launch for 0.99 GB of input (the row two pooling windows
-// share is requested by different waves at different times, in 256-byte segments of four quad planes at once).  Here a workgroup owns
-// a band of K whole output rows = NW 64-pixel windows exactly (K * WPo is a multiple of 64; lane = pixel); per output quad the 2K + 1
-// input rows the band pools over -- a contiguous range of ONE quad plane -- are fetched once by LDS-DMA into one of two slots (the
-// sepconv_ftile scheme: 2.1 rows per output row instead of 3), every lane takes the maximum of its three rows from LDS, and the block
-// output leaves as one 16-byte store per lane and quad.  The residual 1x1 convolution runs first on the MFMA as before; its D tiles are brought to the
-// lane = pixel layout by the inverse of the B-fragment transpose (16 MT permlane swaps).  Same max / add expressions in the same
-// order: bit-identical output.
-// =========================================================================================
-template <int MT>
-__global__ __launch_bounds__(768) void pool_res_ftile_kernel(const float* __restrict__ s /*[B][CQ][H][WPx][4]*/, const float* __restrict__ prev, int C, int Cp, int H,
-                                                            int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, const float* __restrict__ wr /*[Cp][C]*/,
-                                                            const float* __restrict__ br, float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int prev_compact,
-                                                            int K, uint32_t magic_WPo, int slot_px) {
-  const int NWV = blockDim.x >> 6;  // windows (= waves) per band: K * WPo / 64
-  extern __shared__ __attribute__((aligned(16))) float smem_pf[];  // [2][slot_px][4]
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int bx, b;
-  xcd_remap(bx, b);
-  const int lk = lane >> 4, lj = lane & 15;
-  const int CQ = (C + 3) >> 2, CQp = (Cp + 3) >> 2;
-  const int WPx = (Wo + 3) & ~3;
-  const int plane_o = (Ho + 2 * R) * WPo;
-  const int64_t plane_p = prev_compact ? (int64_t)Ho * Wo : (int64_t)(H + 2 * R) * WP;
-  const int plane_s = H * WPx;
-
-  // rows of the x-pooled planes this workgroup pools over: output rows i_lo .. i_hi of its band
-  const int i_lo = bx * K;
-  const int i_hi = i_lo + K - 1 < Ho ? i_lo + K - 1 : Ho - 1;
-  int yb = 2 * i_lo - pad_top;
-  yb = yb < 0 ? 0 : (yb >= H ? H - 1 : yb);
-  const int nchunk = ((2 * (i_hi - i_lo) + 3) * WPx + 63) >> 6;     // <= slot_px / 64
-  const char* sbase = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(s) + (int64_t)b * CQ * plane_s);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_pf;
-  uint32_t goff[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int p = yb * WPx + 64 * (wave + u * NWV) + lane;
-    goff[u] = (uint32_t)(p < plane_s ? p : plane_s - 1) * 16u;  // clamped: positions past the plane are never read back
-  }
-  const int mine = wave < nchunk ? (wave + NWV < nchunk ? (wave + 2 * NWV < nchunk ? 3 : 2) : 1) : 0;
-  auto issue = [&](int oq) {
-    const char* base = sbase + (int64_t)oq * plane_s * 16;
-    const uint32_t slot = lds0 + (uint32_t)((oq & 1) * slot_px * 16);
-    if (mine > 0) glds16(base + goff[0], slot + (uint32_t)wave * 1024u);
-    if (mine > 1) glds16(base + goff[1], slot + (uint32_t)(wave + NWV) * 1024u);
-    if (mine > 2) glds16(base + goff[2], slot + (uint32_t)(wave + 2 * NWV) * 1024u);
-  };
-  issue(0);
-
-  // ---- this wave's window: lane = output pixel
-  const int q = (R + i_lo) * WPo + wave * 64 + lane;
-  const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
-  const int pj = q - prow * WPo, pi = prow - R;
-  const bool pvalid = pj < Wo && pi < Ho;
-  const int jc = pj < Wo ? pj : Wo - 1, ic = pi < Ho ? pi : Ho - 1;
-  // ---- residual branch: Conv2D(C, 1, strides 2)(prev) at the window's 64 pixels, MFMA (see pool_res_add_x_kernel)
-  f32x4 acc[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  {
-    const int srcpix = prev_compact ? ic * Wo + jc : (2 * ic + R) * WP + 2 * jc;
-    const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane_p + srcpix;
-    float4 nxt = pp[0];
-    for (int cq = 0; cq < CQp; ++cq) {
-      const float4 cur = nxt;
-      if (cq + 1 < CQp) nxt = pp[(int64_t)(cq + 1) * plane_p];
-      float afrag[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int ci = cq * 4 + lk, co = m * 16 + lj;
-        const bool ok = ci < Cp && co < C;
-        const float av = wr[ok ? ci * C + co : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      float d[4] = {cur.x, cur.y, cur.z, cur.w};
-      swap32(d[0], d[2]);
-      swap32(d[1], d[3]);
-      swap16(d[0], d[1]);
-      swap16(d[2], d[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], d[t], acc[m][t]);
-    }
-  }
-  // D tile (m, t), register r, lane (lk, lj) = channel 16m + 4lk + r of pixel 16t + lj.  The inverse of the B-fragment transpose on
-  // the four tile registers of a fixed (m, r) leaves register c with channel 16m + 4c + r of pixel lane: output quad 4m + c takes its
-  // four channels from registers (m, r = 0..3, c).
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x0 = acc[m][0][r], x1 = acc[m][1][r], x2 = acc[m][2][r], x3 = acc[m][3][r];
-      swap16(x0, x1);
-      swap16(x2, x3);
-      swap32(x0, x2);
-      swap32(x1, x3);
-      acc[m][0][r] = x0; acc[m][1][r] = x1; acc[m][2][r] = x2; acc[m][3][r] = x3;
-    }
-  // LDS pixel of this lane's three pooling rows (clamped rows: a duplicated row leaves a maximum unchanged)
-  uint32_t lpix[3];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    int y = 2 * ic - pad_top + dy;
-    y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-    lpix[dy] = (uint32_t)((y - yb) * WPx + jc) * 4u;  // float index inside a slot
-  }
-  const bool any_store = __builtin_amdgcn_readfirstlane((int)(__ballot(pvalid) != 0ull)) != 0;
-  float4* outp = reinterpret_cast<float4*>(out) + (int64_t)b * CQ * plane_o + q;
-
-  for (int oq = 0; oq < CQ; ++oq) {
-    // outstanding, oldest first: this wave's DMAs of quad oq, then (a wave that stores) the output store of quad oq - 1
-    if (any_store && oq > 0) wait_vm_barrier<1>(); else wait_vm_barrier<0>();
-    if (oq + 1 < CQ) issue(oq + 1);
-    const float* rs = smem_pf + (oq & 1) * slot_px * 4;
-    const float4 v0 = *reinterpret_cast<const float4*>(rs + lpix[0]);
-    const float4 v1 = *reinterpret_cast<const float4*>(rs + lpix[1]);
-    const float4 v2 = *reinterpret_cast<const float4*>(rs + lpix[2]);
-    float mx[4] = {v0.x, v0.y, v0.z, v0.w};
-    mx[0] = fmaxf(mx[0], v1.x); mx[1] = fmaxf(mx[1], v1.y); mx[2] = fmaxf(mx[2], v1.z); mx[3] = fmaxf(mx[3], v1.w);
-    mx[0] = fmaxf(mx[0], v2.x); mx[1] = fmaxf(mx[1], v2.y); mx[2] = fmaxf(mx[2], v2.z); mx[3] = fmaxf(mx[3], v2.w);
-    const int m = oq >> 2, c = oq & 3;
-    float res[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {  // acc[m][c][r] with run-time m, c: selected by wave-uniform compares
-      float v = 0.0f;
-#pragma unroll
-      for (int mm = 0; mm < MT; ++mm)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) v = (mm == m && cc == c) ? acc[mm][cc][r] : v;
-      res[r] = v;
-    }
-    if (pvalid) {
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = oq * 4 + r;
-        const float bv = br[co < C ? co : 0];
-        o[r] = co < C ? mx[r] + (res[r] + bv) : 0.0f;
-      }
-      outp[(int64_t)oq * plane_o] = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  }
-}
-
-// =========================================================================================
 // gemm: C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]     (LSTM input projections, Dense-128)
 // 128 x 128 block tile, BK = 16, 4 waves as 2 x 2, wave tile 64 x 64 (4 x 4 MFMA 16x16x4 tiles).
 // MFMA row = M index, MFMA column = N index.
@@ -1639,7 +1489,6 @@ struct SepArgs {
   float* u_out = nullptr;
 };
 
-int g_pool_tile = 1;       // x-pooled pool_res_add on pool_res_ftile_kernel (0: pool_res_add_x_kernel)
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
@@ -1745,12 +1594,6 @@ int orcai_conv1d_sigmoid(const float* x, const float* w, const float* bias, int 
 }
 
 int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
-
-int orcai_pool_tile(int on) {
-  const int prev = g_pool_tile;
-  if (on == 0 || on == 1) g_pool_tile = on;
-  return prev;
-}
 
 int orcai_entry_tile(int waves) {
   const int prev = g_entry_tile;
@@ -1868,24 +1711,8 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   dim3 grid((tasks + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t mg = magic_for(WPo);
-  // x-pooled input: the LDS-shared-row kernel.  A band = K whole output rows = NW windows exactly: K a multiple of 64 / gcd(WPo, 64),
-  // the largest with NW <= 12 waves
-  const int WPx_ = (Wo + 3) & ~3;
-  int g64 = 64, w64 = WPo;
-  while (w64) { const int tmp = g64 % w64; g64 = w64; w64 = tmp; }  // gcd(64, WPo) >= 4
-  const int K0 = 64 / g64, NW0 = K0 * WPo / 64;
-  const int rep = NW0 <= 12 ? 12 / NW0 : 0;
-  const int Kb = K0 * rep, NWb = NW0 * rep;
-  const int slot_px = ((2 * Kb + 1) * WPx_ + 63) / 64 * 64;
-  const size_t pf_lds = (size_t)2 * slot_px * 16;
-  const bool pftile = g_pool_tile && (xpooled & 1) && !bn_mean && rep >= 1 && slot_px <= 3 * NWb * 64 && pf_lds <= 64 * 1024 &&
-                      (int64_t)((C + 3) / 4) * H * WPx_ < (1ll << 27) && (int64_t)((C + 3) / 4) * (Ho + 2 * R) * WPo < (1ll << 31);
-  dim3 pgrid(pftile ? (Ho + Kb - 1) / Kb : 1, B);
 #define ORCAI_POOL_LAUNCH(MT)                                                                                                                        \
-  if (pftile)                                                                                                                                        \
-    hipLaunchKernelGGL(pool_res_ftile_kernel<MT>, pgrid, dim3(64 * NWb), pf_lds, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out,   \
-                       (xpooled >> 1) & 1, Kb, mg, slot_px);                                                                                         \
-  else if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                \
+  if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                     \
     hipLaunchKernelGGL(pool_res_add_x_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out, (xpooled >> 1) & 1, \
                        tasks, mg);                                                                                                                   \
   else                                                                                                                                               \

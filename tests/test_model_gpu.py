@@ -252,64 +252,6 @@ def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in
         assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("C,Cp,H,W,compact", [
-    (30, 16, 736, 171, 1),   # orcai-V1 block 1 behind the fused entry kernel
-    (40, 30, 368, 86, 0),    # block 2: three output tiles, residual input as full planes
-    (30, 16, 35, 171, 0),    # odd H: the pooling pads one row on top
-    (17, 5, 1, 33, 1),       # one image row, ragged channels
-    (64, 48, 20, 64, 0),     # even W, four output tiles
-    (8, 8, 9, 300, 0),       # one output tile, many column tiles
-    (20, 12, 130, 7, 1),     # narrower than a column tile, several row segments
-])
-def test_tile_pool_is_bit_identical(C, Cp, H, W, compact):
-    """pool_res_ftile_kernel (8 output windows per workgroup, the pooling rows of one quad plane shared through LDS, lane = pixel, the
-    residual tiles brought over by the inverse fragment transpose) against pool_res_add_x_kernel (independent flat windows) and
-    against the generic kernel on the un-pooled tensor: block outputs equal bit for bit, pads of the output planes untouched."""
-    from orcai_amd import _native as N
-
-    lib = N.lib()
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device="cpu").manual_seed(C * 1000 + Cp * 10 + H)
-    B, CQ, CQp, WP = 3, (C + 3) // 4, (Cp + 3) // 4, lib.orcai_padded_width(W, 3)
-    Ho, Wo = (H + 1) // 2, (W + 1) // 2
-    WPo, WPx = lib.orcai_padded_width(Wo, 3), (Wo + 3) // 4 * 4
-
-    def planes(Cc, h, w, wp):
-        x = torch.zeros(B, (Cc + 3) // 4 * 4, h + 2, wp)
-        x[:, :Cc, 1:h + 1, :w] = torch.randn(B, Cc, h, w, generator=g)
-        return x.view(B, (Cc + 3) // 4, 4, h + 2, wp).permute(0, 1, 3, 4, 2).contiguous()
-
-    sfull = planes(C, H, W, WP)  # the un-pooled activation, as planes
-    inner = sfull[:, :, 1:H + 1, :, :]
-    cols = torch.full((B, CQ, H, 2 * WPx, 4), float("-inf"))
-    cols[:, :, :, :W] = inner[:, :, :, :W]
-    sx = torch.maximum(cols[:, :, :, 0::2], cols[:, :, :, 1::2]).contiguous()  # [B][CQ][H][WPx][4]: max over the column pair
-    sx[:, :, :, Wo:] = 0.0
-    pfull = planes(Cp, H, W, WP)
-    prev = (pfull[:, :, 1:H + 1:2, 0:W:2, :].contiguous() if compact else pfull).to(dev)
-    wr = (torch.randn(Cp, C, generator=g) / Cp ** 0.5).to(dev)
-    br = torch.randn(C, generator=g).to(dev)
-    st = N.stream_ptr()
-    sxd, sfd = sx.to(dev), sfull.to(dev)
-    outs = []
-    for tile in (0, 1):
-        prev_mode = lib.orcai_pool_tile(tile)
-        try:
-            out = torch.full((B, CQ, Ho + 2, WPo, 4), 7.0, device=dev)  # a sentinel in the pads: no kernel may write them
-            assert lib.orcai_pool_res_add(N.ptr(sxd), N.ptr(prev), B, C, Cp, H, W, 3, N.ptr(wr), N.ptr(br), N.ptr(out), 3 if compact else 1, st) == 0
-            torch.cuda.synchronize()
-        finally:
-            lib.orcai_pool_tile(prev_mode)
-        outs.append(out)
-    assert float(outs[0][:, :, 1:Ho + 1, :Wo].abs().max()) > 0
-    assert torch.equal(outs[1], outs[0])
-    if not compact:  # the generic kernel pools the un-pooled planes itself
-        ref = torch.full((B, CQ, Ho + 2, WPo, 4), 7.0, device=dev)
-        assert lib.orcai_pool_res_add(N.ptr(sfd), N.ptr(prev), B, C, Cp, H, W, 3, N.ptr(wr), N.ptr(br), N.ptr(ref), 0, st) == 0
-        torch.cuda.synchronize()
-        assert torch.equal(outs[1], ref)
-
-
 @pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])
 def test_fused_entry_convolution_is_bit_identical(shape, filters):
     """orcai_conv0_sepconv (entry convolution computed inside block 1's first separable convolution, compact (2i, 2j) subsample for

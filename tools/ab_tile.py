@@ -21,8 +21,7 @@ lib = N.lib()
 ref = None
 for nw in nws + [nws[0]]:
     lib.orcai_sepconv_tile_mode(nw % 10)
-    lib.orcai_entry_tile({0: 10, 1: 0, 2: 16}.get(nw // 10 % 10, 10))  # + 10: entry kernel without tiles, + 20: 16-wave entry tiles
-    lib.orcai_pool_tile(0 if nw >= 100 else 1)  # + 100: flat-window pooling kernel
+    lib.orcai_entry_tile({0: 10, 1: 0, 2: 16}[nw // 10])  # + 10: entry kernel without tiles, + 20: 16-wave entry tiles
     for it in range(3):
         model.kernel_events = {}
         pred = model.predict_spectrogram(spec, chunk=chunk)
