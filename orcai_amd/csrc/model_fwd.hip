@@ -13,6 +13,7 @@
 //   BatchNormalization (inference)               -> y = x*scale + shift, folded on the host
 //   LSTM gate order i,f,c,o; Bidirectional concat [fwd, bwd]
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdint>
 
@@ -1031,57 +1032,95 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
       br_r[m][r] = co < C ? br[co] : 0.0f;
     }
   const int WPx = (Wo + 3) & ~3;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int flat = qbase + 16 * t + lj;
-    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);
-    const int j = flat - row * WPo, i = row - R;
-    if (j >= Wo || i >= Ho) continue;
-    const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int oq = m * 4 + lk;
-      if (oq >= CQ) continue;
-      float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-      if (xpooled) {  // s is [B][CQ][H][WPx][4], already reduced over the column pair (pad_left == 0)
-        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * (int64_t)H * WPx;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int y = ys + dy;
-          if (y >= 0 && y < H) {
-            const float4 v = sp[(int64_t)y * WPx + j];
-            mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
-          }
-        }
-      } else {
-        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * plane;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int y = ys + dy, x = xs + dx;
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-              const float4 v = sp[(int64_t)(y + R) * WP + x];
-              mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z); mx[3] = fmaxf(mx[3], v.w);
-              if (bn_mean) { mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z); mn[3] = fminf(mn[3], v.w); }
-            }
-          }
-      }
-      if (bn_mean) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = oq * 4 + r, cc = c < C ? c : 0;
-          const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps);  // same expressions as bn_planes_apply_kernel
-          mx[r] = fmaf(sc >= 0.0f ? mx[r] : mn[r], sc, bn_beta[cc] - bn_mean[cc] * sc);
-        }
-      }
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f;
-      reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + flat] = make_float4(o[0], o[1], o[2], o[3]);
-    }
+  // Pooling operands of one 16-pixel tile: 3 (x-pooled) or 3 x 2 values per output quad, ALL requested before the first is used, with
+  // clamped coordinates (a duplicated row / column leaves a maximum and a minimum unchanged) instead of a bounds branch around every
+  // load; for up to two output tiles the next tile's operands are requested before the current tile is reduced.
+  constexpr int NV = 6;
+  constexpr bool AHEAD = MT <= 2;
+  float4 va[MT][NV], vb[MT][NV];
+  // (macros, not lambdas taking the arrays by reference: those kept va / vb in scratch memory)
+#define ORCAI_POOL_LOAD_TILE(t, v)                                                                              \
+  {                                                                                                             \
+    const int flat = qbase + 16 * (t) + lj;                                                                     \
+    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);                                                   \
+    int j = flat - row * WPo, i = row - R;                                                                      \
+    j = j < Wo ? j : Wo - 1;                                                                                    \
+    i = i < Ho ? i : Ho - 1;                                                                                    \
+    const int ys = 2 * i - pad_top, xs = 2 * j - pad_left;                                                      \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                            \
+      const int oq = m * 4 + lk < CQ ? m * 4 + lk : 0;                                                          \
+      if (xpooled) {                                                                                            \
+        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * (int64_t)H * WPx;      \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                                      \
+          int y = ys + dy;                                                                                      \
+          y = y < 0 ? 0 : (y >= H ? H - 1 : y);                                                                 \
+          v[m][2 * dy] = sp[(int64_t)y * WPx + j];                                                              \
+          v[m][2 * dy + 1] = v[m][2 * dy];                                                                      \
+        }                                                                                                       \
+      } else {                                                                                                  \
+        const float4* sp = reinterpret_cast<const float4*>(s) + ((int64_t)b * CQ + oq) * plane;                 \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) _Pragma("unroll") for (int dx = 0; dx < 2; ++dx) {     \
+          int y = ys + dy, x = xs + dx;                                                                         \
+          y = y < 0 ? 0 : (y >= H ? H - 1 : y);                                                                 \
+          x = x < 0 ? 0 : (x >= W ? W - 1 : x);                                                                 \
+          v[m][dy * 2 + dx] = sp[(int64_t)(y + R) * WP + x];                                                    \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
   }
+#define ORCAI_POOL_REDUCE_TILE(t, v)                                                                            \
+  {                                                                                                             \
+    const int flat = qbase + 16 * (t) + lj;                                                                     \
+    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);                                                   \
+    const int j = flat - row * WPo, i = row - R;                                                                \
+    if (j < Wo && i < Ho) {                                                                                     \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                          \
+        const int oq = m * 4 + lk;                                                                              \
+        if (oq >= CQ) continue;                                                                                 \
+        float mx[4] = {v[m][0].x, v[m][0].y, v[m][0].z, v[m][0].w};                                             \
+        float mn[4] = {v[m][0].x, v[m][0].y, v[m][0].z, v[m][0].w};                                             \
+        _Pragma("unroll") for (int e = 1; e < NV; ++e) {                                                        \
+          mx[0] = fmaxf(mx[0], v[m][e].x); mx[1] = fmaxf(mx[1], v[m][e].y);                                     \
+          mx[2] = fmaxf(mx[2], v[m][e].z); mx[3] = fmaxf(mx[3], v[m][e].w);                                     \
+          if (bn_mean) {                                                                                        \
+            mn[0] = fminf(mn[0], v[m][e].x); mn[1] = fminf(mn[1], v[m][e].y);                                   \
+            mn[2] = fminf(mn[2], v[m][e].z); mn[3] = fminf(mn[3], v[m][e].w);                                   \
+          }                                                                                                     \
+        }                                                                                                       \
+        if (bn_mean) {                                                                                          \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+            const int c = oq * 4 + r, cc = c < C ? c : 0;                                                       \
+            const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps); /* as bn_planes_apply_kernel */        \
+            mx[r] = fmaf(sc >= 0.0f ? mx[r] : mn[r], sc, bn_beta[cc] - bn_mean[cc] * sc);                       \
+          }                                                                                                     \
+        }                                                                                                       \
+        float o[4];                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f; \
+        reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + flat] = make_float4(o[0], o[1], o[2], o[3]);        \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+  if (AHEAD) {
+    ORCAI_POOL_LOAD_TILE(0, va)
+    ORCAI_POOL_LOAD_TILE(1, vb)
+    ORCAI_POOL_REDUCE_TILE(0, va)
+    ORCAI_POOL_LOAD_TILE(2, va)
+    ORCAI_POOL_REDUCE_TILE(1, vb)
+    ORCAI_POOL_LOAD_TILE(3, vb)
+    ORCAI_POOL_REDUCE_TILE(2, va)
+    ORCAI_POOL_REDUCE_TILE(3, vb)
+  } else {
+    ORCAI_POOL_LOAD_TILE(0, va)
+    ORCAI_POOL_REDUCE_TILE(0, va)
+    ORCAI_POOL_LOAD_TILE(1, va)
+    ORCAI_POOL_REDUCE_TILE(1, va)
+    ORCAI_POOL_LOAD_TILE(2, va)
+    ORCAI_POOL_REDUCE_TILE(2, va)
+    ORCAI_POOL_LOAD_TILE(3, va)
+    ORCAI_POOL_REDUCE_TILE(3, va)
+  }
+#undef ORCAI_POOL_LOAD_TILE
+#undef ORCAI_POOL_REDUCE_TILE
 }
 
 // pool_res_add for the inference path (s x-pooled, no BatchNorm on the fly): the same arithmetic as pool_res_add_kernel, with
