@@ -336,11 +336,31 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   const int istart = i0 > 0 ? i0 - 1 : 0;  // halo window: only its contribution to the shared row is kept
   float4 t0 = ld(2 * istart - pad_top, x0, cx0), t1 = ld(2 * istart - pad_top, x1, cx1);  // first row of the current window
   float4 c0 = zero4, c1 = zero4;                                                            // gradient carried into that row
+  // the five loads of a window (two rows x two columns of v, one gradient) are unconditional (clamped coordinates, masked after
+  // arrival) and requested one window ahead
+  const int xc0 = x0 < 0 ? 0 : (x0 >= W ? W - 1 : x0), xc1 = x1 >= W ? W - 1 : x1;
+  float4 raw[4], dn;
+  auto request = [&](int i) {
+    const int r0 = 2 * i - pad_top;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int y = r0 + 1 + a;
+      y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      raw[2 * a] = yp[(int64_t)(y + R) * WP + xc0];
+      raw[2 * a + 1] = yp[(int64_t)(y + R) * WP + xc1];
+    }
+    dn = dp[(int64_t)((i < Ho ? i : Ho - 1) + R) * WPo + j];
+  };
+  auto masked = [&](float4 t, int y, bool cx) {
+    return (cx && y >= 0 && y < H) ? make_float4(t.x * sgn.x, t.y * sgn.y, t.z * sgn.z, t.w * sgn.w) : ninf;
+  };
+  if (istart < i1) request(istart);
   for (int i = istart; i < i1; ++i) {
     const int r0 = 2 * i - pad_top;
-    const float4 m0 = ld(r0 + 1, x0, cx0), m1 = ld(r0 + 1, x1, cx1);
-    const float4 b0 = ld(r0 + 2, x0, cx0), b1 = ld(r0 + 2, x1, cx1);
-    const float4 d = dp[(int64_t)(i + R) * WPo + j];
+    const float4 m0 = masked(raw[0], r0 + 1, cx0), m1 = masked(raw[1], r0 + 1, cx1);
+    const float4 b0 = masked(raw[2], r0 + 2, cx0), b1 = masked(raw[3], r0 + 2, cx1);
+    const float4 d = dn;
+    if (i + 1 < i1) request(i + 1);
     const float4 m = mx4(mx4(mx4(t0, t1), mx4(m0, m1)), mx4(b0, b1));
     if (i >= i0) {
       if (r0 >= 0) {
