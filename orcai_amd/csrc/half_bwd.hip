@@ -290,11 +290,37 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
   const int istart = i0 > 0 ? i0 - 1 : 0;
   O8 t0 = ld(2 * istart - pad_top, x0, cx0), t1 = ld(2 * istart - pad_top, x1, cx1);
   O8 c0 = o8_fill(0.f), c1 = o8_fill(0.f);
+  // the five loads of a window are unconditional (clamped coordinates, masked after arrival) and requested one window ahead, kept
+  // packed (4 registers each) until they are used -- as in the f32 kernel
+  const int xc0 = x0 < 0 ? 0 : (x0 >= W ? W - 1 : x0), xc1 = x1 >= W ? W - 1 : x1;
+  h16x8 raw[4], dn;
+  auto request = [&](int i) {
+    const int r0 = 2 * i - pad_top;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int y = r0 + 1 + a;
+      y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      raw[2 * a] = reinterpret_cast<const h16x8*>(ybn)[pin + (int64_t)(y + R) * WP + xc0];
+      raw[2 * a + 1] = reinterpret_cast<const h16x8*>(ybn)[pin + (int64_t)(y + R) * WP + xc1];
+    }
+    dn = reinterpret_cast<const h16x8*>(dout)[pout + (int64_t)((i < Ho ? i : Ho - 1) + R) * WPo + j];
+  };
+  auto masked = [&](h16x8 t, int y, bool cx) -> O8 {
+    O8 o;
+    unpack8(t, o.v);
+    const bool ok = cx && y >= 0 && y < H;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o.v[k] = ok ? o.v[k] * sgn[k] : -INFINITY;
+    return o;
+  };
+  if (istart < i1) request(istart);
   for (int i = istart; i < i1; ++i) {
     const int r0 = 2 * i - pad_top;
-    const O8 m0 = ld(r0 + 1, x0, cx0), m1 = ld(r0 + 1, x1, cx1);
-    const O8 b0 = ld(r0 + 2, x0, cx0), b1 = ld(r0 + 2, x1, cx1);
-    const O8 d = ld8(dout, pout + (int64_t)(i + R) * WPo + j);
+    const O8 m0 = masked(raw[0], r0 + 1, cx0), m1 = masked(raw[1], r0 + 1, cx1);
+    const O8 b0 = masked(raw[2], r0 + 2, cx0), b1 = masked(raw[3], r0 + 2, cx1);
+    O8 d;
+    unpack8(dn, d.v);
+    if (i + 1 < i1) request(i + 1);
     const O8 m = mx8(mx8(mx8(t0, t1), mx8(m0, m1)), mx8(b0, b1));
     if (i >= i0) {
       if (r0 >= 0) {
