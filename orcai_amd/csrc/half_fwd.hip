@@ -328,32 +328,38 @@ __global__ __launch_bounds__(256) void pool_res_add_h_kernel(const h16* __restri
       const int oq = 2 * m + (lk >> 1);
       if (!valid || oq >= CO) continue;
       h16x8 mx, mn;
-      bool first = true;
       if (xpooled) {  // s is [B][CO][H][WPx][8], already reduced over the column pair
         const h16x8* sp = reinterpret_cast<const h16x8*>(s) + ((int64_t)b * CO + oq) * (int64_t)H * WPx;
+        h16x8 v[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           int y = ys + dy;
           y = y < 0 ? 0 : (y >= H ? H - 1 : y);  // a duplicated row leaves the maximum unchanged
-          const h16x8 v = sp[(int64_t)y * WPx + j];
-          mx = first ? v : max_h(mx, v);
-          first = false;
+          v[dy] = sp[(int64_t)y * WPx + j];
         }
+        mx = max_h(max_h(v[0], v[1]), v[2]);
         mn = mx;
       } else {
+        // all six operands requested before the first is used: clamped coordinates (a duplicated row / column leaves a maximum and a
+        // minimum unchanged) instead of a bounds branch around every load
         const h16x8* sp = reinterpret_cast<const h16x8*>(s) + ((int64_t)b * CO + oq) * plane;
+        h16x8 v[6];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
-            const int y = ys + dy, x = xs + dx;
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-              const h16x8 v = sp[(int64_t)(y + R) * WP + x];
-              mx = first ? v : max_h(mx, v);
-              mn = first ? v : min_h(mn, v);
-              first = false;
-            }
+            int y = ys + dy, x = xs + dx;
+            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+            v[dy * 2 + dx] = sp[(int64_t)(y + R) * WP + x];
           }
+        mx = v[0];
+        mn = v[0];
+#pragma unroll
+        for (int e = 1; e < 6; ++e) {
+          mx = max_h(mx, v[e]);
+          mn = min_h(mn, v[e]);
+        }
       }
       float pm[8], pn[8], o8[8];
       unpack8(mx, pm);
