@@ -901,7 +901,6 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
   for (int cq = 0; cq < CQr; ++cq) {
     // outstanding, oldest first: this wave's DMAs of quad cq, then (UOUT, cq > 0, a wave that stores) the depthwise-output store of
     // quad cq - 1, which may stay in flight
@@ -1076,7 +1075,7 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
     if (j < Wo && i < Ho) {                                                                                     \
       _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                          \
         const int oq = m * 4 + lk;                                                                              \
-        if (oq >= CQ) continue;                                                                                 \
+        if (oq < CQ) {                                                                                          \
         float mx[4] = {v[m][0].x, v[m][0].y, v[m][0].z, v[m][0].w};                                             \
         float mn[4] = {v[m][0].x, v[m][0].y, v[m][0].z, v[m][0].w};                                             \
         _Pragma("unroll") for (int e = 1; e < NV; ++e) {                                                        \
@@ -1097,6 +1096,7 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
         float o[4];                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f; \
         reinterpret_cast<float4*>(out)[((int64_t)b * CQ + oq) * plane_o + flat] = make_float4(o[0], o[1], o[2], o[3]);        \
+        }                                                                                                       \
       }                                                                                                         \
     }                                                                                                           \
   }

@@ -525,6 +525,85 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __re
   }
 }
 
+// The f16 path's training recurrence (BASELINE configs[4]): the same kernel with the recurrent product h U on
+// v_mfma_f32_16x16x32_f16 -- h is kept in LDS as f16 (A operand: lane l reads the 8 consecutive k of row l & 15 as one 16-byte
+// read), the wave's 32 gate columns of U as f16 B fragments in 32 registers, f32 accumulation on top of the f32 input projection,
+// gate arithmetic, cell state and every stored tensor in f32.  Eight MFMAs of 16 cycles per step instead of 64 of 32: the step is no
+// longer bound by the one compute unit's f32 MFMA rate.
+typedef _Float16 lh16;
+typedef lh16 lh16x8 __attribute__((ext_vector_type(8)));
+
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_train_fwd_h_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
+                                                                  int B, int T, float* __restrict__ out /*[B][T][2U]*/, float* __restrict__ gates, float* __restrict__ cstate) {
+  constexpr int KB = U / 32, HPh = U + 8;  // k blocks of 32; row pitch in halves (16-byte multiple)
+  __shared__ __attribute__((aligned(16))) lh16 hbuf[2][16][HPh];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  lh16x8 ufrag[2][KB];  // B[k = 32 kb + 8 lk + e][col = lj] of gate-column tile nt
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ufrag[nt][kb][e] = (lh16)Ud[(int64_t)(kb * 32 + lk * 8 + e) * (4 * U) + wave * 32 + nt * 16 + lj];
+  for (int i = tid; i < 2 * 16 * HPh; i += U * 8) (&hbuf[0][0][0])[i] = (lh16)0.0f;
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int unit = wave * 8 + (lj & 7);
+  f32x4 xz_next[2];
+  auto load_xz = [&](int tt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + lk * 4 + r;
+        xz_next[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + tt) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+      }
+  };
+  load_xz(dir ? T - 1 : 0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2] = {xz_next[0], xz_next[1]};
+    if (step + 1 < T) load_xz(dir ? (T - 2 - step) : step + 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const lh16x8 a = *reinterpret_cast<const lh16x8*>(&hbuf[cur][lj][kb * 32 + lk * 8]);  // A[row = batch lj][k = 32 kb + 8 lk + e]
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ufrag[0][kb], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ufrag[1][kb], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mine0 = acc[0][r], mine1 = acc[1][r];
+      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
+      const bool low = lj < 8;
+      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
+      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
+      const float c = gf * cst[r] + gi * gg;
+      const float h = go * tanhf_(c);
+      cst[r] = c;
+      const int row = lk * 4 + r, bb = b0 + row;
+      if (bb < B) {
+        float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
+        gp[0] = low ? gi : gf;
+        gp[16] = low ? gg : go;
+      }
+      if (low) {
+        hbuf[cur ^ 1][row][unit] = (lh16)h;
+        if (bb < B) {
+          out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+          cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // =========================================================================================
 // LSTM backward through time for one direction and 16 snippets.  Per step (walking the forward order backwards):
 //   dh = dH[t] + dz[t_next] U^T
@@ -901,6 +980,18 @@ int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int uni
   switch (units) {
     case 128: hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
     case 64: hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_h_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream) {
+  if (!xz || !Uw || !out || !gates || !cstate || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  dim3 grid((B + 15) / 16, 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (units) {
+    case 128: hipLaunchKernelGGL(lstm_train_fwd_h_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+    case 64: hipLaunchKernelGGL(lstm_train_fwd_h_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();

@@ -174,7 +174,8 @@ class HeadTrainer:
             h = torch.empty((n, T, 2 * u), **f32)
             gates = torch.empty((n, T, 2, 4 * u), **f32)
             cs = torch.empty((n, T, 2, u), **f32)
-            N.check(lib.orcai_lstm_train_fwd(xz.data_ptr(), Uc.data_ptr(), n, T, u, h.data_ptr(), gates.data_ptr(), cs.data_ptr(), st), "lstm_train_fwd")
+            fwd = lib.orcai_h_lstm_train_fwd if self.half else lib.orcai_lstm_train_fwd  # f16 path: the recurrent product on f16 MFMA
+            N.check(fwd(xz.data_ptr(), Uc.data_ptr(), n, T, u, h.data_ptr(), gates.data_ptr(), cs.data_ptr(), st), "lstm_train_fwd")
             c[f"lstm{layer}"] = dict(x=x, fin=fin, Wc=Wc, Uc=Uc, h=h, gates=gates, cs=cs)
             if masks is not None:
                 hd = torch.empty_like(h)
