@@ -243,8 +243,10 @@ int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, flo
  * f32[B][T][2][4*units] and cell states f32[B][T][2][units] the backward pass needs. */
 int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream);
 /* The f16 path's twin (same arguments, f32 tensors): the recurrent product on v_mfma_f32_16x16x32_f16 with h and U rounded to f16,
- * f32 accumulation on the f32 input projection, gates / cell state / outputs in f32. */
+ * f32 accumulation on the f32 input projection, gates / cell state / outputs in f32; orcai_h_lstm_bwd likewise for the recurrent
+ * term dz U^T of orcai_lstm_bwd (dz rounded to f16 for the product only; dxz is written in f32). */
 int orcai_h_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream);
+int orcai_h_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream);
 /* Backward through time: dH f32[B][T][2*units] (gradient of the layer output) -> dxz f32[B][T][2][4*units] (permuted columns). */
 int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream);
 /* hprev[b][t][dir][u] = h[b][t-1 (dir 0) | t+1 (dir 1)][dir*units + u], 0 at the sequence start: left operand of dU = hprev^T dxz. */

@@ -705,6 +705,96 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_kernel(const float* __restrict
   }
 }
 
+// The f16 path's twin: the recurrent term dz U^T (contraction over the 4U gate columns) on v_mfma_f32_16x16x32_f16.  dz goes to LDS
+// twice -- in f32 for the coalesced dxz rows, in f16 as the MFMA's A operand (lane l: row l & 15, the 8 consecutive columns
+// 32 kb + 8 (l >> 4) of k block kb: one 16-byte read) -- and the wave's 16 units of U^T live in 4U / 32 f16 fragment registers
+// quadruples (64 VGPRs instead of 128).  4U / 32 MFMAs of 16 cycles per step instead of U of 32; gate arithmetic, cell-state
+// gradient and dxz in f32.
+template <int U>
+__global__ __launch_bounds__(U * 4) void lstm_bwd_h_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
+                                                            const float* __restrict__ Uw /*[2][U][4U] permuted*/, int B, int T,
+                                                            float* __restrict__ dxz /*[B][T][2][4U] permuted*/) {
+  constexpr int ZP = 4 * U + 4, ZH = 4 * U + 8, KB = 4 * U / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem_lb[];
+  float (*dzs)[16][ZP] = reinterpret_cast<float (*)[16][ZP]>(smem_lb);              // [2][16][ZP] f32: dz rows of the step (for dxz)
+  lh16 (*dzh)[16][ZH] = reinterpret_cast<lh16 (*)[16][ZH]>(smem_lb + 2 * 16 * ZP);  // [2][16][ZH] f16: the MFMA's A operand
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  const int unit = wave * 16 + lj;
+  lh16x8 ut[KB];  // B[k = 32 kb + 8 lk + e][col = lj] = U[unit][p = k]
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ut[kb][e] = (lh16)Ud[(int64_t)unit * (4 * U) + kb * 32 + lk * 8 + e];
+  float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhr[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pl = wave * 64 + (lj >> 3) * 32 + (lj & 7);
+  float pg[4][4], pc[4], pcp[4], pdh[4];
+  auto load_step = [&](int step) {
+    const int t = dir ? step : (T - 1 - step);
+    const int tprev = dir ? t + 1 : t - 1;
+    const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bb = b0 + lk * 4 + r;
+      const bool ok = bb < B && step < T;
+      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + pl : 0;
+      pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
+      pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
+      pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
+      pcp[r] = (ok && has_prev) ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.f;
+      pdh[r] = ok ? dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] : 0.f;
+    }
+  };
+  load_step(0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : (T - 1 - step);
+    const int cur = step & 1;
+    float cg[4][4], cc[4], ccp[4], cdh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cc[r] = pc[r]; ccp[r] = pcp[r]; cdh[r] = pdh[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cg[r][q] = pg[r][q];
+    }
+    load_step(step + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
+      const float c = cc[r], cp = ccp[r];
+      const float dh = cdh[r] + dhr[r];
+      const float tc = tanhf_(c);
+      const float dO = dh * tc;
+      const float dct = dc[r] + dh * go * (1.0f - tc * tc);
+      dc[r] = dct * gf;
+      const float z0 = dct * gg * gi * (1.0f - gi), z1 = dct * cp * gf * (1.0f - gf), z2 = dct * gi * (1.0f - gg * gg), z3 = dO * go * (1.0f - go);
+      float* zr = &dzs[cur][lk * 4 + r][pl];
+      zr[0] = z0; zr[8] = z1; zr[16] = z2; zr[24] = z3;
+      lh16* zh = &dzh[cur][lk * 4 + r][pl];
+      zh[0] = (lh16)z0; zh[8] = (lh16)z1; zh[16] = (lh16)z2; zh[24] = (lh16)z3;
+    }
+    __syncthreads();  // dz[cur] of every wave is visible (f32 rows and f16 operand); the buffers cur^1 are free again after the next barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 4 + lk, bb = b0 + row;
+      const float4 v = *reinterpret_cast<const float4*>(&dzs[cur][row][wave * 64 + lj * 4]);
+      if (bb < B) *reinterpret_cast<float4*>(dxz + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + lj * 4) = v;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const lh16x8 a = *reinterpret_cast<const lh16x8*>(&dzh[cur][lj][kb * 32 + lk * 8]);
+      acc[kb & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ut[kb], acc[kb & 3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+  }
+}
+
 // h_prev[b][t][dir][u] = h[b][t -+ 1][dir*U + u] (0 at the sequence start of each direction): left operand of dU = h_prev^T dxz
 __global__ __launch_bounds__(256) void lstm_hprev_kernel(const float* __restrict__ h /*[B][T][2U]*/, int B, int T, int U, float* __restrict__ hp /*[B][T][2][U]*/) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -981,6 +1071,28 @@ int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int uni
     case 128: hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
     case 64: hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
     default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_h_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream) {
+  if (!dH || !gates || !cstate || !Uw || !dxz || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  dim3 grid((B + 15) / 16, 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (units == 128) {
+    const size_t lds = (size_t)2 * 16 * (4 * 128 + 4) * 4 + (size_t)2 * 16 * (4 * 128 + 8) * 2;  // 99 328 B > 64 KiB: opt in once
+    static bool opted = false;
+    if (!opted) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_h_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      opted = true;
+    }
+    hipLaunchKernelGGL(lstm_bwd_h_kernel<128>, grid, dim3(512), lds, st, dH, gates, cstate, Uw, B, T, dxz);
+  } else if (units == 64) {
+    const size_t lds = (size_t)2 * 16 * (4 * 64 + 4) * 4 + (size_t)2 * 16 * (4 * 64 + 8) * 2;  // 50 176 B
+    hipLaunchKernelGGL(lstm_bwd_h_kernel<64>, grid, dim3(256), lds, st, dH, gates, cstate, Uw, B, T, dxz);
+  } else {
+    return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();
 }

@@ -255,7 +255,8 @@ class HeadTrainer:
             if masks is not None:
                 N.check(lib.orcai_mask_scale(dh.data_ptr(), masks[f"drop{layer}"].data_ptr(), 1.0 / keep, dh.numel(), dh.data_ptr(), st), "mask_scale")
             dxz = torch.empty((n, T, 2, 4 * u), **f32)
-            N.check(lib.orcai_lstm_bwd(dh.data_ptr(), lc["gates"].data_ptr(), lc["cs"].data_ptr(), lc["Uc"].data_ptr(), n, T, u, dxz.data_ptr(), st), "lstm_bwd")
+            bwd = lib.orcai_h_lstm_bwd if self.half else lib.orcai_lstm_bwd
+            N.check(bwd(dh.data_ptr(), lc["gates"].data_ptr(), lc["cs"].data_ptr(), lc["Uc"].data_ptr(), n, T, u, dxz.data_ptr(), st), "lstm_bwd")
             fin = lc["fin"]
             # input kernels (both directions at once, permuted columns): dWc = x^T dxz
             dWc = torch.empty((fin, 8 * u), **f32)
