@@ -330,6 +330,9 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
  * partial products (up to 512 * Ca * Cb floats are used; fewer workgroups run if it is smaller). */
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
                        float* workspace, int64_t workspace_floats, void* stream);
+/* Pixels per pass of orcai_outer_reduce's LDS image: 0 (default) = 256 up to 32 channels per operand, 128 beyond (the LDS per workgroup
+ * decides this kernel's occupancy); 128 / 256 force one.  Same sums in a different order.  Returns the previous value. */
+int orcai_outer_reduce_pixels(int pixels);
 /* dW[tap][c] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient, written in the Keras
  * kernel layout (k, k, C, 1), i.e. straight into the flat gradient buffer) */
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);

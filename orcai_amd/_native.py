@@ -78,6 +78,7 @@ _SIGNATURES = {
     "orcai_planes_sum": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_pool_bwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "orcai_outer_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "orcai_outer_reduce_pixels": (C.c_int, [C.c_int]),
     "orcai_dw_wgrad": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]),
     "orcai_conv0_wgrad": (C.c_int, [C.c_void_p, c_i64, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]),
     "orcai_feat_to_planes": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),

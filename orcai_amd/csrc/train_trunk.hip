@@ -407,11 +407,16 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 // second kernel adds the partials into D: same-line float atomics serialise at ~12 ns each, which with 512 blocks cost
 // more than the whole reduction.
 // a_mode 1: A is sampled at pixel (2i, 2j) of planes (Ha, Wa) for each pixel (i, j) of the Bq planes (stride-2 1x1 conv).
-constexpr int OR_P = 258;
 constexpr int OR_MAXQ = 16;  // up to 64 channels per operand
 
+// PP pixels per pass (the LDS image is [channel][PP + 2]).  256: a thread stages one pixel of BOTH operands; 128: the first 128 threads
+// stage A, the other 128 stage B -- half the LDS per workgroup, which is what decides the occupancy of this kernel
+// ((MT + NT) * 16.5 KiB at 256 pixels: one workgroup per compute unit from 40 channels per operand on).
+template <int PP>
 __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restrict__ A, int Ca, const float* __restrict__ Bq, int Cb, int H, int W, int WP, int R,
                                                             int B, int a_mode, int Ha, int WPa, float* __restrict__ part /*[gridDim.x][Ca*Cb]*/, uint32_t magic_WP) {
+  constexpr int OR_P = PP + 2, PARTS = 256 / PP;
+  static_assert(PP == 256 || PP == 128, "pixels per pass");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int CQa = (Ca + 3) >> 2, CQb = (Cb + 3) >> 2;
   const int MT = (Ca + 15) >> 4, NT = (Cb + 15) >> 4, ntile = MT * NT;
@@ -420,17 +425,20 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
   for (int i = threadIdx.x; i < (MT + NT) * 16 * OR_P; i += 256) smem[i] = 0.0f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lk = lane >> 4, lj = lane & 15;
+  const int pix = tid & (PP - 1);
+  const bool do_a = PARTS == 1 || tid < PP, do_b = PARTS == 1 || tid >= PP;  // wave-uniform
   const int plane = (H + 2 * R) * WP;
   const int64_t plane_a = a_mode ? (int64_t)(Ha + 2 * R) * WPa : plane;
   f32x4 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int chunks_per_plane = (plane + 255) >> 8;
+  const int chunks_per_plane = (plane + PP - 1) / PP;
   const int64_t nchunks = (int64_t)B * chunks_per_plane;
-  float4 ra[OR_MAXQ], rb[OR_MAXQ];
+  float4 rq[OR_MAXQ];  // this thread's pixel of its operand(s): PARTS == 1 keeps A here and B in rb
+  float4 rb[PARTS == 1 ? OR_MAXQ : 1];
   auto fetch = [&](int64_t ch) {
     const int64_t b = ch / chunks_per_plane;
-    const int p = (int)(ch - b * chunks_per_plane) * 256 + tid;  // this thread's pixel
+    const int p = (int)(ch - b * chunks_per_plane) * PP + pix;  // this thread's pixel
     const bool pin = ch < nchunks && p < plane;
     int pa = p;
     bool ain = pin;
@@ -442,8 +450,14 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
     }
 #pragma unroll
     for (int q = 0; q < OR_MAXQ; ++q) {
-      ra[q] = (q < CQa && ain) ? reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa] : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[q] = (q < CQb && pin) ? reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PARTS == 1) {
+        rq[q] = (q < CQa && ain) ? reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa] : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[q] = (q < CQb && pin) ? reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (do_a) {
+        rq[q] = (q < CQa && ain) ? reinterpret_cast<const float4*>(A)[((int64_t)b * CQa + q) * plane_a + pa] : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        rq[q] = (q < CQb && pin) ? reinterpret_cast<const float4*>(Bq)[((int64_t)b * CQb + q) * plane + p] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   fetch(blockIdx.x);
@@ -451,11 +465,18 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
     __syncthreads();  // previous pass's MFMA reads are done (also orders the initial zero fill)
 #pragma unroll
     for (int q = 0; q < OR_MAXQ; ++q) {
-      if (q < CQa) {
-        As[(4 * q + 0) * OR_P + tid] = ra[q].x; As[(4 * q + 1) * OR_P + tid] = ra[q].y; As[(4 * q + 2) * OR_P + tid] = ra[q].z; As[(4 * q + 3) * OR_P + tid] = ra[q].w;
-      }
-      if (q < CQb) {
-        Bs[(4 * q + 0) * OR_P + tid] = rb[q].x; Bs[(4 * q + 1) * OR_P + tid] = rb[q].y; Bs[(4 * q + 2) * OR_P + tid] = rb[q].z; Bs[(4 * q + 3) * OR_P + tid] = rb[q].w;
+      if (PARTS == 1) {
+        if (q < CQa) {
+          As[(4 * q + 0) * OR_P + pix] = rq[q].x; As[(4 * q + 1) * OR_P + pix] = rq[q].y; As[(4 * q + 2) * OR_P + pix] = rq[q].z; As[(4 * q + 3) * OR_P + pix] = rq[q].w;
+        }
+        if (q < CQb) {
+          Bs[(4 * q + 0) * OR_P + pix] = rb[q].x; Bs[(4 * q + 1) * OR_P + pix] = rb[q].y; Bs[(4 * q + 2) * OR_P + pix] = rb[q].z; Bs[(4 * q + 3) * OR_P + pix] = rb[q].w;
+        }
+      } else {
+        float* dst = do_a ? As : Bs;
+        if (q < (do_a ? CQa : CQb)) {
+          dst[(4 * q + 0) * OR_P + pix] = rq[q].x; dst[(4 * q + 1) * OR_P + pix] = rq[q].y; dst[(4 * q + 2) * OR_P + pix] = rq[q].z; dst[(4 * q + 3) * OR_P + pix] = rq[q].w;
+        }
       }
     }
     __syncthreads();
@@ -468,7 +489,7 @@ __global__ __launch_bounds__(256) void outer_reduce_kernel(const float* __restri
         const float* ar = As + (mt * 16 + lj) * OR_P + lk;
         const float* br = Bs + (nt * 16 + lj) * OR_P + lk;
         f32x4 c0 = acc[ti], c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < 64; s += 2) {  // A[i = ca][k = pixel], B[k = pixel][j = cb]; two interleaved accumulator chains
+        for (int s = 0; s < PP / 4; s += 2) {  // A[i = ca][k = pixel], B[k = pixel][j = cb]; two interleaved accumulator chains
           c0 = mfma16(ar[4 * s], br[4 * s], c0);
           c1 = mfma16(ar[4 * s + 4], br[4 * s + 4], c1);
         }
@@ -910,6 +931,8 @@ int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int
   return orcai_pool_bwd_bn(dout, ybn, B, C, H, W, ksize, dy, nullptr, nullptr, nullptr, 0.0f, nullptr, stream);
 }
 
+static int g_outer_pp = 0;  // 0: by operand width; 128 / 256: forced (orcai_outer_reduce_pixels, experiments)
+
 int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D,
                        float* workspace, int64_t workspace_floats, void* stream) {
   if (!A || !Bq || !D || !workspace || Ca <= 0 || Cb <= 0 || Ca > 64 || Cb > 64 || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
@@ -918,23 +941,39 @@ int orcai_outer_reduce(const float* A, int Ca, const float* Bq, int Cb, int B, i
   const int WP = orcai_padded_width(W, ksize), R = ksize / 2;
   // dynamic LDS beyond the 64 KiB default (any operand wider than 32 channels) needs the opt-in below: a launch without it was the one
   // difference between the test shapes that ran and the one that aborted in round 1
-  const size_t lds = (size_t)(((Ca + 15) / 16 + (Cb + 15) / 16) * 16) * OR_P * sizeof(float);
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)outer_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int MTN = (Ca + 15) / 16 + (Cb + 15) / 16;
+  // 256 pixels per pass while two workgroups fit a compute unit (<= 32 channels per operand: 66 KiB), 128 beyond (50-66 KiB instead
+  // of 99-132); g_outer_pp overrides for experiments
+  const int PP = g_outer_pp ? g_outer_pp : (MTN <= 4 ? 256 : 128);
+  const size_t lds = (size_t)(MTN * 16) * (PP + 2) * sizeof(float);
+  static size_t lds_set[2] = {0, 0};
+  if (lds > lds_set[PP == 256]) {
+    hipError_t e = PP == 256 ? hipFuncSetAttribute((const void*)outer_reduce_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                             : hipFuncSetAttribute((const void*)outer_reduce_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    lds_set = lds;
+    lds_set[PP == 256] = lds;
   }
   const int plane = (H + 2 * R) * WP;
-  const int64_t nchunks = (int64_t)B * ((plane + 255) / 256);
-  int64_t grid = nchunks < 512 ? nchunks : 512;
+  const int64_t nchunks = (int64_t)B * ((plane + PP - 1) / PP);
+  const int64_t cap = PP == 256 ? 512 : 768;  // two / three workgroups per compute unit
+  int64_t grid = nchunks < cap ? nchunks : cap;
   if (grid * Ca * Cb > workspace_floats) grid = workspace_floats / ((int64_t)Ca * Cb);
   if (grid < 1) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(outer_reduce_kernel, dim3((unsigned)grid), dim3(256), lds, st, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
-                     a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
+  if (PP == 256)
+    hipLaunchKernelGGL(outer_reduce_kernel<256>, dim3((unsigned)grid), dim3(256), lds, st, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
+                       a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
+  else
+    hipLaunchKernelGGL(outer_reduce_kernel<128>, dim3((unsigned)grid), dim3(256), lds, st, A, Ca, Bq, Cb, H, W, WP, R, B, a_stride2, Ha,
+                       a_stride2 ? orcai_padded_width(Wa, ksize) : 0, workspace, magic_for(WP));
   hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Ca * Cb), 8), dim3(256), 0, st, workspace, (int)grid, Ca * Cb, D);
   return (int)hipGetLastError();
+}
+
+int orcai_outer_reduce_pixels(int pixels) {
+  const int prev = g_outer_pp;
+  if (pixels == 0 || pixels == 128 || pixels == 256) g_outer_pp = pixels;
+  return prev;
 }
 
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {

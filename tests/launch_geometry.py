@@ -316,24 +316,27 @@ def pool_bwd(B, C, H, W, k, G=4, PB_ROWS=8):
 
 # ------------------------------------------------------------------------------------------------ outer_reduce_kernel
 def outer_reduce(B, Ca, Cb, H, W, k, a_stride2=False, Ha=0, Wa=0, workspace_floats=512 * 64 * 64, G=4):
-    """train_trunk.hip outer_reduce_kernel + add_partials: 256-pixel chunks over whole planes (pads are zero), the stride-2 sampling of
-    A for the residual conv, and the per-workgroup partial products in the workspace."""
+    """train_trunk.hip outer_reduce_kernel<PP> + add_partials: PP-pixel chunks over whole planes (pads are zero; f32: PP = 256 up to 32
+    channels per operand, 128 beyond, 768 workgroups then; f16: 256), the stride-2 sampling of A for the residual conv, and the
+    per-workgroup partial products in the workspace."""
     t = Touch()
     R, WP = k // 2, padded_width(W, k)
     plane = (H + 2 * R) * WP
     CGa, CGb = -(-Ca // G), -(-Cb // G)
     WPa = padded_width(Wa, k) if a_stride2 else 0
     plane_a = (Ha + 2 * R) * WPa if a_stride2 else plane
-    cpp = (plane + 255) >> 8
+    tiles = (Ca + 15) // 16 + (Cb + 15) // 16
+    PP = 256 if (G != 4 or tiles <= 4) else 128
+    cpp = (plane + PP - 1) // PP
     nchunks = B * cpp
-    grid = min(nchunks, 512)
+    grid = min(nchunks, 512 if PP == 256 else 768)
     if grid * Ca * Cb > workspace_floats:
         grid = workspace_floats // (Ca * Cb)
-    tid = np.arange(256)[None, :]
+    tid = (np.arange(256) % PP)[None, :]  # PP = 128: the two halves of the workgroup stage one operand each, the same pixels
     # every chunk a block can ask for, including the prefetch one stride past the end (must be masked, not dereferenced)
     ch = np.arange(nchunks + grid)[:, None]
     b = ch // cpp
-    p = (ch - b * cpp) * 256 + tid
+    p = (ch - b * cpp) * PP + tid
     pin = (ch < nchunks) & (p < plane)
     row = np.where(pin, p, 0) // WP
     x, i = p - row * WP, row - R
@@ -347,8 +350,7 @@ def outer_reduce(B, Ca, Cb, H, W, k, a_stride2=False, Ha=0, Wa=0, workspace_floa
     for cg in (0, CGb - 1):
         t.add("B", (b * CGb + cg) * plane + p, pin)
     t.add("workspace", np.array([0, grid * Ca * Cb - 1]))
-    tiles = (Ca + 15) // 16 + (Cb + 15) // 16
-    lds = tiles * 16 * 258 * 4 if G == 4 else 256 * (tiles * 16 + 16) * 2  # f32: [channel][pixel] image; f16: [pixel][channel] image
+    lds = tiles * 16 * (PP + 2) * 4 if G == 4 else 256 * (tiles * 16 + 16) * 2  # f32: [channel][pixel] image; f16: [pixel][channel] image
     return t.r, {"grid": grid, "lds_bytes": lds}
 
 
