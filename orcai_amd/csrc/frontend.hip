@@ -96,39 +96,60 @@ __device__ __forceinline__ int shift_for(uint64_t width) {
   return s;
 }
 
-// ---------------------------------------------------------------- FFT-16 in registers
-__device__ __forceinline__ void bfly4(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr, float& di) {
-  float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
-  float t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
-  ar = t0r + t2r; ai = t0i + t2i;
-  cr = t0r - t2r; ci = t0i - t2i;
-  br = t1r + t3i; bi = t1i - t3r;
-  dr = t1r - t3i; di = t1i + t3r;
+// ---------------------------------------------------------------- FFT-16 in registers, packed complex arithmetic
+// A complex number is one aligned register pair (re, im); every butterfly add / subtract is ONE v_pk_add_f32, a multiplication by
+// -i or +i is folded into the add that consumes it through the operand selectors of VOP3P (op_sel / op_sel_hi pick which half of a
+// source feeds which half of the result, neg_lo / neg_hi negate it), and a complex multiplication is v_pk_mul_f32 + v_pk_fma_f32.
+// Written as inline asm: left to itself the compiler keeps re[] / im[] apart and spends a fifth of the kernel's vector instructions
+// on register moves that assemble packed operands.
+typedef float c2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ c2 add_mi(c2 a, c2 b) {  // a - i b = (a.re + b.im, a.im - b.re)
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
-__device__ __forceinline__ void cmul(float& r, float& i, float wr, float wi) {
-  float tr = r * wr - i * wi;
-  i = r * wi + i * wr;
-  r = tr;
+__device__ __forceinline__ c2 add_pi(c2 a, c2 b) {  // a + i b = (a.re - b.im, a.im + b.re)
+  c2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ c2 cmulv(c2 a, c2 w) {  // a * w, w = (wr, wi) in a VGPR pair
+  c2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));                                  // (a.re wr, a.im wr)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));  // (-a.im wi + ., a.re wi + .)
+  return r;
+}
+__device__ __forceinline__ c2 cmuls(c2 a, c2 w) {  // the same with a wave-uniform constant in an SGPR pair
+  c2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+  return r;
+}
+__device__ __forceinline__ void bfly4(c2& a, c2& b, c2& c, c2& d) {
+  const c2 t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+  a = t0 + t2;
+  c = t0 - t2;
+  b = add_mi(t1, t3);
+  d = add_pi(t1, t3);
 }
 // In-place forward FFT-16; output bin k ends up at position P16(k).
 #define P16(k) (4 * ((k) & 3) + ((k) >> 2))
-__device__ __forceinline__ void fft16(float (&re)[16], float (&im)[16]) {
+__device__ __forceinline__ void fft16(c2 (&x)[16]) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) bfly4(re[a], im[a], re[a + 4], im[a + 4], re[a + 8], im[a + 8], re[a + 12], im[a + 12]);
+  for (int a = 0; a < 4; ++a) bfly4(x[a], x[a + 4], x[a + 8], x[a + 12]);
   // position a + 4q holds y[a][q]; multiply by W16^(a q)
-  cmul(re[1 + 4], im[1 + 4], C1, -S1);    // a=1,q=1 : W^1
-  cmul(re[1 + 8], im[1 + 8], R2, -R2);    // a=1,q=2 : W^2
-  cmul(re[1 + 12], im[1 + 12], S1, -C1);  // a=1,q=3 : W^3
-  cmul(re[2 + 4], im[2 + 4], R2, -R2);    // a=2,q=1 : W^2
-  { float t = re[2 + 8]; re[2 + 8] = im[2 + 8]; im[2 + 8] = -t; }  // a=2,q=2 : W^4 = -i
-  cmul(re[2 + 12], im[2 + 12], -R2, -R2); // a=2,q=3 : W^6
-  cmul(re[3 + 4], im[3 + 4], S1, -C1);    // a=3,q=1 : W^3
-  cmul(re[3 + 8], im[3 + 8], -R2, -R2);   // a=3,q=2 : W^6
-  cmul(re[3 + 12], im[3 + 12], -C1, S1);  // a=3,q=3 : W^9
+  x[1 + 4] = cmuls(x[1 + 4], (c2){C1, -S1});     // a=1,q=1 : W^1
+  x[1 + 8] = cmuls(x[1 + 8], (c2){R2, -R2});     // a=1,q=2 : W^2
+  x[1 + 12] = cmuls(x[1 + 12], (c2){S1, -C1});   // a=1,q=3 : W^3
+  x[2 + 4] = cmuls(x[2 + 4], (c2){R2, -R2});     // a=2,q=1 : W^2
+  x[2 + 8] = add_mi((c2){0.f, 0.f}, x[2 + 8]);   // a=2,q=2 : W^4 = -i
+  x[2 + 12] = cmuls(x[2 + 12], (c2){-R2, -R2});  // a=2,q=3 : W^6
+  x[3 + 4] = cmuls(x[3 + 4], (c2){S1, -C1});     // a=3,q=1 : W^3
+  x[3 + 8] = cmuls(x[3 + 8], (c2){-R2, -R2});    // a=3,q=2 : W^6
+  x[3 + 12] = cmuls(x[3 + 12], (c2){-C1, S1});   // a=3,q=3 : W^9
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    bfly4(re[4 * q], im[4 * q], re[4 * q + 1], im[4 * q + 1], re[4 * q + 2], im[4 * q + 2], re[4 * q + 3], im[4 * q + 3]);
+  for (int q = 0; q < 4; ++q) bfly4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
 }
 
 constexpr int ROW_BYTES = 144;               // 16 complex (128 B) + 16 B pad: conflict-free b128 row reads
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     const bool valid = FAST ? true : (t < n_frames);
     const int64_t s0 = t * (int64_t)hop - (NFFT / 2);
 
-    float re[16], im[16];
+    c2 z[16];
     // The wave's 4 frames cover padded samples [hop*t0w, hop*(t0w+3) + 512): for the default hop 256 that is one
     // contiguous run of 1280 floats, fetched as 5 dwordx4 per lane (1 KiB per instruction) into the wave's tile.
     const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);  // first sample the wave needs
@@ -195,10 +216,9 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
       const float* fr = st + fsub * 256;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float2 v = *reinterpret_cast<const float2*>(fr + 2 * (l16 + 16 * j));
-        const float2 w = lds.win2[l16 + 16 * j];
-        re[j] = v.x * w.x;
-        im[j] = v.y * w.y;
+        const c2 v = *reinterpret_cast<const c2*>(fr + 2 * (l16 + 16 * j));
+        const c2 w = *reinterpret_cast<const c2*>(&lds.win2[l16 + 16 * j]);
+        z[j] = v * w;  // (x[2n] w[2n], x[2n+1] w[2n+1]): the 512-point real frame packed as 256 complex points
       }
       wave_lds_fence();  // staging reads done before the tile is reused for the transpose
     } else {
@@ -208,49 +228,48 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
         const float x0 = (valid && sidx >= 0 && sidx < n_samples) ? pcm[sidx] : 0.0f;
         const float x1 = (valid && sidx + 1 >= 0 && sidx + 1 < n_samples) ? pcm[sidx + 1] : 0.0f;
         const float2 w = lds.win2[l16 + 16 * j];
-        re[j] = x0 * w.x;
-        im[j] = x1 * w.y;
+        z[j] = (c2){x0 * w.x, x1 * w.y};
       }
     }
 
     // step 1: FFT-16 over n2 -> Y[n1][k2] at position P16(k2); step 2: twiddle W256^(n1 k2)
-    fft16(re, im);
+    fft16(z);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) {
-      float2 w = lds.tw256[k2 * 16 + l16];
-      cmul(re[P16(k2)], im[P16(k2)], w.x, w.y);
-    }
+    for (int k2 = 1; k2 < 16; ++k2) z[P16(k2)] = cmulv(z[P16(k2)], *reinterpret_cast<const c2*>(&lds.tw256[k2 * 16 + l16]));
     // step 3: transpose through the wave-private tile: row k2, column n1
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2)
-      *reinterpret_cast<float2*>(my_frame + k2 * ROW_BYTES + l16 * 8) = make_float2(re[P16(k2)], im[P16(k2)]);
+    for (int k2 = 0; k2 < 16; ++k2) *reinterpret_cast<c2*>(my_frame + k2 * ROW_BYTES + l16 * 8) = z[P16(k2)];
     wave_lds_fence();
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      float4 v = *reinterpret_cast<const float4*>(my_frame + l16 * ROW_BYTES + h * 16);
-      re[2 * h] = v.x; im[2 * h] = v.y; re[2 * h + 1] = v.z; im[2 * h + 1] = v.w;
+      const float4 v = *reinterpret_cast<const float4*>(my_frame + l16 * ROW_BYTES + h * 16);
+      z[2 * h] = (c2){v.x, v.y};
+      z[2 * h + 1] = (c2){v.z, v.w};
     }
     // step 4: FFT-16 over n1 -> Z[16 k1 + k2] at position P16(k1), lane = k2
-    fft16(re, im);
+    fft16(z);
     wave_lds_fence();  // all lanes have read the tile before it is reused as output staging
 
     // step 5: real-FFT split.  A = Z[k], B = Z[256-k]: lane (16-k2)&15, register 15-k1 (k2 != 0) or (16-k1)&15 (k2 == 0).
+    //   2 X[k] = (A + conj B) + (c - i s)(-i)(A - conj B)        with (c, s) = tw512[k]
+    // in packed form: E = A + conj B, O = (A.im + B.im, B.re - A.re), 2 X = E + (c O.re + s O.im, c O.im - s O.re); power = |2X|^2 / 4.
     const int src_lane = (lane & 48) | ((16 - l16) & 15);
     float* stage = reinterpret_cast<float*>(my_tile) + fsub * k_crop;
-    const float z0r = re[P16(0)], z0i = im[P16(0)];
+    const c2 z0 = z[P16(0)];
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
-      const float ar = re[P16(k1)], ai = im[P16(k1)];
-      float br = __shfl(re[P16(15 - k1)], src_lane, 64);
-      float bi = __shfl(im[P16(15 - k1)], src_lane, 64);
-      if (l16 == 0) { br = re[P16((16 - k1) & 15)]; bi = im[P16((16 - k1) & 15)]; }
+      const c2 A = z[P16(k1)];
+      c2 Bv = (c2){__shfl(z[P16(15 - k1)].x, src_lane, 64), __shfl(z[P16(15 - k1)].y, src_lane, 64)};
+      if (l16 == 0) Bv = z[P16((16 - k1) & 15)];
       const int k = 16 * k1 + l16;
-      const float2 cs = lds.tw512[k];
-      const float er = 0.5f * (ar + br), ei = 0.5f * (ai - bi);
-      const float orr = 0.5f * (ai + bi), oi = -0.5f * (ar - br);
-      const float xr = er + (cs.x * orr + cs.y * oi);
-      const float xi = ei + (cs.x * oi - cs.y * orr);
-      const float p = xr * xr + xi * xi;
+      const c2 cs = *reinterpret_cast<const c2*>(&lds.tw512[k]);
+      c2 E, O, P, T;
+      asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E) : "v"(A), "v"(Bv));                                              // (A.re + B.re, A.im - B.im)
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(O) : "v"(A), "v"(Bv));                 // (A.im + B.im, B.re - A.re)
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(T) : "v"(O), "v"(cs));                              // (c O.re, c O.im)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(P) : "v"(O), "v"(cs), "v"(T));  // (s O.im + ., -s O.re + .)
+      const c2 X2 = E + P;
+      const float p = 0.25f * (X2.x * X2.x + X2.y * X2.y);
       if (valid) pmax = fmaxf(pmax, p);
       if (k < k_crop) {
         const float L = power_to_db(p);
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
       }
     }
     if (l16 == 0) {  // Nyquist bin 256: X = Re Z0 - Im Z0
-      const float x = z0r - z0i;
+      const float x = z0.x - z0.y;
       const float p = x * x;
       if (valid) pmax = fmaxf(pmax, p);
       if (256 < k_crop) {
