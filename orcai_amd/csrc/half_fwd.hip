@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "half_planes.h"
+#include "lds_dma.h"
 #include "orcai_hip.h"
 
 namespace {
@@ -453,6 +454,145 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const float* __restrict__ A
     }
 }
 
+// =========================================================================================
+// sepconv_h_ftile: sepconv_h_kernel<3, MT> with the window rows shared through LDS -- the f16 twin of sepconv_ftile_kernel
+// (model_fwd.hip).  A pixel of an octet plane is 16 bytes like a pixel of an f32 quad plane, so the scheme carries over unchanged:
+// the 8 waves of a workgroup own 8 consecutive 64-pixel windows of the flat padded plane, the three rows of all of them are one
+// contiguous range of 7 VAL + 64 + 2 WP pixels fetched once per octet by LDS-DMA in 1-KiB chunks (chunk c by wave c mod 8) into one of
+// two slots, and every wave reads its three rows back with ds_read_b128.  One raw barrier per octet; counted vmcnt waits leave the
+// depthwise-output store of the training forward in flight.  Same arithmetic in the same order as sepconv_h_kernel.
+// =========================================================================================
+template <int MT, bool XP, bool UOUT>
+__global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restrict__ in /*[B][CO][HP][WP][8]*/, int Cin, int H, int W, int WP, int relu_in,
+                                                              const h16* __restrict__ dw /*[CO][9][8]*/, const h16* __restrict__ pwf /*[KG][MT][64][8]*/,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                              void* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk, h16* __restrict__ u_out) {
+  using orcai_lds::glds16;
+  using orcai_lds::wait_vm_barrier;
+  constexpr int NWV = 8, KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  static_assert(!(XP && UOUT), "the training forward writes planes");
+  extern __shared__ __attribute__((aligned(16))) h16x8 smem_hf[];
+  const int CO = (Cin + 7) >> 3, COo = (Cout + 7) >> 3, KG = (CO + 3) >> 2;
+  h16x8* rows_s = smem_hf;                    // [2][nchunk * 64] pixels
+  h16x8* pw_s = smem_hf + 2 * nchunk * 64;    // [KG][MT][64]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const char* src = reinterpret_cast<const char*>(in) + (int64_t)b * CO * plane * 16;
+
+  const int s0 = bx * NWV * VAL - lo;  // flat pixel of LDS position 0: lane 0 of the first window, one row up
+  auto goff = [&](int c) {
+    const int i = s0 + 64 * c + lane;
+    return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+  };
+  const uint32_t off0 = goff(wave), off1 = goff(wave + NWV), off2 = goff(wave + 2 * NWV);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)rows_s;
+  const int mine = wave < nchunk ? (wave + NWV < nchunk ? (wave + 2 * NWV < nchunk ? 3 : 2) : 1) : 0;
+  auto issue = [&](int o) {
+    const char* base = src + (int64_t)o * plane * 16;
+    const uint32_t slot = lds0 + (uint32_t)((o & 1) * nchunk * 1024);
+    if (mine > 0) glds16(base + off0, slot + (uint32_t)wave * 1024u);
+    if (mine > 1) glds16(base + off1, slot + (uint32_t)(wave + NWV) * 1024u);
+    if (mine > 2) glds16(base + off2, slot + (uint32_t)(wave + 2 * NWV) * 1024u);
+  };
+  issue(0);
+  for (int i = threadIdx.x; i < KG * MT * 64; i += 64 * NWV) pw_s[i] = reinterpret_cast<const h16x8*>(pwf)[i];
+  __syncthreads();
+
+  const int task = bx * NWV + wave;
+  const bool wave_live = task < tasks;
+  const int qbase = R * WP + task * VAL - lo;
+  const int q = qbase + lane;
+  bool u_live = false;
+  if (UOUT) {
+    const int urow = (int)__umulhi((uint32_t)q, magic_WP);
+    u_live = wave_live && lane >= lo && lane < 64 - lo && (q - urow * WP) < W && urow < R + H;
+  }
+  const bool u_any = UOUT && __builtin_amdgcn_readfirstlane((int)(__ballot(u_live) != 0ull)) != 0;
+  const h16x8* rbase = rows_s + wave * VAL + lane;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kg = 0; kg < KG; ++kg) {
+    u32x4 d[4];
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo) {
+      const int o = kg * 4 + oo;
+      if (o < CO) {  // workgroup-uniform
+        // outstanding, oldest first: this wave's DMAs of octet o, then (a wave that stores) the depthwise-output store of octet o - 1
+        if (u_any && o > 0) wait_vm_barrier<1>(); else wait_vm_barrier<0>();
+        if (o + 1 < CO) issue(o + 1);
+        const h16x8* rs = rbase + (o & 1) * nchunk * 64;
+        const h16x8 cur[3] = {rs[0], rs[WP], rs[2 * WP]};
+        const h16x8 dd = relu_in ? dw_octet<3, true>(cur, dw + (int64_t)o * KK * 8) : dw_octet<3, false>(cur, dw + (int64_t)o * KK * 8);
+        if (UOUT) {
+          if (u_live) reinterpret_cast<h16x8*>(u_out)[((int64_t)b * CO + o) * plane + q] = dd;
+        }
+        d[oo] = as_u(dd);
+      } else {
+        d[oo] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    octets_to_fragments(d);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const h16x8 a = pw_s[(kg * MT + m) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = mfma_h(a, as_h(d[t]), acc[m][t]);
+    }
+  }
+  if (!wave_live) return;
+
+  // ---- epilogue of sepconv_h_kernel, plane (0) and x-pooled (2) layouts
+  float sc_r[MT][4], sh_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = m * 16 + lk * 4 + r;
+      sc_r[m][r] = co < Cout ? scale[co] : 0.0f;
+      sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
+    }
+  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+#pragma unroll
+  for (int tp = 0; tp < 4; tp += 2) {
+    const int wl = 16 * (tp + (lk & 1)) + lj, flat = qbase + wl;
+    const int row = (int)__umulhi((uint32_t)flat, magic_WP);
+    const int x = flat - row * WP;
+    const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float a[4], bq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = fmaf(acc[m][tp][r], sc_r[m][r], sh_r[m][r]);
+        bq[r] = fmaf(acc[m][tp + 1][r], sc_r[m][r], sh_r[m][r]);
+        if (relu_out) { a[r] = fmaxf(a[r], 0.0f); bq[r] = fmaxf(bq[r], 0.0f); }
+        if (XP) {
+          const int f0 = qbase + 16 * tp + lj, f1 = f0 + 16;
+          const int r0 = (int)__umulhi((uint32_t)f0, magic_WP), r1 = (int)__umulhi((uint32_t)f1, magic_WP);
+          const float oa = __shfl_xor(a[r], 1, 64), ob = __shfl_xor(bq[r], 1, 64);
+          if ((f0 - r0 * WP) + 1 < W) a[r] = fmaxf(a[r], oa);
+          if ((f1 - r1 * WP) + 1 < W) bq[r] = fmaxf(bq[r], ob);
+        }
+      }
+      float o8[8];
+      tiles_to_octet(a, bq, o8);
+      const int oq = 2 * m + (lk >> 1);
+      if (!live || oq >= COo) continue;
+      const h16x8 val = pack8(o8);
+      if (!XP) reinterpret_cast<h16x8*>(out)[((int64_t)b * COo + oq) * plane + flat] = val;
+      else if ((x & 1) == 0) reinterpret_cast<h16x8*>(out)[(((int64_t)b * COo + oq) * H + (row - R)) * WPx + (x >> 1)] = val;
+    }
+  }
+}
+
 struct SepArgsH {
   const h16 *in, *dw, *pwf;
   const float *scale, *shift;
@@ -467,6 +607,23 @@ int launch_sepconv_h(hipStream_t st, const SepArgsH& a) {
   const int VAL = 64 - 2 * lo;
   const int tasks = (a.H * a.WP + VAL - 1) / VAL;
   if ((int64_t)(a.H + 2 * a.RP) * a.WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  if constexpr (KS == 3) {  // k = 3, plane or x-pooled output: rows shared through LDS (the f32 launcher's rule, orcai_sepconv_tile_mode)
+    const int nchunk = (7 * VAL + 64 + 2 * a.WP + 63) / 64;
+    const int KG = ((a.Cin + 7) / 8 + 3) / 4;
+    const size_t lds = ((size_t)2 * nchunk * 64 + (size_t)KG * MT * 64) * 16;
+    if (orcai_sepconv_tile_mode(-1) != 0 && a.RP == 1 && (a.out_layout == 0 || (a.out_layout == 2 && !a.u_out)) && nchunk <= 24 && lds <= 64 * 1024 &&
+        (int64_t)((a.Cout + 7) / 8) * (a.H + 2) * a.WP < (1ll << 27)) {
+      dim3 tgrid((tasks + 7) / 8, a.B);
+#define ORCAI_HFTILE(XP, UOUT)                                                                                                                       \
+  hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, XP, UOUT>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, \
+                     a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
+      if (a.out_layout == 2) ORCAI_HFTILE(true, false);
+      else if (a.u_out) ORCAI_HFTILE(false, true);
+      else ORCAI_HFTILE(false, false);
+#undef ORCAI_HFTILE
+      return (int)hipGetLastError();
+    }
+  }
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_h_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, a.shift, a.Cout, a.relu_out,
                      a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 
+#include "lds_dma.h"
 #include "orcai_hip.h"
 
 namespace {
@@ -692,14 +693,8 @@ __global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* _
 // training forward outstanding).  Ring depths of 3 and 4 slots measured equal to 2: the other 7 waves of the SIMD cover the latency.
 // Same fma chains in the same order as the other two kernels: bit-identical results.
 // =========================================================================================
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier() {  // this wave's DMAs of the current quad have landed -> everybody's have after the barrier
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
+using orcai_lds::glds16;
+using orcai_lds::wait_vm_barrier;
 
 template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT>
 __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,

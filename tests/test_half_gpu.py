@@ -57,12 +57,22 @@ def _sepconv_int_ref(x, dwk, pw, relu_in):
     return np.einsum("bchw,cd->bdhw", u, pw), u
 
 
-@pytest.mark.parametrize("Cin,Cout,k,H,W", [(40, 24, 3, 9, 21), (16, 30, 3, 12, 62), (13, 36, 5, 8, 17), (64, 64, 3, 6, 33), (20, 10, 7, 10, 15)])
-def test_sepconv_h_layouts_exact_integers(Cin, Cout, k, H, W):
+@pytest.mark.parametrize("tile_mode", [0, 1])  # 0: sepconv_h_kernel (one window per wave); 1: sepconv_h_ftile_kernel for k = 3 (rows through LDS)
+@pytest.mark.parametrize("Cin,Cout,k,H,W", [(40, 24, 3, 9, 21), (16, 30, 3, 12, 62), (13, 36, 5, 8, 17), (64, 64, 3, 6, 33), (20, 10, 7, 10, 15),
+                                            (30, 30, 3, 20, 171), (10, 20, 3, 33, 130), (50, 60, 3, 5, 300)])
+def test_sepconv_h_layouts_exact_integers(Cin, Cout, k, H, W, tile_mode):
     from orcai_amd import _native as N
     from orcai_amd.half import pack_depthwise_octets, pack_pointwise_fragments
 
     lib = N.lib()
+    prev_mode = lib.orcai_sepconv_tile_mode(tile_mode)
+    try:
+        _sepconv_h_exact(lib, N, pack_depthwise_octets, pack_pointwise_fragments, Cin, Cout, k, H, W)
+    finally:
+        lib.orcai_sepconv_tile_mode(prev_mode)
+
+
+def _sepconv_h_exact(lib, N, pack_depthwise_octets, pack_pointwise_fragments, Cin, Cout, k, H, W):
     rng = np.random.default_rng(Cin * 100 + Cout)
     B = 2
     x = rng.integers(-2, 3, size=(B, Cin, H, W))
