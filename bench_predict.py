@@ -437,7 +437,7 @@ class HpsearchWorkload:
         return out
 
     def roofline(self):
-        """Dominant kernel symbol of the sweep: the f16 separable-convolution kernel on block-1 planes (sepconv_h_kernel<3, MT>):
+        """Dominant kernel symbol of the sweep: the f16 separable-convolution kernel on block-1 planes (sepconv_h_ftile_kernel<MT, ...>):
         HIP events around its launches inside the timed steps; algorithmic bytes = f16 tensors read / written once per launch."""
         t, by, n = 0.0, 0.0, 0
         for v in self.variants:
@@ -446,7 +446,7 @@ class HpsearchWorkload:
                 t += a.elapsed_time(b)
                 by += 2.0 * B * H * W * (Cin + Cout + (Cin if u_out else 0))
                 n += 1
-        out = {"bound": "hbm", "kernel": "sepconv_h_kernel<3, MT> on block-1 planes (736 x 171), all variants", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        out = {"bound": "hbm", "kernel": "sepconv_h_ftile_kernel<MT, XP, UOUT> on block-1 planes (736 x 171), all variants", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         if n:
             ach = by / (t * 1e-3) / 1e9
             out.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_ms": round(t / n, 4), "launches": n,
