@@ -289,7 +289,8 @@ int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ks
                            const float* scale, const float* shift, int Cout, int relu_out, int out_layout, int H2, int W2, float* out, float* u_out,
                            void* stream);
 
-/* BatchNormalization (training) on padded channel-quad planes: batch mean / biased variance (scratch: f64[8*ceil(C/4)]),
+/* BatchNormalization (training) on padded channel-quad planes: batch mean / biased variance (scratch: f64[8*ceil(C/4)*32] for
+ * orcai_bn_planes_stats -- 32 accumulator copies for its small-plane pass --, f64[8*ceil(C/4)] for the other entry points),
  * y = [relu](v*s + t) at interior pixels, backward (dbeta, dgamma, dv) with the optional ReLU folded in. */
 int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize, double* scratch, float* mean, float* var, void* stream);
 int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
@@ -406,7 +407,7 @@ int orcai_h_gemm_bias_act(const float* A, const void* Wt, const float* bias, con
  * the reference lines); plane tensors are f16 octet planes, statistics / weight gradients / scratch stay f32 / f64, and matrix operands
  * are f16 A fragments: wtf of orcai_h_bn_bwd_pointwise = fragments of the TRANSPOSED pointwise matrix (row = conv-input channel,
  * k = conv-output channel).  Gradient planes carry the caller's static loss scale; nothing here knows its value.
- * scratch2C: f64[16 * ceil(C/8)].  orcai_h_planes_relu_bwd counts f16 elements (a multiple of 8).
+ * scratch2C: f64[16 * ceil(C/8)] (orcai_h_bn_planes_stats: x 32 accumulator copies).  orcai_h_planes_relu_bwd counts f16 elements (a multiple of 8).
  * orcai_h_pack_weights descriptors {type, src offset (floats), dst offset (halves), C, aux}: 0 / 1 depthwise octets forward / reversed
  * (aux = k*k), 2 A fragments of W[C][aux], 3 A fragments of its transpose, 4 identity fragments of C channels, 5 all-ones taps. */
 int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize, double* scratch2C, float* mean, float* var, void* stream);

@@ -63,6 +63,63 @@ __global__ __launch_bounds__(256) void planes_sums_h_kernel(const h16* __restric
   }
 }
 
+// small planes: one workgroup per 4096 consecutive pixels of a (snippet, octet) plane, totals to one of SUM_SHARDS accumulator copies
+// (see planes_sums_sharded_kernel of train_trunk.hip)
+constexpr int SUM_SHARDS = 32;
+__global__ __launch_bounds__(256) void planes_sums_sharded_h_kernel(const h16* __restrict__ x, int CO, int plane, int nchunk, double* __restrict__ shards /*[SUM_SHARDS][CO][16]*/) {
+  __shared__ double red[4][16];
+  const int co = blockIdx.y, b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  const int64_t base = ((int64_t)b * CO + co) * plane;
+  double t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[k] = 0.0;
+  const int p0 = chunk * 4096 + threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    h16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + (it * 4 + u) * 256;
+      v[u] = reinterpret_cast<const h16x8*>(x)[base + (p < plane ? p : plane - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + (it * 4 + u) * 256 < plane) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float f = (float)v[u][k];
+          t[k] += f;
+          t[8 + k] += (double)f * f;
+        }
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t[k] += __shfl_xor(t[k], o, 64);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[threadIdx.x >> 6][k] = t[k];
+  __syncthreads();
+  if (threadIdx.x < 16)
+    atomicAdd(&shards[((int64_t)(blockIdx.x % SUM_SHARDS) * CO + co) * 16 + threadIdx.x],
+              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void bn_finish_stats_sharded_h_kernel(const double* __restrict__ shards, int C, int CO, double count, float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double su = 0.0, sq = 0.0;
+  for (int sh = 0; sh < SUM_SHARDS; ++sh) {
+    su += shards[((int64_t)sh * CO + (c >> 3)) * 16 + (c & 7)];
+    sq += shards[((int64_t)sh * CO + (c >> 3)) * 16 + 8 + (c & 7)];
+  }
+  const double mu = su / count;
+  const double v = sq / count - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(v < 0.0 ? 0.0 : v);
+}
+
 __global__ void bn_finish_stats_h_kernel(const double* __restrict__ sums, const double* __restrict__ sumsq, int C, double count, float* __restrict__ mean,
                                          float* __restrict__ var) {
   const int c = blockIdx.x * 64 + threadIdx.x;
@@ -706,6 +763,14 @@ int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize
   const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  if (plane < 32768) {  // small planes (f16: half the bytes of the f32 case at equal size): sharded accumulators, scratch f64[16 * ceil(C/8) * 32]
+    const int nchunk = (int)((plane + 4095) / 4096);
+    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO * SUM_SHARDS, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(planes_sums_sharded_h_kernel, dim3((unsigned)(B * nchunk), CO), dim3(256), 0, st, (const h16*)v, CO, (int)plane, nchunk, scratch2C);
+    hipLaunchKernelGGL(bn_finish_stats_sharded_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, C, CO, (double)B * H * W, mean, var);
+    return (int)hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);

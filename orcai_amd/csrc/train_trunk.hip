@@ -47,6 +47,59 @@ __global__ __launch_bounds__(256) void planes_sums_kernel(const float* __restric
   }
 }
 
+// The same sums for SMALL planes (blocks 3-4: a few thousand pixels): there planes_sums_kernel's 128 grid-striding workgroups per
+// quad, each ending in a block reduction and same-line double atomics, cost more than the data (48 us for 30 MB).  One workgroup per
+// 4096 consecutive pixels of a (snippet, quad) plane, 16 loads per thread four at a time, totals added to one of SUM_SHARDS copies of
+// the accumulators (copy = workgroup index mod SUM_SHARDS) so that same-line atomics stay few; the finish kernel adds the copies:
+// 13 us.  On block 1 this shape is SLOWER than the striding kernel (284 vs 239 us), so the launcher picks by plane size.
+constexpr int SUM_SHARDS = 32;
+__global__ __launch_bounds__(256) void planes_sums_sharded_kernel(const float* __restrict__ x, int CQ, int plane, int nchunk, double* __restrict__ shards /*[SUM_SHARDS][CQ][8]*/) {
+  __shared__ double red[4][8];
+  const int cq = blockIdx.y, b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  const float4* xp = reinterpret_cast<const float4*>(x) + ((int64_t)b * CQ + cq) * plane;
+  double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = chunk * 4096 + threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + (it * 4 + u) * 256;
+      v[u] = p < plane ? xp[p] : make_float4(0.f, 0.f, 0.f, 0.f);  // the tail adds zeros, like the pads
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t[0] += v[u].x; t[1] += v[u].y; t[2] += v[u].z; t[3] += v[u].w;
+      t[4] += (double)v[u].x * v[u].x; t[5] += (double)v[u].y * v[u].y; t[6] += (double)v[u].z * v[u].z; t[7] += (double)v[u].w * v[u].w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t[k] += __shfl_xor(t[k], o, 64);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x >> 6][k] = t[k];
+  __syncthreads();
+  if (threadIdx.x < 8)
+    atomicAdd(&shards[((int64_t)(blockIdx.x % SUM_SHARDS) * CQ + cq) * 8 + threadIdx.x],
+              red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void bn_finish_stats_sharded_kernel(const double* __restrict__ shards, int C, int CQ, double count, float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double su = 0.0, sq = 0.0;
+  for (int sh = 0; sh < SUM_SHARDS; ++sh) {
+    su += shards[((int64_t)sh * CQ + (c >> 2)) * 8 + (c & 3)];
+    sq += shards[((int64_t)sh * CQ + (c >> 2)) * 8 + 4 + (c & 3)];
+  }
+  const double mu = su / count;
+  const double v = sq / count - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(v < 0.0 ? 0.0 : v);
+}
+
 __global__ void bn_finish_stats_kernel(const double* __restrict__ sums, const double* __restrict__ sumsq, int C, double count, float* __restrict__ mean,
                                        float* __restrict__ var) {
   const int c = blockIdx.x * 64 + threadIdx.x;
@@ -813,6 +866,14 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  if (plane < 16384) {  // small planes: the full-occupancy pass with sharded accumulators (scratch: f64[8 * ceil(C/4) * 32])
+    const int nchunk = (int)((plane + 4095) / 4096);
+    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ * SUM_SHARDS, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(planes_sums_sharded_kernel, dim3((unsigned)(B * nchunk), CQ), dim3(256), 0, st, v, CQ, (int)plane, nchunk, scratch2C);
+    hipLaunchKernelGGL(bn_finish_stats_sharded_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, C, CQ, (double)B * H * W, mean, var);
+    return (int)hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);

@@ -378,7 +378,7 @@ class TrunkTrainer:
         self.adt = torch.float16 if self.half else torch.float32
         if self.half and getattr(model, "architecture", "") != "ResNetLSTM":
             raise NotImplementedError("the f16 path implements ResNetLSTM only")
-        self.scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad, <= 64 channels
+        self.scratch = torch.zeros(8 * 16 * 32, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad (<= 64 channels) x the 32 accumulator copies of orcai_bn_planes_stats
         # ResNet1DConv drops out the output of every residual block (architectures.py:97); ResNetLSTM has no Dropout in the trunk
         self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
         self.block_masks = None  # list of 0/1 plane tensors (one per block) for the current step, or None
