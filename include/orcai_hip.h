@@ -129,10 +129,6 @@ int orcai_padded_width(int W, int ksize);
  * value; values outside [0, 2] only query.  Process-wide, not thread-safe. */
 int orcai_sepconv_tile_mode(int mode);
 
-/* x-pooled strip tiles: 1 (default) = BatchNorm fma and column-pair max fused into 2 instructions per value (the max reads its partner
- * through DPP), 0 = the 5-instruction form.  Bit-identical.  Returns the previous value; other values only query. */
-int orcai_fast_epilogue(int on);
-
 /* Same kind of knob for orcai_conv0_sepconv: windows per wave (>= 1; the next window's inputs are prefetched while the current
  * one is computed).  Returns the previous value; values outside [1, 64] only query. */
 int orcai_entry_windows(int windows_per_wave);

@@ -34,7 +34,6 @@ _SIGNATURES = {
     "orcai_pool_res_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orcai_padded_width": (C.c_int, [C.c_int, C.c_int]),
     "orcai_sepconv_tile_mode": (C.c_int, [C.c_int]),
-    "orcai_fast_epilogue": (C.c_int, [C.c_int]),
     "orcai_entry_windows": (C.c_int, [C.c_int]),
     "orcai_entry_tile": (C.c_int, [C.c_int]),
     "orcai_conv0_sepconv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

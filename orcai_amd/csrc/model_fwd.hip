@@ -146,27 +146,6 @@ __device__ __forceinline__ float relu1(float x) {
   return r;
 }
 
-// Epilogue of the x-pooled kernels for one accumulator (4 output channels of one pixel): v = [max(., 0)] fma(acc, sc, sh), then the max over
-// the column pair (lanes 2k, 2k + 1) with the partner read through the DPP quad permute [1,0,3,2] by the v_max itself.  One asm block
-// so that every DPP read is >= 2 instructions behind the write of its source (the hazard the compiler cannot see through inline asm).
-template <bool RELU>
-__device__ __forceinline__ void bn_pair_max4(const f32x4& acc, const float4& sc, const float4& sh, float (&v)[4]) {
-  if constexpr (RELU) {
-    asm("v_fma_f32 %0, %4, %8, %12\n\tv_fma_f32 %1, %5, %9, %13\n\tv_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15\n\t"
-        "v_max_f32_e32 %0, 0, %0\n\tv_max_f32_e32 %1, 0, %1\n\tv_max_f32_e32 %2, 0, %2\n\tv_max_f32_e32 %3, 0, %3\n\t"
-        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-        : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(sc.x), "v"(sc.y), "v"(sc.z), "v"(sc.w), "v"(sh.x), "v"(sh.y), "v"(sh.z), "v"(sh.w));
-  } else {
-    asm("v_fma_f32 %0, %4, %8, %12\n\tv_fma_f32 %1, %5, %9, %13\n\tv_fma_f32 %2, %6, %10, %14\n\tv_fma_f32 %3, %7, %11, %15\n\t"
-        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-        : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(sc.x), "v"(sc.y), "v"(sc.z), "v"(sc.w), "v"(sh.x), "v"(sh.y), "v"(sh.z), "v"(sh.w));
-  }
-}
-
 // Depthwise stage for one channel quad, lane = pixel.  rows[dy] = the quad's dwordx4 of window row dy; wq = the quad's taps
 // [k*k][4] (channel innermost, wave-uniform -> scalar loads); relu_lo = 0 (ReLU on load) or -inf.
 // By linearity the horizontal taps are applied to per-column partial sums: p_dx = sum_dy w[dy][dx] * a_dy (lane-local,
@@ -717,7 +696,7 @@ __global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* _
 using orcai_lds::glds16;
 using orcai_lds::wait_vm_barrier;
 
-template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, bool FASTEPI = false>
+template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT>
 __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
@@ -815,24 +794,16 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
     const int x = c0 - lo + wl;
     const bool live = wl >= lo && wl < 64 - lo && x < W && (!XP || (x & 1) == 0);
     const bool pair_ok = x + 1 < W;
-    // FASTEPI: a tile without a stored pixel whose pair partner is past the image (all tiles but one per row when W is odd, all of them when
-    // it is even; wave-uniform) takes the 2-instructions-per-value epilogue
-    const bool plain = FASTEPI && XP && __builtin_amdgcn_ballot_w64(live && !pair_ok) == 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
-      float v[4];
-      if (plain) {
-        if (relu_out) bn_pair_max4<true>(acc[m][tt], sc, sh, v); else bn_pair_max4<false>(acc[m][tt], sc, sh, v);
-      } else {
-        v[0] = fmaf(acc[m][tt][0], sc.x, sh.x), v[1] = fmaf(acc[m][tt][1], sc.y, sh.y), v[2] = fmaf(acc[m][tt][2], sc.z, sh.z), v[3] = fmaf(acc[m][tt][3], sc.w, sh.w);
+      float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = max2(v[r], lo_out);
-          if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
-            const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
-            v[r] = max2(v[r], pair_ok ? other : v[r]);
-          }
+      for (int r = 0; r < 4; ++r) {
+        v[r] = max2(v[r], lo_out);
+        if (XP) {  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
+          const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+          v[r] = max2(v[r], pair_ok ? other : v[r]);
         }
       }
       const int oq = m * 4 + lk;
@@ -1837,7 +1808,6 @@ int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
 int g_front_rows = 8;     // output rows per tile of block_front_kernel (8 or 10)
 int g_front_groups = 4;   // consecutive row groups one workgroup of block_front_kernel walks down
-int g_fast_epilogue = 1;  // x-pooled strip tiles: fused fma / pair-max epilogue (A/B knob)
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
                       // >= 2 strips that cover the width with <= 15 % waste) and sepconv_ftile_kernel otherwise; 2 = sepconv_ftile_kernel for
                       // all of them; 0 = sepconv_kernel everywhere (the reference the bit-identity tests compare with)
@@ -1850,14 +1820,7 @@ int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
   hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
   if (a.out_layout == 2) {
-    if (g_fast_epilogue) {
-      if (a.relu_in)
-        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, true, true, TR, false, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
-                           a.Cout, a.relu_out, a.out, nstrip, a.u_out);
-      else
-        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, true, false, TR, false, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
-                           a.Cout, a.relu_out, a.out, nstrip, a.u_out);
-    } else if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
+    if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
   } else if (a.u_out) {
     if (a.relu_in) ORCAI_TILE_LAUNCH(false, true, true); else ORCAI_TILE_LAUNCH(false, false, true);
   } else {
@@ -1958,12 +1921,6 @@ int orcai_entry_tile(int waves) {
 int orcai_entry_windows(int windows_per_wave) {
   const int prev = g_entry_windows;
   if (windows_per_wave >= 1 && windows_per_wave <= 64) g_entry_windows = windows_per_wave;
-  return prev;
-}
-
-int orcai_fast_epilogue(int on) {
-  const int prev = g_fast_epilogue;
-  if (on == 0 || on == 1) g_fast_epilogue = on;
   return prev;
 }
 
