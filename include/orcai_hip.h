@@ -158,21 +158,6 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
                         const float* dw, const float* pw, const float* scale, const float* shift, int Cout, int relu_out, float* out, float* prev_sub,
                         void* stream);
 
-/* The front of residual block 1 in ONE launch, k = 3, inference (architectures.py:164-189):
- *   Conv2D(16, 3, same) + BN + ReLU -> ReLU -> SeparableConv2D(Cmid) -> BN -> ReLU -> SeparableConv2D(Cout) -> BN -> [ReLU] -> max over column pairs
- * = orcai_conv0_sepconv(relu_out = 1) followed by orcai_sepconv_bn(relu_in = 0, out_layout = 2), bit for bit, without the first
- * separable convolution's output (the largest tensor of the model) ever reaching HBM.  Cmid, Cout <= 32.
- *   in / snippet_stride / w0 / scale0 / shift0 / prev_sub   as for orcai_conv0_sepconv
- *   dw_a f32[4][9][4], pw_a f32[16][Cmid], scale_a / shift_a f32[Cmid]; dw_b f32[ceil(Cmid/4)][9][4], pw_b f32[Cmid][Cout], scale_b / shift_b f32[Cout]
- *   out_x   f32[B][ceil(Cout/4)][H][WPx][4], WPx = ceil(W/2) rounded up to 4: the x-pooled planes orcai_pool_res_add reads (out_layout 2 of orcai_sepconv_bn) */
-int orcai_block_front(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w0, const float* scale0, const float* shift0,
-                      const float* dw_a, const float* pw_a, const float* scale_a, const float* shift_a, int Cmid, const float* dw_b, const float* pw_b,
-                      const float* scale_b, const float* shift_b, int Cout, int relu_out, float* out_x, float* prev_sub, void* stream);
-
-/* Tile shape of orcai_block_front: output rows per tile (8 or 10; a workgroup has rows + 4 waves) and the number of consecutive tiles a
- * workgroup walks down its column strip (1..255).  Returns previous rows * 256 + previous groups; other values only query. */
-int orcai_block_front_config(int rows, int groups);
-
 /* [ReLU] -> SeparableConv2D(Cout, k, same) -> BN -> [ReLU]   (architectures.py:174-189, :198-206)
  *   in   f32[B][ceil(Cin/4)][HP][WP][4] padded channel-quad planes
  *   dw   f32[ceil(Cin/4)][k*k][4]   channel-quad layout: element (q, tap, j) = Keras depthwise kernel (k,k,Cin,1) at

@@ -37,8 +37,6 @@ _SIGNATURES = {
     "orcai_entry_windows": (C.c_int, [C.c_int]),
     "orcai_entry_tile": (C.c_int, [C.c_int]),
     "orcai_conv0_sepconv": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "orcai_block_front": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "orcai_block_front_config": (C.c_int, [C.c_int, C.c_int]),
     "orcai_gemm_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "orcai_lstm_recurrent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dense_sigmoid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -87,7 +87,6 @@ class ResNetLSTM:
         # inference, k = 3: the entry convolution is computed inside the first separable convolution (orcai_conv0_sepconv); the
         # 16-channel entry activation never reaches HBM, block 1's residual branch reads a quarter-size subsample of it
         self.fuse_entry = os.environ.get("ORCAI_FUSE_ENTRY", "1") != "0"
-        self.fuse_front = os.environ.get("ORCAI_FUSE_FRONT", "0") != "0"  # experiment: orcai_block_front for block 1
         self.kernel_events = None  # bench hook: {label: [(start_event, end_event), ...]} when not None
         self.kernel_event_labels = None  # bench hook: restrict the event brackets to these labels (an event pair costs ~15 us of queue time)
         # Inference trunk in two phases: blocks < tail_from_block in chunks of `chunk` snippets (their planes are large), the
@@ -362,14 +361,7 @@ class ResNetLSTM:
             prev, a, bb, nxt = ws[f"prev{b - 1}"], ws[f"a{b}"], ws[f"b{b}"], ws[f"prev{b}"]
             pa, pb = f"b{b}/sep_a", f"b{b}/sep_b"
             entry = fuse_entry and b == 1
-            front = entry and self.fuse_front and f <= 32
-            if front:  # entry conv + both separable convs of block 1 in one launch: the a1 tensor never reaches HBM
-                prev = ws["prev0s"]
-                self._launch("conv0+b1/sep_a+sep_b", "orcai_block_front", lib.orcai_block_front, src.data_ptr(), snippet_stride, B, H, W, N.ptr(d["conv0/w"]),
-                             N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
-                             N.ptr(d[pa + "/shift"]), f, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0,
-                             N.ptr(bb), N.ptr(prev), st)
-            elif entry:
+            if entry:
                 prev = ws["prev0s"]
                 self._launch("conv0+b1/sep_a", "orcai_conv0_sepconv", lib.orcai_conv0_sepconv, src.data_ptr(), snippet_stride, B, H, W, N.ptr(d["conv0/w"]),
                              N.ptr(d["conv0/scale"]), N.ptr(d["conv0/shift"]), N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]), N.ptr(d[pa + "/scale"]),
@@ -377,9 +369,8 @@ class ResNetLSTM:
             else:
                 self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                              N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
-            if not front:
-                self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
-                             N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
+            self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
+                         N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),
                          N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 3 if entry else 1, st)
         if last == nb + 1:

@@ -816,287 +816,6 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 }
 
 // =========================================================================================
-// block_front: entry conv + BN + ReLU -> first separable conv + BN + ReLU -> second separable conv + BN -> x-pool of block 1 in ONE
-// launch: neither the entry activation nor the first separable conv's output (the largest tensor of the model: 15 MB written and
-// read back per snippet) reaches HBM.  A workgroup of TRO + 4 waves owns TRO output rows x 60 columns (lane l <-> column c0 - 2 + l in
-// all three stages) and walks down `gpw` consecutive row groups of its column strip:
-//   phase 1  wave w computes the entry activation of image row r0 - 2 + w (all 64 lanes valid: inputs straight from the snippet) -> LDS;
-//   phase 2  waves 0 .. TRO + 1: separable conv a of row r0 - 1 + w from three LDS rows (lanes 1..62 valid), BN + ReLU, ZERO outside the
-//            image (it is the padding of the next depthwise stage) -> LDS [row][quad][lane][4], the layout the plane kernels read;
-//   phase 3  waves 0 .. TRO - 1: separable conv b of row r0 + w from three LDS rows (lanes 2..61 valid), BN, x-pool, store.
-// Two barriers per tile (LDS only: stores and the next tile's input loads stay in flight); waves without a phase-3 row start the next
-// tile's phase 1 early.  The arithmetic of conv0_kernel + sepconv_kernel<3, 2> twice, same fma chains in the same order: bit-identical
-// to the three-launch path.  One workgroup per compute unit (LDS: (TRO + 4) * 4 + (TRO + 2) * 8 KiB), TRO + 4 waves.
-// =========================================================================================
-// dw_quad_impl<3, false> in two halves, weights passed by value (already in scalar registers): the multiply-accumulate block that consumes
-// the rows and the taps, and the lane-shift block that needs neither -- block_front issues the next quad's loads between the two.
-__device__ __forceinline__ void load36(const float* __restrict__ src, float (&w)[36]) {
-#pragma unroll
-  for (int i = 0; i < 36; ++i) w[i] = src[i];
-}
-__device__ __forceinline__ void dw3_partial(const float4 (&rows)[3], const float (&w)[36], f32x2 (&p01)[3], f32x2 (&p23)[3]) {
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx) { p01[dx] = (f32x2){0.f, 0.f}; p23[dx] = (f32x2){0.f, 0.f}; }
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    const f32x2 a01 = {rows[dy].x, rows[dy].y}, a23 = {rows[dy].z, rows[dy].w};
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int o = (dy * 3 + dx) * 4;
-      const f32x2 w01 = {w[o], w[o + 1]}, w23 = {w[o + 2], w[o + 3]};
-      p01[dx] = a01 * w01 + p01[dx];
-      p23[dx] = a23 * w23 + p23[dx];
-    }
-  }
-}
-__device__ __forceinline__ void dw3_finish(const f32x2 (&p01)[3], const f32x2 (&p23)[3], float (&d)[4]) {
-  d[0] = p01[1].x + lane_shift<-1>(p01[0].x);
-  d[1] = p01[1].y + lane_shift<-1>(p01[0].y);
-  d[2] = p23[1].x + lane_shift<-1>(p23[0].x);
-  d[3] = p23[1].y + lane_shift<-1>(p23[0].y);
-  d[0] += lane_shift<1>(p01[2].x);
-  d[1] += lane_shift<1>(p01[2].y);
-  d[2] += lane_shift<1>(p23[2].x);
-  d[3] += lane_shift<1>(p23[2].y);
-}
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int TRO, bool FULLQ /*Cmid in 29..32: all eight input quads of the second conv, no per-quad branch*/>
-__global__ __launch_bounds__(64 * (TRO + 4)) void block_front_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W,
-                                                                   const float* __restrict__ w0_ /*[9][16]*/, const float* __restrict__ sc0_,
-                                                                   const float* __restrict__ sh0_, const float* __restrict__ dwa_ /*[4][9][4]*/,
-                                                                   const float* __restrict__ pwa /*[16][Cmid]*/, const float* __restrict__ sca,
-                                                                   const float* __restrict__ sha, int Cmid, const float* __restrict__ dwb_ /*[8][9][4]*/,
-                                                                   const float* __restrict__ pwb /*[Cmid][Cout]*/, const float* __restrict__ scb,
-                                                                   const float* __restrict__ shb, int Cout, int relu_b, float* __restrict__ out,
-                                                                   float* __restrict__ prev_sub, int nstrip, int ngroups, int gpw) {
-  constexpr int lo = 2, VAL = 60, C0 = 16, MT = 2, NW = TRO + 4;
-  extern __shared__ __attribute__((aligned(16))) float smem_bf[];
-  float* act_s = smem_bf;                      // [NW][4][64][4]       entry activation
-  float* a1_s = act_s + NW * 1024;             // [TRO + 2][8][64][4]  first separable conv's output
-  float* pwa_s = a1_s + (TRO + 2) * 2048;      // [(ci * 16 + lj)][m]
-  float* pwb_s = pwa_s + C0 * 16 * MT;
-  float* sca_s = pwb_s + 32 * 16 * MT;
-  float* sha_s = sca_s + 32;
-  float* scb_s = sha_s + 32;
-  float* shb_s = scb_s + 32;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int bx, b;
-  xcd_remap(bx, b);
-  const int chunk = bx / nstrip, strip = bx - chunk * nstrip;
-  const int c0 = strip * VAL;
-  const int g0 = chunk * gpw, g1 = g0 + gpw < ngroups ? g0 + gpw : ngroups;
-  const int lk = lane >> 4, lj = lane & 15;
-  const int CQb = (Cmid + 3) >> 2, CQo = (Cout + 3) >> 2;
-  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-  const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
-  const float lo_out = relu_b ? 0.0f : -INFINITY;
-  const int x = c0 - lo + lane;
-
-  for (int i = threadIdx.x; i < C0 * 16 * MT; i += 64 * NW) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pwa_s[i] = co < Cmid ? pwa[ci * Cmid + co] : 0.0f;
-  }
-  for (int i = threadIdx.x; i < 32 * 16 * MT; i += 64 * NW) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pwb_s[i] = (ci < Cmid && co < Cout) ? pwb[ci * Cout + co] : 0.0f;
-  }
-  if (threadIdx.x < 32) {
-    const int co = threadIdx.x;
-    sca_s[co] = co < Cmid ? sca[co] : 0.0f;
-    sha_s[co] = co < Cmid ? sha[co] : 0.0f;
-    scb_s[co] = co < Cout ? scb[co] : 0.0f;
-    shb_s[co] = co < Cout ? shb[co] : 0.0f;
-  }
-
-  // inputs of the entry convolution through a raw buffer resource over the snippet's H * W floats: rows outside the snippet and columns
-  // outside the image (offset sentinel) read as 0
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
-  f32x2 inp[5];  // input (row d, column j) in half (3d + j) & 1 of pair (3d + j) >> 1
-  auto load_inputs = [&](int g) {
-    constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a row pitch
-    const int e = g * TRO - 2 + wave;
-    const uint32_t center = (uint32_t)((e * W + x) * 4);
-    const bool e_ok = e >= -1 && e <= H;  // beyond that even the neighbouring rows are outside (and center may wrap into range)
-    const uint32_t off[3] = {(e_ok && x >= 1 && x <= W) ? center - 4u : OOB, (e_ok && x >= 0 && x < W) ? center : OOB, (e_ok && x >= -1 && x + 1 < W) ? center + 4u : OOB};
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        inp[(3 * d + j) >> 1][(3 * d + j) & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 1) * W * 4), 0, 0));
-    inp[4][1] = 0.0f;
-  };
-  load_inputs(g0);
-
-  for (int g = g0; g < g1; ++g) {
-    const int r0 = g * TRO;
-    // the weights are re-read through the scalar cache every tile: hoisted out of the tile loop the ~600 scalars do not fit the SGPR file
-    int opaque_zero = 0;
-    asm volatile("" : "+s"(opaque_zero));
-    // ---- phase 1: entry activation of image row e at columns x
-    {
-      const float* w0 = static_cast<const float*>(__builtin_assume_aligned(w0_ + opaque_zero, 16));
-      const float* sc0 = static_cast<const float*>(__builtin_assume_aligned(sc0_ + opaque_zero, 16));
-      const float* sh0 = static_cast<const float*>(__builtin_assume_aligned(sh0_ + opaque_zero, 16));
-      const int e = r0 - 2 + wave;
-      const float hi = (x >= 0 && x < W && e >= 0 && e < H) ? INFINITY : 0.0f;  // the activation is zero outside the image: the depthwise padding
-      // the residual branch's (2i, 2j) subsample: written by the owner of the row (tile rows 2 .. TRO + 1, lanes lo .. 63 - lo)
-      const bool sub_lane = prev_sub && wave >= 2 && wave < TRO + 2 && lane >= lo && lane < 64 - lo && x < W && e < H && ((x | e) & 1) == 0;
-      float4* sub = reinterpret_cast<float4*>(prev_sub) + (int64_t)b * (C0 / 4) * Ho * Wo + (e >> 1) * Wo + (x >> 1);
-#pragma unroll
-      for (int cq = 0; cq < C0 / 4; ++cq) {
-        const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
-        const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
-            const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
-            const int ii = 3 * dy + dx;
-            a01 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w01, a01) : pk_fma_bcast<0>(inp[ii >> 1], w01, a01));
-            a23 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w23, a23) : pk_fma_bcast<0>(inp[ii >> 1], w23, a23));
-          }
-        a01 = a01 * s01 + h01;
-        a23 = a23 * s23 + h23;
-        const float4 c = make_float4(relu_mask(a01.x, hi), relu_mask(a01.y, hi), relu_mask(a23.x, hi), relu_mask(a23.y, hi));
-        *reinterpret_cast<float4*>(&act_s[(wave * 4 + cq) * 256 + lane * 4]) = c;
-        if (sub_lane) sub[(int64_t)cq * Ho * Wo] = c;
-      }
-    }
-    if (g + 1 < g1) load_inputs(g + 1);  // in flight during phases 2 and 3
-    lds_barrier();  // entry rows of this tile written (and: every wave is done with the previous tile's phase 3)
-
-    // ---- phase 2: first separable conv of image row r0 - 1 + wave
-    if (wave < TRO + 2) {
-      const float* dwa = static_cast<const float*>(__builtin_assume_aligned(dwa_ + opaque_zero, 16));
-      f32x4 acc[MT][4];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float4 rows[3];
-      f32x2 af;
-      float w[36];
-#define ORCAI_BF_ISSUE2(cq_)                                                                                                       \
-  {                                                                                                                                \
-    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&act_s[((wave + dy) * 4 + (cq_)) * 256 + lane * 4]); \
-    af = *reinterpret_cast<const f32x2*>(&pwa_s[(((cq_) * 4 + lk) * 16 + lj) * MT]);                                              \
-    load36(dwa + (cq_) * 36, w);                                                                                                   \
-  }
-      ORCAI_BF_ISSUE2(0)
-#pragma unroll
-      for (int cq = 0; cq < C0 / 4; ++cq) {
-        f32x2 p01[3], p23[3];
-        __builtin_amdgcn_sched_barrier(0);
-        dw3_partial(rows, w, p01, p23);  // the entry activation is already >= 0: the separable conv's ReLU is the identity
-        const f32x2 afc = af;
-        __builtin_amdgcn_sched_barrier(0);
-        if (cq + 1 < C0 / 4) ORCAI_BF_ISSUE2(cq + 1)  // rows and taps of this quad are consumed: the next quad's land behind the shifts and MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        float d[4];
-        dw3_finish(p01, p23, d);
-        swap32(d[0], d[2]);
-        swap32(d[1], d[3]);
-        swap16(d[0], d[1]);
-        swap16(d[2], d[3]);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          acc[0][tt] = mfma16(afc.x, d[tt], acc[0][tt]);
-          acc[1][tt] = mfma16(afc.y, d[tt], acc[1][tt]);
-        }
-      }
-#undef ORCAI_BF_ISSUE2
-      const int ea = r0 - 1 + wave;
-      const bool row_in = ea >= 0 && ea < H;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int wl = 16 * tt + lj;
-        const int xx = c0 - lo + wl;
-        const float hi = (row_in && xx >= 0 && xx < W) ? INFINITY : 0.0f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 sc = reinterpret_cast<const float4*>(sca_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sha_s)[m * 4 + lk];
-          const int oq = m * 4 + lk;
-          *reinterpret_cast<float4*>(&a1_s[(wave * 8 + oq) * 256 + wl * 4]) =
-              make_float4(relu_mask(fmaf(acc[m][tt][0], sc.x, sh.x), hi), relu_mask(fmaf(acc[m][tt][1], sc.y, sh.y), hi),
-                          relu_mask(fmaf(acc[m][tt][2], sc.z, sh.z), hi), relu_mask(fmaf(acc[m][tt][3], sc.w, sh.w), hi));
-        }
-      }
-    }
-    lds_barrier();  // first-conv rows written; the entry rows are free for the next tile
-
-    // ---- phase 3: second separable conv of image row r0 + wave, x-pooled
-    const int row = r0 + wave;
-    if (wave < TRO && row < H) {
-      const float* dwb = static_cast<const float*>(__builtin_assume_aligned(dwb_ + opaque_zero, 16));
-      f32x4 acc[MT][4];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      float4 rows[3];
-      f32x2 af;
-      float w[36];
-#define ORCAI_BF_ISSUE3(cq_)                                                                                                       \
-  {                                                                                                                                \
-    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&a1_s[((wave + dy) * 8 + (cq_)) * 256 + lane * 4]); \
-    af = *reinterpret_cast<const f32x2*>(&pwb_s[(((cq_) * 4 + lk) * 16 + lj) * MT]);                                              \
-    load36(dwb + (cq_) * 36, w);                                                                                                   \
-  }
-      ORCAI_BF_ISSUE3(0)
-#pragma unroll
-      for (int cq = 0; cq < 8; ++cq) {
-        if (FULLQ || cq < CQb) {  // workgroup-uniform
-          f32x2 p01[3], p23[3];
-          __builtin_amdgcn_sched_barrier(0);
-          dw3_partial(rows, w, p01, p23);
-          const f32x2 afc = af;
-          __builtin_amdgcn_sched_barrier(0);
-          if (cq + 1 < 8 && (FULLQ || cq + 1 < CQb)) ORCAI_BF_ISSUE3(cq + 1)
-          __builtin_amdgcn_sched_barrier(0);
-          float d[4];
-          dw3_finish(p01, p23, d);
-          swap32(d[0], d[2]);
-          swap32(d[1], d[3]);
-          swap16(d[0], d[1]);
-          swap16(d[2], d[3]);
-#pragma unroll
-          for (int tt = 0; tt < 4; ++tt) {
-            acc[0][tt] = mfma16(afc.x, d[tt], acc[0][tt]);
-            acc[1][tt] = mfma16(afc.y, d[tt], acc[1][tt]);
-          }
-        }
-      }
-#undef ORCAI_BF_ISSUE3
-      float4* outb = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * H * WPx;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int wl = 16 * tt + lj;
-        const int xo = c0 - lo + wl;
-        const bool live = wl >= lo && wl < 64 - lo && xo < W && (xo & 1) == 0;
-        const bool pair_ok = xo + 1 < W;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 sc = reinterpret_cast<const float4*>(scb_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(shb_s)[m * 4 + lk];
-          float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = max2(v[r], lo_out);
-            const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
-            v[r] = max2(v[r], pair_ok ? other : v[r]);  // max over the column pair (2j, 2j+1); the second column is ignored when it is past the image
-          }
-          const int oq = m * 4 + lk;
-          if (live && oq < CQo) outb[(oq * H + row) * WPx + (xo >> 1)] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-    }
-  }
-}
-
-// =========================================================================================
 // sepconv_ftile: the LDS-shared rows of sepconv_tile for ANY plane width.  The NWV waves of a workgroup own NWV consecutive 64-pixel
 // windows of the flat padded plane (the mapping of sepconv_kernel: no strip waste on narrow planes); the rows above and below are
 // the same flat range shifted by -WP / +WP, so the three rows of all NWV windows are ONE contiguous range of
@@ -1806,8 +1525,6 @@ struct SepArgs {
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
-int g_front_rows = 8;     // output rows per tile of block_front_kernel (8 or 10)
-int g_front_groups = 4;   // consecutive row groups one workgroup of block_front_kernel walks down
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
                       // >= 2 strips that cover the width with <= 15 % waste) and sepconv_ftile_kernel otherwise; 2 = sepconv_ftile_kernel for
                       // all of them; 0 = sepconv_kernel everywhere (the reference the bit-identity tests compare with)
@@ -1983,50 +1700,6 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
     case 4: ORCAI_C0S(4); break;
   }
 #undef ORCAI_C0S
-  return (int)hipGetLastError();
-}
-
-int orcai_block_front_config(int rows, int groups) {
-  const int prev = g_front_rows * 256 + g_front_groups;
-  if (rows == 8 || rows == 10) g_front_rows = rows;
-  if (groups >= 1 && groups <= 255) g_front_groups = groups;
-  return prev;
-}
-
-int orcai_block_front(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w0, const float* scale0, const float* shift0,
-                      const float* dw_a, const float* pw_a, const float* scale_a, const float* shift_a, int Cmid, const float* dw_b, const float* pw_b,
-                      const float* scale_b, const float* shift_b, int Cout, int relu_out, float* out_x, float* prev_sub, void* stream) {
-  if (!in || !w0 || !scale0 || !shift0 || !dw_a || !pw_a || !scale_a || !shift_a || !dw_b || !pw_b || !scale_b || !shift_b || !out_x || B <= 0 || H <= 0 ||
-      W <= 0 || Cmid <= 0 || Cout <= 0)
-    return ORCAI_E_BADARG;
-  if (Cmid > 32 || Cout > 32 || B > 65535 || (int64_t)H * W >= (1ll << 26) ||
-      (((uintptr_t)w0 | (uintptr_t)dw_a | (uintptr_t)dw_b | (uintptr_t)scale0 | (uintptr_t)shift0 | (uintptr_t)out_x) & 15))
-    return ORCAI_E_UNSUPPORTED;
-  const int WPx = (((W + 1) >> 1) + 3) & ~3;
-  if ((int64_t)((Cout + 3) / 4) * H * WPx >= (1ll << 27)) return ORCAI_E_UNSUPPORTED;  // 32-bit element offsets inside a snippet's planes
-  hipStream_t st = (hipStream_t)stream;
-  const int nstrip = (W + 59) / 60;
-  const int TRO = g_front_rows, ngroups = (H + TRO - 1) / TRO, gpw = g_front_groups < ngroups ? g_front_groups : ngroups;
-  const size_t lds = (size_t)((TRO + 4) * 1024 + (TRO + 2) * 2048 + 16 * 16 * 2 + 32 * 16 * 2 + 4 * 32) * sizeof(float);
-  dim3 grid(nstrip * ((ngroups + gpw - 1) / gpw), B);
-#define ORCAI_FRONT(TRO_, FULLQ_)                                                                                                                     \
-  {                                                                                                                                                     \
-    static bool opted = false;                                                                                                                          \
-    if (!opted) {                                                                                                                                       \
-      hipError_t e = hipFuncSetAttribute((const void*)block_front_kernel<TRO_, FULLQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-      if (e != hipSuccess) return (int)e;                                                                                                               \
-      opted = true;                                                                                                                                     \
-    }                                                                                                                                                   \
-    hipLaunchKernelGGL((block_front_kernel<TRO_, FULLQ_>), grid, dim3(64 * (TRO_ + 4)), lds, st, in, snippet_stride, H, W, w0, scale0, shift0, dw_a, pw_a,   \
-                       scale_a, shift_a, Cmid, dw_b, pw_b, scale_b, shift_b, Cout, relu_out, out_x, prev_sub, nstrip, ngroups, gpw);                  \
-  }
-  const bool fullq = Cmid > 28;
-  if (TRO == 10) {
-    if (fullq) ORCAI_FRONT(10, true) else ORCAI_FRONT(10, false)
-  } else {
-    if (fullq) ORCAI_FRONT(8, true) else ORCAI_FRONT(8, false)
-  }
-#undef ORCAI_FRONT
   return (int)hipGetLastError();
 }
 

@@ -408,52 +408,3 @@ def test_forward_is_hip_graph_capturable():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(static_out, want)
-
-
-def test_block_front_random_shapes():
-    """orcai_block_front (entry conv + both separable convs of block 1 + x-pool in one launch, the intermediate tensors in LDS) against
-    orcai_conv0_sepconv + orcai_sepconv_bn(out_layout 2) on seeded random shapes: single rows, fewer rows than a tile, widths from a
-    fraction of a strip to several strips, odd / even sizes, every channel count up to 32, both tile heights, one and several tiles
-    per workgroup; overlapping snippet views.  Same fma chains in the same order: bit-identical."""
-    from orcai_amd import _native as N
-
-    lib = N.lib()
-    dev = torch.device("cuda", 0)
-    rng = np.random.default_rng(31)
-    g = torch.Generator(device="cpu").manual_seed(31)
-    for case in range(14):
-        H, W = int(rng.integers(1, 60)), int(rng.integers(2, 200))
-        Cmid, Cout = int(rng.integers(1, 33)), int(rng.integers(1, 33))
-        if case % 3 == 0:
-            W, Cmid, Cout = int(rng.integers(106, 260)), int(rng.integers(17, 33)), int(rng.integers(17, 33))
-        B = 3
-        stride = (H // 2 + 1) * W
-        src = torch.randn((B - 1) * stride + H * W, generator=g).to(dev)
-        w0, sc0, sh0 = torch.randn(9, 16, generator=g).to(dev), torch.randn(16, generator=g).to(dev), torch.randn(16, generator=g).to(dev)
-        dwa, pwa = torch.randn(4, 9, 4, generator=g).to(dev), (0.25 * torch.randn(16, Cmid, generator=g)).to(dev)
-        sca, sha = torch.randn(Cmid, generator=g).to(dev), torch.randn(Cmid, generator=g).to(dev)
-        CQm, CQo = (Cmid + 3) // 4, (Cout + 3) // 4
-        dwb = torch.randn(CQm, 9, 4, generator=g).to(dev)
-        pwb = (0.25 * torch.randn(Cmid, Cout, generator=g)).to(dev)
-        scb, shb = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
-        WP, WPx = lib.orcai_padded_width(W, 3), (((W + 1) // 2) + 3) & ~3
-        relu_out = int(rng.integers(0, 2))
-        st = N.stream_ptr()
-        a = torch.zeros((B, CQm, H + 2, WP, 4), device=dev)
-        sub_ref = torch.zeros((B, 4, (H + 1) // 2, (W + 1) // 2, 4), device=dev)
-        x_ref = torch.zeros((B, CQo, H, WPx, 4), device=dev)
-        assert lib.orcai_conv0_sepconv(N.ptr(src), stride, B, H, W, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(dwa), N.ptr(pwa), N.ptr(sca), N.ptr(sha), Cmid, 1,
-                                       N.ptr(a), N.ptr(sub_ref), st) == 0
-        assert lib.orcai_sepconv_bn(N.ptr(a), B, Cmid, H, W, 3, 0, N.ptr(dwb), N.ptr(pwb), N.ptr(scb), N.ptr(shb), Cout, relu_out, 2, N.ptr(x_ref), st) == 0
-        for rows, groups in ((8, 1), (8, 4), (10, 3)):
-            prev = lib.orcai_block_front_config(rows, groups)
-            try:
-                x_f = torch.zeros_like(x_ref)
-                sub = torch.zeros_like(sub_ref)
-                assert lib.orcai_block_front(N.ptr(src), stride, B, H, W, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(dwa), N.ptr(pwa), N.ptr(sca), N.ptr(sha), Cmid,
-                                             N.ptr(dwb), N.ptr(pwb), N.ptr(scb), N.ptr(shb), Cout, relu_out, N.ptr(x_f), N.ptr(sub), st) == 0
-                torch.cuda.synchronize()
-            finally:
-                lib.orcai_block_front_config(prev >> 8, prev & 255)
-            assert torch.equal(x_f, x_ref), (case, H, W, Cmid, Cout, rows, groups, float((x_f - x_ref).abs().max()))
-            assert torch.equal(sub, sub_ref), (case, H, W, Cmid, Cout, rows, groups)
