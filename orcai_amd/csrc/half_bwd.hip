@@ -134,6 +134,14 @@ __global__ void f64_to_f32_h_kernel(const double* __restrict__ a, float* __restr
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
 }
+// the two BatchNorm parameter gradients (d beta, d gamma) in one launch
+__global__ void f64_to_f32_pair_h_kernel(const double* __restrict__ a0, float* __restrict__ b0, const double* __restrict__ a1, float* __restrict__ b1, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) {
+    b0[i] = (float)a0[i];
+    b1[i] = (float)a1[i];
+  }
+}
 
 // y = [relu](v * s + t) at interior pixels; pads of y stay zero
 __global__ __launch_bounds__(256) void bn_planes_apply_h_kernel(const h16* __restrict__ v, int C, int H, int W, int WP, int R, const float* __restrict__ mean,
@@ -516,9 +524,13 @@ __global__ __launch_bounds__(256) void add_partials_h_kernel(const float* __rest
   if (i >= n) return;
   const int per = (nparts + gridDim.y - 1) / gridDim.y;
   const int k0 = blockIdx.y * per, k1 = (k0 + per < nparts) ? k0 + per : nparts;
-  float s = 0.f;
-  for (int k = k0; k < k1; ++k) s += part[(int64_t)k * n + i];
-  if (k1 > k0) atomicAdd(&D[i], s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight per thread (as add_partials_kernel of the f32 path)
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {
+    s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 1) * n + i]; s2 += part[(int64_t)(k + 2) * n + i]; s3 += part[(int64_t)(k + 3) * n + i];
+  }
+  for (; k < k1; ++k) s0 += part[(int64_t)k * n + i];
+  if (k1 > k0) atomicAdd(&D[i], (s0 + s1) + (s2 + s3));
 }
 
 // ---------------------------------------------------------------- depthwise weight gradient
@@ -836,8 +848,7 @@ int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H,
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_HBBP
-  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
-  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_pair_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 
@@ -928,8 +939,7 @@ int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy
     case 7: hipLaunchKernelGGL((conv0_bn_wgrad_h_kernel<7, 4>), grid, dim3(256), 0, st, in, snippet_stride, (const h16*)dy, (const h16*)v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);
-  hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3(1), dim3(64), 0, st, dg, dgamma, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_pair_h_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 

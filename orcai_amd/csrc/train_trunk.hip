@@ -320,6 +320,14 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ a, float* __restric
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
 }
+// the two BatchNorm parameter gradients (d beta, d gamma) in one launch
+__global__ void f64_to_f32_pair_kernel(const double* __restrict__ a0, float* __restrict__ b0, const double* __restrict__ a1, float* __restrict__ b1, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) {
+    b0[i] = (float)a0[i];
+    b1[i] = (float)a1[i];
+  }
+}
 
 // ---------------------------------------------------------------- max-pool backward
 // dy[y][x] = sum over the pooling windows (i, j) containing (y, x) of dout[i][j] * [ybn[y][x] == max of that window]
@@ -925,8 +933,7 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
   const int64_t n = (int64_t)B * CQ * H * W;
   hipLaunchKernelGGL(bn_planes_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, v, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg,
                      (double)B * H * W, dv, B);
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 
@@ -961,8 +968,7 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_BBP
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, C, 0);
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dg, dgamma, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 
@@ -1094,8 +1100,7 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
     case 7: hipLaunchKernelGGL(conv0_bn_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dy, v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, db, dbeta, C, 0);
-  hipLaunchKernelGGL(f64_to_f32_kernel, dim3(1), dim3(64), 0, st, dg, dgamma, C, 0);
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 
