@@ -288,8 +288,10 @@ def main():
     wl = WORKLOADS[args.workload](device, rank)
     if hasattr(wl, "events"):
         wl.events = {}
+    drain = getattr(wl, "drain", lambda: None)  # predict: the host half of the last recording (see PredictWorkload.step)
     for _ in range(args.warmup):
         wl.step(False)
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -297,6 +299,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step(True)
+    drain()  # inside the timed region: every recording's label table is complete when the clock stops
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -89,15 +89,30 @@ class PredictWorkload:
         self.model.kernel_event_labels = set(self.DOMINANT)
 
     def step(self, timed: bool):
-        from orcai_amd.predict import aggregate_predictions_device, compute_binary_predictions, compute_labels
+        """One recording, as predict()'s table mode runs it (orcai_amd/predict.py: _launch_recording / _finish_recording): the GPU half
+        (front end, model, overlap average, copy to pinned host memory) is queued, then the host half of the PREVIOUS recording
+        (threshold, runs, label table: ~1 ms of numpy / pandas) runs beside it.  drain() finishes the last one; bench.py calls it
+        inside the timed region, so K steps = K complete recordings."""
+        from orcai_amd.predict import aggregate_predictions_device
 
         self.model.kernel_events = self.events if timed else None
         spec = self.fe.make_spectrogram(self.pcm, SPEC_PARAM)
         pred = self.model.predict_spectrogram(spec, chunk=self.chunk)
-        agg, cnt = aggregate_predictions_device(pred, self.T, 736, 4)
-        s, e, n = compute_binary_predictions(agg, cnt, CALLS, 0.5)
-        self.last = compute_labels(s, e, n, 16, "*")
+        pending = aggregate_predictions_device(pred, self.T, 736, 4, wait=False)
         self.model.kernel_events = None
+        self.drain()
+        self.in_flight = pending
+
+    in_flight = None
+
+    def drain(self):
+        from orcai_amd.predict import compute_binary_predictions, compute_labels
+
+        if self.in_flight is not None:
+            agg, cnt = self.in_flight.result()
+            self.in_flight = None
+            s, e, n = compute_binary_predictions(agg, cnt, CALLS, 0.5)
+            self.last = compute_labels(s, e, n, 16, "*")
 
     events: dict = {}
 
@@ -147,6 +162,7 @@ class PredictWorkload:
         n_steps = max(1, len(timed_events.get("b1/sep_b", [])) // max(1, -(-self.n_snippets // self.chunk)))
         self.events, self.model.kernel_event_labels = {}, None
         self.step(True)  # all layers bracketed, outside the timed region
+        self.drain()
         torch.cuda.synchronize()
         table = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}
         self.events = timed_events

@@ -83,9 +83,24 @@ def filter_predictions_file(predicted_labels: Path | str, output_file: Path | st
     save_predictions(kept, output_file, delta_t=1, msgr=msgr)
 
 
-def aggregate_predictions_device(predictions: torch.Tensor, n_frames: int, snippet_length: int, n_filters: int):
+class PendingAggregate:
+    """Averaged probabilities of one recording on their way from the GPU to pinned host memory.  `result()` waits for the copy (an
+    event on the launch stream, not a device-wide synchronisation) and returns the two host arrays."""
+
+    def __init__(self, agg_host: torch.Tensor, cnt_host: torch.Tensor, event, keep=()):
+        self._agg, self._cnt, self._event, self._keep = agg_host, cnt_host, event, keep
+
+    def result(self) -> tuple[np.ndarray, np.ndarray]:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event, self._keep = None, ()
+        return self._agg.numpy(), self._cnt.numpy()
+
+
+def aggregate_predictions_device(predictions: torch.Tensor, n_frames: int, snippet_length: int, n_filters: int, wait: bool = True):
     """Overlap-average of per-snippet predictions on the GPU (predict.py:276-293).
-    predictions: f32 cuda [n, P, L].  Returns host (f64 [n_frames // 2**n_filters, L], f64 [...])."""
+    predictions: f32 cuda [n, P, L].  Returns host (f64 [n_frames // 2**n_filters, L], f64 [...]); with wait=False a PendingAggregate
+    whose copy to (pinned) host memory is still in flight, so that the caller can queue the next recording's GPU work first."""
     lib = N.lib()
     tpo = 2**n_filters
     shift = snippet_length // 2
@@ -98,16 +113,25 @@ def aggregate_predictions_device(predictions: torch.Tensor, n_frames: int, snipp
         pred = predictions.contiguous()
         N.check(lib.orcai_overlap_average(pred.data_ptr() if n > 0 else agg.data_ptr(), n, P, L, shift // tpo, S, N.ptr(agg), N.ptr(cnt), N.stream_ptr()),
                 "orcai_overlap_average")
-    return agg.cpu().numpy(), cnt.cpu().numpy()
+    if wait:
+        return agg.cpu().numpy(), cnt.cpu().numpy()
+    agg_host = torch.empty((S, L), dtype=torch.float64, pin_memory=True)
+    cnt_host = torch.empty((S,), dtype=torch.float64, pin_memory=True)
+    agg_host.copy_(agg, non_blocking=True)
+    cnt_host.copy_(cnt, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return PendingAggregate(agg_host, cnt_host, event, keep=(agg, cnt, predictions))
 
 
 def compute_aggregated_predictions(recording_path: Path, spectrogram, model, orcai_parameter: dict, shape: dict,
-                                   msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None) -> tuple[np.ndarray, np.ndarray]:
+                                   msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None, wait: bool = True):
     """Slice into 50 %-overlapping snippets, predict, overlap-average (predict.py:235-295).
 
     ``model`` may be any object with ``.predict(ndarray[n,L,F,1], verbose=int) -> ndarray[n,P,labels]`` (the
     reference's duck-typed boundary).  A native ResNetLSTM is run without materialising the snippets; a
-    ``spectrogram`` that already lives on the GPU (torch tensor) is used in place.
+    ``spectrogram`` that already lives on the GPU (torch tensor) is used in place.  wait=False returns a PendingAggregate (the
+    device-to-host copy of the averaged probabilities still in flight) instead of the two host arrays.
     """
     snippet_length = shape["input_shape"][0]
     shift = snippet_length // 2
@@ -136,7 +160,7 @@ def compute_aggregated_predictions(recording_path: Path, spectrogram, model, orc
         progressbar.refresh()
     if predictions.shape[0] == 0:
         predictions = predictions.reshape(0, snippet_length // 2**n_filters, shape["num_labels"])
-    return aggregate_predictions_device(predictions, n_frames, snippet_length, n_filters)
+    return aggregate_predictions_device(predictions, n_frames, snippet_length, n_filters, wait=wait)
 
 
 def compute_binary_predictions(aggregated_predictions: np.ndarray, overlap_count: np.ndarray, calls: list[str], threshold: float = 0.5):
@@ -173,14 +197,17 @@ def _convert_times_to_seconds(predicted_labels: pd.DataFrame, delta_t: float) ->
     return predicted_labels
 
 
-def predict_wav(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, label_suffix: str = "*",
-                msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None):
-    """(predicted_labels DataFrame, aggregated_predictions ndarray, delta_t) for one wav file (predict.py:367-471)."""
+def predict_wav_launch(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, msgr: Messenger = Messenger(verbosity=0),
+                       progressbar: tqdm = None) -> dict:
+    """First half of predict_wav: spectrogram, snippets through the model and the overlap average are QUEUED on the GPU, the averaged
+    probabilities are on their way to pinned host memory.  The returned state goes to predict_wav_finish; in table mode the next
+    recording is launched in between, so the host half of one recording runs beside the GPU half of the next."""
     recording_path = Path(recording_path)
     if progressbar:
         progressbar.set_description(f"{recording_path.stem}: Generating spectrogram")
         progressbar.refresh()
-    if hasattr(model, "predict_spectrogram"):
+    native = hasattr(model, "predict_spectrogram")
+    if native:
         spectrogram, _, times = make_spectrogram_device(recording_path, channel, orcai_parameter, msgr)
     else:
         spectrogram, _, times = make_spectrogram(recording_path, channel, orcai_parameter, msgr=msgr)
@@ -191,8 +218,15 @@ def predict_wav(recording_path: Path | str, channel: int, model, orcai_parameter
     if progressbar:
         progressbar.set_description(f"{recording_path.stem} - Predicting annotations")
         progressbar.refresh()
-    aggregated_predictions, overlap_count = compute_aggregated_predictions(recording_path=recording_path, spectrogram=spectrogram, model=model,
-                                                                           orcai_parameter=orcai_parameter, shape=shape, msgr=msgr, progressbar=progressbar)
+    pending = compute_aggregated_predictions(recording_path=recording_path, spectrogram=spectrogram, model=model, orcai_parameter=orcai_parameter, shape=shape,
+                                             msgr=msgr, progressbar=progressbar, wait=not native)
+    return {"pending": pending, "delta_t": delta_t, "orcai_parameter": orcai_parameter}
+
+
+def predict_wav_finish(state: dict, label_suffix: str = "*", msgr: Messenger = Messenger(verbosity=0)):
+    """Second half of predict_wav (host): threshold, runs of ones, label table (predict.py:298-340)."""
+    pending, orcai_parameter = state["pending"], state["orcai_parameter"]
+    aggregated_predictions, overlap_count = pending.result() if isinstance(pending, PendingAggregate) else pending
     row_starts, row_stops, label_names = compute_binary_predictions(aggregated_predictions=aggregated_predictions, overlap_count=overlap_count,
                                                                     calls=orcai_parameter["calls"], threshold=0.5)
     msgr.info("converting binary predictions into start and stop frames")
@@ -200,7 +234,14 @@ def predict_wav(recording_path: Path | str, channel: int, model, orcai_parameter
     predicted_labels = compute_labels(row_starts, row_stops, label_names, time_steps_per_output_step=time_steps_per_output_step, label_suffix=label_suffix)
     msgr.info(f"found {len(predicted_labels)} acoustic signals")
     msgr.success("Prediction finished.")
-    return predicted_labels, aggregated_predictions, delta_t
+    return predicted_labels, aggregated_predictions, state["delta_t"]
+
+
+def predict_wav(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, label_suffix: str = "*",
+                msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None):
+    """(predicted_labels DataFrame, aggregated_predictions ndarray, delta_t) for one wav file (predict.py:367-471)."""
+    state = predict_wav_launch(recording_path, channel, model, orcai_parameter, shape, msgr=msgr, progressbar=progressbar)
+    return predict_wav_finish(state, label_suffix=label_suffix, msgr=msgr)
 
 
 def save_predictions(predicted_labels: pd.DataFrame, output_path: Path | str, delta_t: float, msgr: Messenger = Messenger(verbosity=0)) -> None:
@@ -220,10 +261,9 @@ def save_prediction_probabilities(aggregated_predictions: np.ndarray, orcai_para
     msgr.info(f"Prediction probabilities saved to {predictions_path}")
 
 
-def _predict_and_save(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, output_path: Path | str = "default",
-                      overwrite: bool = False, save_probabilities: bool = False, call_duration_limits: (Path | str) | dict = None,
-                      label_suffix: str = "*", msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None) -> None:
-    """predict.py:534-632."""
+def _launch_recording(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, output_path: Path | str = "default",
+                      overwrite: bool = False, msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None) -> dict:
+    """predict.py:534-575: output path and overwrite check, then the GPU half of the recording (queued, not waited for)."""
     recording_path = Path(recording_path)
     if output_path is not None:
         if output_path == "default":
@@ -237,13 +277,31 @@ def _predict_and_save(recording_path: Path | str, channel: int, model, orcai_par
                 msgr.warning(f"Output file {output_path} already exists. Overwriting.")
             else:
                 raise FileExistsError(f"Annotation file already exists: {output_path}")
-    predicted_labels, aggregated_predictions, delta_t = predict_wav(recording_path=recording_path, channel=channel, model=model, orcai_parameter=orcai_parameter,
-                                                                    shape=shape, label_suffix=label_suffix, msgr=msgr, progressbar=progressbar)
+    state = predict_wav_launch(recording_path=recording_path, channel=channel, model=model, orcai_parameter=orcai_parameter, shape=shape, msgr=msgr,
+                               progressbar=progressbar)
+    state["output_path"] = output_path
+    return state
+
+
+def _finish_recording(state: dict, save_probabilities: bool = False, call_duration_limits: (Path | str) | dict = None, label_suffix: str = "*",
+                      msgr: Messenger = Messenger(verbosity=0)) -> None:
+    """predict.py:576-632: the host half -- labels, optional duration filter, files."""
+    predicted_labels, aggregated_predictions, delta_t = predict_wav_finish(state, label_suffix=label_suffix, msgr=msgr)
+    output_path, orcai_parameter = state["output_path"], state["orcai_parameter"]
     if call_duration_limits is not None:
         predicted_labels = filter_predictions(predicted_labels, delta_t=delta_t, call_duration_limits=call_duration_limits, label_suffix=label_suffix, msgr=msgr)
     save_predictions(predicted_labels=predicted_labels, output_path=output_path, delta_t=delta_t, msgr=msgr)
     if save_probabilities:
         save_prediction_probabilities(aggregated_predictions=aggregated_predictions, orcai_parameter=orcai_parameter, delta_t=delta_t, output_path=output_path, msgr=msgr)
+
+
+def _predict_and_save(recording_path: Path | str, channel: int, model, orcai_parameter: dict, shape: dict, output_path: Path | str = "default",
+                      overwrite: bool = False, save_probabilities: bool = False, call_duration_limits: (Path | str) | dict = None,
+                      label_suffix: str = "*", msgr: Messenger = Messenger(verbosity=0), progressbar: tqdm = None) -> None:
+    """predict.py:534-632."""
+    state = _launch_recording(recording_path, channel, model, orcai_parameter, shape, output_path=output_path, overwrite=overwrite, msgr=msgr,
+                              progressbar=progressbar)
+    _finish_recording(state, save_probabilities=save_probabilities, call_duration_limits=call_duration_limits, label_suffix=label_suffix, msgr=msgr)
 
 
 def predict(recording_path: str | Path, channel: int = 1, model_dir: str | Path = DEFAULT_MODEL_DIR, output_path: str | Path = "default",
@@ -284,13 +342,29 @@ def predict(recording_path: str | Path, channel: int = 1, model_dir: str | Path 
     # decode the next recordings on background threads while the GPU works on the current one (the GPU needs ~60 ms per hour of audio)
     wavio.set_prefetcher(wavio.WavPrefetcher([Path(recording_table.loc[i, "base_dir_recording"]).joinpath(recording_table.loc[i, "rel_recording_path"])
                                               for i in recording_table.index]))
-    for i in progressbar:
+    # one recording deep: the GPU half of recording i is queued before the host half of recording i - 1 (threshold, label table, files) runs
+    quiet = Messenger(verbosity=0)
+    in_flight = None  # (table index, state)
+
+    def finish(entry):
+        j, state = entry
         try:
-            _predict_and_save(recording_path=Path(recording_table.loc[i, "base_dir_recording"]).joinpath(recording_table.loc[i, "rel_recording_path"]),
-                              channel=recording_table.loc[i, "channel"], model=model, orcai_parameter=orcai_parameter, shape=shape,
-                              output_path=recording_table.loc[i, "output_path"], overwrite=overwrite, save_probabilities=save_probabilities,
-                              call_duration_limits=call_duration_limits, label_suffix=label_suffix, msgr=Messenger(verbosity=0), progressbar=progressbar)
+            _finish_recording(state, save_probabilities=save_probabilities, call_duration_limits=call_duration_limits, label_suffix=label_suffix, msgr=quiet)
         except Exception as e:  # predict.py:752-755: log and continue with the next recording
+            msgr.error(f"Error predicting {recording_table.loc[j, 'recording']}: {e.args[0] if e.args else e}")
+
+    for i in progressbar:
+        launched = None
+        try:
+            launched = (i, _launch_recording(recording_path=Path(recording_table.loc[i, "base_dir_recording"]).joinpath(recording_table.loc[i, "rel_recording_path"]),
+                                             channel=recording_table.loc[i, "channel"], model=model, orcai_parameter=orcai_parameter, shape=shape,
+                                             output_path=recording_table.loc[i, "output_path"], overwrite=overwrite, msgr=quiet, progressbar=progressbar))
+        except Exception as e:  # predict.py:752-755
             msgr.error(f"Error predicting {recording_table.loc[i, 'recording']}: {e.args[0] if e.args else e}")
+        if in_flight is not None:
+            finish(in_flight)
+        in_flight = launched
+    if in_flight is not None:
+        finish(in_flight)
     wavio.set_prefetcher(None)
     msgr.success("Predictions finished.")

@@ -128,7 +128,9 @@ def test_predict_table_mode_and_cli(tmp_path):
     rec.mkdir()
     for name in ("a", "b"):
         write_wav_pcm16(rec / f"{name}.wav", synth_recording(9.0, 48000, seed=ord(name)), 48000)
-    table = pd.DataFrame({"recording": ["a", "b", "missing"], "base_dir_recording": [str(rec)] * 3, "rel_recording_path": ["a.wav", "b.wav", "nope.wav"], "channel": [1, 1, 1]})
+    # a failing recording BETWEEN two good ones: table mode keeps one recording in flight on the GPU while the previous one's labels are
+    # written, and an error in either half must neither lose nor mix up its neighbours
+    table = pd.DataFrame({"recording": ["a", "missing", "b"], "base_dir_recording": [str(rec)] * 3, "rel_recording_path": ["a.wav", "nope.wav", "b.wav"], "channel": [1, 1, 1]})
     table.to_csv(tmp_path / "table.csv", index=False)
     outdir = tmp_path / "out"
     outdir.mkdir()
@@ -138,6 +140,13 @@ def test_predict_table_mode_and_cli(tmp_path):
     assert not (outdir / "missing_model_predicted.txt").exists()  # per-recording errors are logged, not raised
     first = (outdir / "a_model_predicted.txt").read_text().splitlines()[0]
     assert first == "start\tstop\tlabel"
+    # the pipelined table run writes, per recording, exactly the file the one-recording path writes
+    from orcai_amd.predict import predict
+
+    for name in ("a", "b"):
+        single = tmp_path / f"single_{name}.txt"
+        predict(rec / f"{name}.wav", model_dir=model_dir, output_path=single, verbosity=0)
+        assert single.read_text() == (outdir / f"{name}_model_predicted.txt").read_text(), name
     res = CliRunner().invoke(cli, ["predict", str(tmp_path / "model" / "model_shape.json")])
     assert res.exit_code != 0  # "Recording file must be a wav or csv file"
 

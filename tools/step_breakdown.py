@@ -8,6 +8,7 @@ from orcai_amd.predict import aggregate_predictions_device, compute_binary_predi
 
 w = PredictWorkload(torch.device("cuda", 0), 0)
 for _ in range(3): w.step(False)
+w.drain()
 torch.cuda.synchronize()
 acc = {}
 def tick(name, t0):
