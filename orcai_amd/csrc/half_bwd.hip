@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void planes_sums_h_kernel(const h16* __restric
   const int co = blockIdx.y;
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
-  for (int b = 0; b < B; ++b) {
+  for (int b = B - 1; b >= 0; --b) {  // last snippet first: the tail of what the preceding kernel wrote may still be in the Infinity Cache
     const int64_t base = ((int64_t)b * CO + co) * plane;
     for (int p = p0; p < (int)plane; p += pstep) {
       const O8 v = ld8(x, base + p);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_planes_bwd_sums_h_kernel(const h16* __
   }
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
-  for (int b = 0; b < B; ++b) {
+  for (int b = B - 1; b >= 0; --b) {  // last snippet first: the tail of what the preceding kernel wrote may still be in the Infinity Cache
     const int64_t base = ((int64_t)b * CO + co) * plane;
     for (int p = p0; p < (int)plane; p += pstep) {
       const O8 d = ld8(dy, base + p), vv = ld8(v, base + p);

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void planes_sums_kernel(const float* __restric
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   // snippet-outer / pixel-inner: no 64-bit division per element (it cost more than the rest of the loop body)
   const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
-  for (int b = 0; b < B; ++b) {
+  // last snippet first: the pass follows the kernel that wrote x in ascending snippet order, and whatever of x is still in the
+  // Infinity Cache is its tail
+  for (int b = B - 1; b >= 0; --b) {
     const float4* xp = reinterpret_cast<const float4*>(x) + ((int64_t)b * CQ + cq) * plane;
     for (int p = p0; p < (int)plane; p += pstep) {
       const float4 v = xp[p];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_planes_bwd_sums_kernel(const float* __
   }
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
   const int p0 = blockIdx.x * 256 + threadIdx.x, pstep = gridDim.x * 256;
-  for (int b = 0; b < B; ++b) {  // snippet-outer / pixel-inner: no 64-bit division per element
+  for (int b = B - 1; b >= 0; --b) {  // snippet-outer / pixel-inner: no 64-bit division per element
     const int64_t base = ((int64_t)b * CQ + cq) * plane;
     const float4* dp = reinterpret_cast<const float4*>(dy) + base;
     const float4* vp = reinterpret_cast<const float4*>(v) + base;
