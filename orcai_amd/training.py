@@ -382,6 +382,8 @@ class TrunkTrainer:
         # ResNet1DConv drops out the output of every residual block (architectures.py:97); ResNetLSTM has no Dropout in the trunk
         self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
         self.block_masks = None  # list of 0/1 plane tensors (one per block) for the current step, or None
+        self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
+        self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
     # ------------------------------------------------------------- helpers
@@ -599,15 +601,21 @@ class TrunkTrainer:
         # d loss / d bias = sum_pixels dv, and dv is the gradient through a BatchNormalization of batch statistics: that sum is
         # identically zero (the bias shifts the batch mean, which BN subtracts), so the gradient buffer keeps its zero.
         # u = dw(relu?(x)) was stored by the forward pass.
-        N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
-                                         self.partials.numel(), st), "outer_reduce")
         if not have_du:  # du = Wpw dv   (pointwise conv with the transposed weights)
             wt = self._w_pwT(name + "/pointwise", Cin, Cout)
             self._sep(dv, Cout, H, W, 1, 0, self._w_ones_dw(Cout), wt, self._zeros(64), Cin, du)
+        if self.dgrad_first:
+            # the input gradient (the only kernel of this layer the next layer waits for) first; the two weight-gradient passes are
+            # read-only, and a read-only pass runs faster behind a kernel that wrote ANOTHER tensor (dr) than directly behind the writer
+            # of its own input (dv, du) -- DESIGN.md 4.4
+            self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
+        N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                         self.partials.numel(), st), "outer_reduce")
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
         N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
-        # dr = depthwise conv of du with the flipped taps (identity pointwise)
-        self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
+        if not self.dgrad_first:
+            # dr = depthwise conv of du with the flipped taps (identity pointwise)
+            self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
 
     def backward(self, dfeatv: torch.Tensor) -> None:
         """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
@@ -627,15 +635,20 @@ class TrunkTrainer:
                 N.check(lib.orcai_mask_scale(dprev.data_ptr(), self.block_masks[i - 1].data_ptr(), 1.0 / (1.0 - self.block_rate), dprev.numel(), dprev.data_ptr(), st),
                         "mask_scale")
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
-            # residual 1x1 stride-2 conv: weight / bias gradients
-            N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
-                                             self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
-            N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
+            def residual_wgrad():  # residual 1x1 stride-2 conv: weight / bias gradients (read-only passes over prev and dout)
+                N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
+                                                 self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
+                N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
+
+            if not self.dgrad_first:
+                residual_wgrad()
             # max-pool branch
             dyb = b[f"dyb{i}"]
             bmean, bvar = self.stats[f"b{i}/bn_b"]  # the pooling backward also accumulates bn_b's backward reductions (sum dy, sum dy*xhat)
             N.check(self._fn("pool_bwd_bn")(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
                                             bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
+            if self.dgrad_first:  # behind the kernel that wrote dyb, not behind the one that wrote dout (see _sep_backward)
+                residual_wgrad()
             dya = b[f"dya{i}"]
             self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1)
             dr = b[f"dr{i}"]
