@@ -293,6 +293,17 @@ int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ks
  * orcai_bn_planes_stats -- 32 accumulator copies for its small-plane pass --, f64[8*ceil(C/4)] for the other entry points),
  * y = [relu](v*s + t) at interior pixels, backward (dbeta, dgamma, dv) with the optional ReLU folded in. */
 int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize, double* scratch, float* mean, float* var, void* stream);
+
+/* Training forward of a k = 3 separable convolution with the BatchNorm batch statistics of its output reduced in the kernel's epilogue
+ * (train.py:155-219 runs keras' SeparableConv2D -> BatchNormalization(training=True)): = orcai_sepconv_planes_u(ksize_planes = ktap = 3,
+ * relu_out = 0, out_layout = 0) followed by the sums of orcai_bn_planes_stats, without the read pass over `out`.
+ *   shards   f64[32][ceil(Cout/4)][8] accumulator copies (zeroed here); orcai_bn_finish_sharded turns them into mean / biased variance
+ * Only the wide two-tile shapes of the strip-tile kernel (Cout in 17..32, <= 32 input channels, planes at least two 62-column strips
+ * wide): ORCAI_E_UNSUPPORTED otherwise, and the caller runs the two calls above.  Per-workgroup partial sums are f32 (512 pixels),
+ * accumulated in f64. */
+int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
+                               int Cout, float* out, float* u_out, double* shards, void* stream);
+int orcai_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);
 int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,

@@ -696,13 +696,16 @@ __global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* _
 using orcai_lds::glds16;
 using orcai_lds::wait_vm_barrier;
 
-template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT>
+template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, bool STATS = false>
 __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                             float* __restrict__ out, int nstrip, float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/) {
+                                                             float* __restrict__ out, int nstrip, float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
+                                                             double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/4)][8] sums / sums of squares of the output*/) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   static_assert(TR == 4 || TR == 8, "rows (= waves) per workgroup");
+  static_assert(!STATS || (!XP && MT == 2), "statistics epilogue: plane output, two output tiles");
+  __shared__ float stat_s[STATS ? TR : 1][4][16];  // STATS: per wave and 16-lane row, the row's 8 sums and 8 sums of squares
   static_assert(!(XP && UOUT), "the training forward writes planes");
   __shared__ __attribute__((aligned(16))) float rows_s[2][TR + 2][256];  // [slot][tile row][lane][4]
   __shared__ float pw_s[CQ * 4 * 16 * MT];                               // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
@@ -746,6 +749,7 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
   }
+  if (STATS && threadIdx.x < TR * 64) (&stat_s[0][0][0])[threadIdx.x] = 0.0f;  // waves past the last image row leave before the epilogue
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int row = r0 + wave;  // this wave's image row
@@ -788,6 +792,11 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
   }
   // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> tile column 16*tt + lj]
   if (row >= H) return;
+  float st[STATS ? 16 : 1];  // STATS: [sum | sum of squares][m][r] over this lane's stored pixels
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) st[j] = 0.0f;
+  }
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) {
     const int wl = 16 * tt + lj;
@@ -805,12 +814,44 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
           const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
           v[r] = max2(v[r], pair_ok ? other : v[r]);
         }
+        if (STATS) {
+          const float lv = live ? v[r] : 0.0f;
+          st[(MT == 2 ? m : 0) * 4 + r] += lv;
+          st[8 + (MT == 2 ? m : 0) * 4 + r] = fmaf(lv, lv, st[8 + (MT == 2 ? m : 0) * 4 + r]);
+        }
       }
       const int oq = m * 4 + lk;
       if (live && oq < CQo) {
         const int idx = XP ? ((oq * H + row) * WPx + (x >> 1)) : (oq * plane + (R + row) * WP + x);
         outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+  }
+  if (STATS) {
+    // BatchNorm batch statistics of the tensor just written (the training forward's separate read pass over it): the 16 lanes of a row
+    // hold the same 4 channel quads' values for 16 pixels -> inclusive DPP row scan (lane 15 of the row ends with the row's total),
+    // rows of the 8 waves through LDS, one f64 atomic per value and workgroup into one of 32 accumulator copies
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float a = st[j];
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x118 /*row_shr:8*/, 0xf, 0xf, true));
+      st[j] = a;
+    }
+    if (lj == 15) {
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(&stat_s[wave][lk][j]) = make_float4(st[j], st[j + 1], st[j + 2], st[j + 3]);
+    }
+    __syncthreads();  // among the waves that have an image row (the others are gone; their slots hold zeros)
+    if (wave == 0) {
+      const int g = lane >> 4, j = lane & 15;  // channel quad (j >> 2 & 1) * 4 + g, element (j >> 3) * 4 + (j & 3) of its 8 doubles
+      float tot = 0.0f;
+#pragma unroll
+      for (int w2 = 0; w2 < TR; ++w2) tot += stat_s[w2][g][j];
+      const int cq = ((j >> 2) & 1) * 4 + g;
+      if (cq < CQo) atomicAdd(&shards[(((bx + b * 7) & 31) * CQo + cq) * 8 + (j >> 3) * 4 + (j & 3)], (double)tot);
     }
   }
 }
@@ -1521,6 +1562,7 @@ struct SepArgs {
   float* out;
   int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
   float* u_out = nullptr;
+  double* shards = nullptr;  // strip tiles with the depthwise-output store: BatchNorm statistics of the output in the epilogue
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
@@ -1538,6 +1580,15 @@ int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
                      a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
   if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
+  } else if (a.u_out && a.shards) {
+    if constexpr (MT == 2) {
+      if (a.relu_in)
+        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, true, TR, true, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                           a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards);
+      else
+        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, false, TR, true, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                           a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards);
+    }
   } else if (a.u_out) {
     if (a.relu_in) ORCAI_TILE_LAUNCH(false, true, true); else ORCAI_TILE_LAUNCH(false, false, true);
   } else {
@@ -1706,6 +1757,23 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
 int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, int relu_in, const float* dw, const float* pw, const float* scale,
                      const float* shift, int Cout, int relu_out, int out_layout, float* out, void* stream) {
   return orcai_sepconv_planes(in, B, Cin, H, W, ksize, ksize, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, 0, 0, out, stream);
+}
+
+int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
+                               int Cout, float* out, float* u_out, double* shards, void* stream) {
+  if (!in || !dw || !pw || !scale || !shift || !out || !u_out || !shards || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
+  if (((uintptr_t)in & 15) || B > 65535) return ORCAI_E_UNSUPPORTED;
+  // the shapes launch_sepconv_impl<3, 2> hands to the strip tiles (orcai-V1 block 1); everything else: ORCAI_E_UNSUPPORTED, and the caller
+  // runs orcai_sepconv_planes_u + orcai_bn_planes_stats
+  const int CQ = (Cin + 3) / 4, CQo = (Cout + 3) / 4, WP = orcai_padded_width(W, 3), nstrip = (W + 61) / 62;
+  if (g_tile_mode != 1 || Cout <= 16 || Cout > 32 || CQ > 8 || nstrip < 2 || W * 100 < nstrip * 62 * 85 || (int64_t)CQo * (H + 2) * WP >= (1ll << 27) ||
+      (int64_t)CQ * (H + 2) * WP >= (1ll << 27))
+    return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(shards, 0, sizeof(double) * 8 * CQo * 32, st);
+  if (e != hipSuccess) return (int)e;
+  SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, u_out, shards};
+  return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
 }
 
 int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,

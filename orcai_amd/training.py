@@ -383,6 +383,7 @@ class TrunkTrainer:
         self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
         self.block_masks = None  # list of 0/1 plane tensors (one per block) for the current step, or None
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
+        self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
@@ -433,11 +434,24 @@ class TrunkTrainer:
                                                 shift.data_ptr(), Cout, 0, layout, H2, W2, out.data_ptr(), None if u_out is None else u_out.data_ptr(),
                                                 N.stream_ptr()), "orcai_sepconv_planes_u")
 
-    def _bn_fwd(self, v, bn, C, H, W, relu, y):
+    def _sep_stats(self, x, Cin, H, W, relu_in, dw, pw, shift, Cout, out, u_out) -> bool:
+        """Training forward of a k = 3 separable conv with the batch statistics of its output reduced in the kernel's epilogue (sums into
+        self.scratch); False when the shape is not one of the strip-tile kernel's: the caller then runs the two separate launches."""
+        rc = self.lib.orcai_sepconv_planes_stats(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
+                                                 out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
+        if rc == N.E_UNSUPPORTED:
+            return False
+        N.check(rc, "orcai_sepconv_planes_stats")
+        return True
+
+    def _bn_fwd(self, v, bn, C, H, W, relu, y, sums_in_shards=False):
         """Batch statistics of v; y = [relu](BN(v)) is materialised unless y is None (the consumer applies BN on the fly)."""
         lib, P, st = self.lib, self.P, N.stream_ptr()
         mean, var = P.B(bn + "/mean"), P.B(bn + "/var")  # this step's batch statistics live in the flat buffer the EMA update reads
-        N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
+        if sums_in_shards:  # the producing kernel left the sums in self.scratch (orcai_sepconv_planes_stats)
+            N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), self.B, C, H, W, mean.data_ptr(), var.data_ptr(), st), "bn_finish_sharded")
+        else:
+            N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
         self.stats[bn] = (mean, var)
         if y is None:
             return
@@ -554,9 +568,12 @@ class TrunkTrainer:
             for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], None, 0)):
                 name = f"b{i}/sep_{tag}"
                 self.dwl[name] = self._w_dw(name)
-                self._sep(x, cin, h, w, k, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
                 # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
-                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None)
+                fused = self.stats_in_epilogue and not self.half and k == 3 and self._sep_stats(x, cin, h, w, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"),
+                                                                                                P.W(name + "/bias"), f, v, b[f"u_{tag}{i}"])
+                if not fused:
+                    self._sep(x, cin, h, w, k, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
+                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None, sums_in_shards=fused)
             # the residual branch reads the block input BEFORE the previous block's Dropout (architectures.py:88-97)
             bmean, bvar = self.stats[f"b{i}/bn_b"]
             N.check(self._fn("pool_res_add_bn")(b[f"vb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, self._w_pw(f"b{i}/res/kernel").data_ptr(),

@@ -252,6 +252,51 @@ def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in
         assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W,relu_in", [(16, 30, 21, 171, 1), (30, 30, 9, 171, 0), (20, 17, 8, 120, 0), (13, 32, 1, 230, 1), (16, 30, 16, 60, 1), (40, 30, 8, 171, 0)])
+def test_sepconv_with_statistics_in_the_epilogue(Cin, Cout, H, W, relu_in):
+    """orcai_sepconv_planes_stats + orcai_bn_finish_sharded (training forward of a separable conv with the BatchNorm batch statistics of
+    its output reduced in the kernel's epilogue) against orcai_sepconv_planes_u + orcai_bn_planes_stats: both output tensors bit for
+    bit, mean / variance to f32-partial-sum accuracy (and against float64 sums of the output itself); shapes outside the strip-tile
+    kernel's return ORCAI_E_UNSUPPORTED and touch nothing."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(Cin * 100 + Cout + W)
+    B, CQ, CQo, WP = 3, (Cin + 3) // 4, (Cout + 3) // 4, lib.orcai_padded_width(W, 3)
+    x = torch.zeros(B, CQ * 4, H + 2, WP)
+    x[:, :Cin, 1:H + 1, :W] = torch.randn(B, Cin, H, W, generator=g) + 0.5
+    planes = x.view(B, CQ, 4, H + 2, WP).permute(0, 1, 3, 4, 2).contiguous().to(dev)
+    dw = torch.randn(CQ, 9, 4, generator=g).to(dev)
+    pw = (torch.randn(Cin, Cout, generator=g) / Cin ** 0.5).to(dev)
+    scale, shift = torch.ones(Cout).to(dev), (3.0 * torch.randn(Cout, generator=g)).to(dev)  # large biases: mean^2 >> variance for some channels
+    st = N.stream_ptr()
+    out_ref, u_ref = torch.zeros((B, CQo, H + 2, WP, 4), device=dev), torch.zeros((B, CQ, H + 2, WP, 4), device=dev)
+    scratch = torch.zeros(8 * 16 * 32, dtype=torch.float64, device=dev)
+    mean_ref, var_ref = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    assert lib.orcai_sepconv_planes_u(N.ptr(planes), B, Cin, H, W, 3, 3, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, 0, 0, 0, 0, N.ptr(out_ref),
+                                      N.ptr(u_ref), st) == 0
+    assert lib.orcai_bn_planes_stats(N.ptr(out_ref), B, Cout, H, W, 3, N.ptr(scratch), N.ptr(mean_ref), N.ptr(var_ref), st) == 0
+    out, u = torch.zeros_like(out_ref), torch.zeros_like(u_ref)
+    shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device=dev)  # the launcher zeroes what it uses
+    rc = lib.orcai_sepconv_planes_stats(N.ptr(planes), B, Cin, H, W, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, N.ptr(out), N.ptr(u), N.ptr(shards), st)
+    supported = 16 < Cout <= 32 and Cin <= 32 and W >= 106
+    if not supported:
+        torch.cuda.synchronize()
+        assert rc == N.E_UNSUPPORTED and float(out.abs().max()) == 0 and float(shards.min()) == 7.0
+        return
+    assert rc == 0
+    mean, var = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    assert lib.orcai_bn_finish_sharded(N.ptr(shards), B, Cout, H, W, N.ptr(mean), N.ptr(var), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref) and torch.equal(u, u_ref)
+    v64 = out.double().permute(0, 1, 4, 2, 3).reshape(B, CQo * 4, H + 2, WP)[:, :Cout, 1:H + 1, :W]
+    m64, s64 = v64.mean(dim=(0, 2, 3)), v64.var(dim=(0, 2, 3), unbiased=False)
+    for got_m, got_v in ((mean, var), (mean_ref, var_ref)):
+        assert float((got_m[:Cout].double() - m64).abs().max()) <= 2e-6 * float(m64.abs().max())
+        assert float(((got_v[:Cout].double() - s64).abs() / (s64 + 1e-3 * m64 * m64)).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("shape,filters", [((736, 171, 1), (30, 40, 50, 60)), ((33, 70, 1), (17, 20)), ((16, 64, 1), (64, 12)), ((50, 9, 1), (8, 8))])
 def test_fused_entry_convolution_is_bit_identical(shape, filters):
     """orcai_conv0_sepconv (entry convolution computed inside block 1's first separable convolution, compact (2i, 2j) subsample for

@@ -46,6 +46,8 @@ def _run(cfg, B, seed, rate=0.5):
         (dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=64, num_labels=3), 3),
         (dict(input_shape=(48, 21, 1), filters=(12, 30, 40), kernel_size=3, lstm_units=64, num_labels=7), 2),
         (dict(input_shape=(32, 16, 1), filters=(10, 20), kernel_size=5, lstm_units=64, num_labels=2), 2),
+        # a first block wide enough for the strip-tile kernels (BatchNorm statistics reduced in the separable convs' epilogue)
+        (dict(input_shape=(16, 120, 1), filters=(20, 24), kernel_size=3, lstm_units=64, num_labels=3), 2),
     ],
 )
 def test_full_step_gradients_vs_autograd(cfg, B):
