@@ -304,6 +304,11 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
 int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
                                int Cout, float* out, float* u_out, double* shards, void* stream);
 int orcai_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);
+/* The f16 twins (octet planes; shards f64[32][ceil(Cout/8)][16]; flat-tile kernel, any plane width and channel count it handles; the sums are
+ * taken on the f32 values before their rounding to f16). */
+int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
+                          void* out, void* u_out, double* shards, void* stream);
+int orcai_h_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);
 int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
                           float eps, int relu, float* y, void* stream);
 int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,

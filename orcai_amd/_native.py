@@ -74,6 +74,8 @@ _SIGNATURES = {
     "orcai_sepconv_planes_u": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
+    "orcai_h_sepconv_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
+    "orcai_h_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "orcai_bn_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4),
     "orcai_bn_planes_apply": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_bn_planes_bwd": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int] + [C.c_void_p] * 5),

@@ -792,6 +792,12 @@ int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize
   return (int)hipGetLastError();
 }
 
+int orcai_h_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream) {
+  if (!shards || !mean || !var || B <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(bn_finish_stats_sharded_h_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, shards, C, (C + 7) / 8, (double)B * H * W, mean, var);
+  return (int)hipGetLastError();
+}
+
 int orcai_h_planes_sum(const void* x, int B, int C, int H, int W, int ksize, double* scratchC, float* out, int accumulate, void* stream) {
   if (!x || !scratchC || !out || B <= 0 || C <= 0 || C > 64) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;

@@ -462,15 +462,18 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const float* __restrict__ A
 // two slots, and every wave reads its three rows back with ds_read_b128.  One raw barrier per octet; counted vmcnt waits leave the
 // depthwise-output store of the training forward in flight.  Same arithmetic in the same order as sepconv_h_kernel.
 // =========================================================================================
-template <int MT, bool XP, bool UOUT>
+template <int MT, bool XP, bool UOUT, bool STATS = false>
 __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restrict__ in /*[B][CO][HP][WP][8]*/, int Cin, int H, int W, int WP, int relu_in,
                                                               const h16* __restrict__ dw /*[CO][9][8]*/, const h16* __restrict__ pwf /*[KG][MT][64][8]*/,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
-                                                              void* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk, h16* __restrict__ u_out) {
+                                                              void* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk, h16* __restrict__ u_out,
+                                                              double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/8)][16]*/) {
   using orcai_lds::glds16;
   using orcai_lds::wait_vm_barrier;
   constexpr int NWV = 8, KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   static_assert(!(XP && UOUT), "the training forward writes planes");
+  static_assert(!STATS || !XP, "statistics epilogue: plane output");
+  __shared__ float stat_s[STATS ? NWV : 1][4][STATS ? 8 * MT : 1];  // STATS: per wave and 16-lane row, the row's sums and sums of squares
   extern __shared__ __attribute__((aligned(16))) h16x8 smem_hf[];
   const int CO = (Cin + 7) >> 3, COo = (Cout + 7) >> 3, KG = (CO + 3) >> 2;
   h16x8* rows_s = smem_hf;                    // [2][nchunk * 64] pixels
@@ -499,6 +502,9 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
   };
   issue(0);
   for (int i = threadIdx.x; i < KG * MT * 64; i += 64 * NWV) pw_s[i] = reinterpret_cast<const h16x8*>(pwf)[i];
+  if (STATS) {  // waves without a window leave before the epilogue: their slots must read as zero
+    for (int i = threadIdx.x; i < NWV * 4 * 8 * MT; i += 64 * NWV) (&stat_s[0][0][0])[i] = 0.0f;
+  }
   __syncthreads();
 
   const int task = bx * NWV + wave;
@@ -560,12 +566,24 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
       sh_r[m][r] = co < Cout ? shift[co] : 0.0f;
     }
   const int Wx = (W + 1) >> 1, WPx = (Wx + 3) & ~3;
+  float st[STATS ? 8 * MT : 1];  // STATS: [sum | sum of squares][m][r] over this lane's stored pixels (f32 values, before the f16 rounding)
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 8 * MT; ++j) st[j] = 0.0f;
+  }
 #pragma unroll
   for (int tp = 0; tp < 4; tp += 2) {
     const int wl = 16 * (tp + (lk & 1)) + lj, flat = qbase + wl;
     const int row = (int)__umulhi((uint32_t)flat, magic_WP);
     const int x = flat - row * WP;
     const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H;
+    bool live0 = false, live1 = false;  // STATS: the pixels of column tiles tp and tp + 1 this lane holds BEFORE the octet exchange
+    if (STATS) {
+      const int w0 = 16 * tp + lj, w1 = w0 + 16, g0 = qbase + w0, g1 = qbase + w1;
+      const int y0 = (int)__umulhi((uint32_t)g0, magic_WP), y1 = (int)__umulhi((uint32_t)g1, magic_WP);
+      live0 = w0 >= lo && w0 < 64 - lo && (g0 - y0 * WP) < W && y0 < R + H;
+      live1 = w1 >= lo && w1 < 64 - lo && (g1 - y1 * WP) < W && y1 < R + H;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       float a[4], bq[4];
@@ -574,6 +592,11 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
         a[r] = fmaf(acc[m][tp][r], sc_r[m][r], sh_r[m][r]);
         bq[r] = fmaf(acc[m][tp + 1][r], sc_r[m][r], sh_r[m][r]);
         if (relu_out) { a[r] = fmaxf(a[r], 0.0f); bq[r] = fmaxf(bq[r], 0.0f); }
+        if (STATS) {
+          const float l0 = live0 ? a[r] : 0.0f, l1 = live1 ? bq[r] : 0.0f;
+          st[m * 4 + r] += l0 + l1;
+          st[4 * MT + m * 4 + r] = fmaf(l1, l1, fmaf(l0, l0, st[4 * MT + m * 4 + r]));
+        }
         if (XP) {
           const int f0 = qbase + 16 * tp + lj, f1 = f0 + 16;
           const int r0 = (int)__umulhi((uint32_t)f0, magic_WP), r1 = (int)__umulhi((uint32_t)f1, magic_WP);
@@ -591,6 +614,35 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
       else if ((x & 1) == 0) reinterpret_cast<h16x8*>(out)[(((int64_t)b * COo + oq) * H + (row - R)) * WPx + (x >> 1)] = val;
     }
   }
+  if (STATS) {
+    // BatchNorm batch statistics of the tensor just written (the f32 path's scheme, model_fwd.hip sepconv_tile_kernel): inclusive DPP scan
+    // over the 16 lanes of a row, rows of the 8 waves through LDS, one f64 atomic per value and workgroup into one of 32 accumulator copies
+#pragma unroll
+    for (int j = 0; j < 8 * MT; ++j) {
+      float a = st[j];
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x118 /*row_shr:8*/, 0xf, 0xf, true));
+      st[j] = a;
+    }
+    if (lj == 15) {
+#pragma unroll
+      for (int j = 0; j < 8 * MT; ++j) stat_s[wave][lk][j] = st[j];
+    }
+    __syncthreads();  // among the waves that have a window (the others are gone; their slots hold zeros)
+    if (wave == 0) {
+      const int g = lane >> 4;
+      for (int j = lane & 15; j < 8 * MT; j += 16) {  // j = [sum | sum of squares] * 4 MT + m * 4 + r -> channel m * 16 + g * 4 + r
+        float tot = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < NWV; ++w2) tot += stat_s[w2][g][j];
+        const int isq = j / (4 * MT), m = (j / 4) % MT, r = j & 3;
+        const int octet = m * 2 + (g >> 1);
+        if (octet < COo) atomicAdd(&shards[((((bx + b * 7) & 31) * COo) + octet) * 16 + isq * 8 + (g & 1) * 4 + r], (double)tot);
+      }
+    }
+  }
 }
 
 struct SepArgsH {
@@ -599,6 +651,7 @@ struct SepArgsH {
   void* out;
   int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
   h16* u_out;
+  double* shards = nullptr;  // flat tiles with the depthwise-output store: BatchNorm statistics of the output in the epilogue
 };
 
 template <int KS, int MT>
@@ -618,12 +671,17 @@ int launch_sepconv_h(hipStream_t st, const SepArgsH& a) {
   hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, XP, UOUT>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
       if (a.out_layout == 2) ORCAI_HFTILE(true, false);
+      else if (a.u_out && a.shards) {
+        hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, false, true, true>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, a.shift,
+                           a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
+      }
       else if (a.u_out) ORCAI_HFTILE(false, true);
       else ORCAI_HFTILE(false, false);
 #undef ORCAI_HFTILE
       return (int)hipGetLastError();
     }
   }
+  if (a.shards) return ORCAI_E_UNSUPPORTED;  // the statistics epilogue exists in the flat-tile kernel only
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_h_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, a.shift, a.Cout, a.relu_out,
                      a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);
@@ -677,6 +735,23 @@ int orcai_h_sepconv(const void* in, int B, int Cin, int H, int W, int ksize_plan
     case 7: return launch_sepconv_h_mt<7>(st, a);
     default: return ORCAI_E_UNSUPPORTED;
   }
+}
+
+int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
+                          void* out, void* u_out, double* shards, void* stream) {
+  if (!in || !dw || !pwf || !scale || !shift || !out || !u_out || !shards || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
+  if (Cout > 64 || Cin > 64 || (((uintptr_t)in | (uintptr_t)dw | (uintptr_t)pwf | (uintptr_t)out | (uintptr_t)u_out) & 15) || B > 65535) return ORCAI_E_UNSUPPORTED;
+  // the launcher's own conditions for the flat-tile kernel, checked BEFORE anything is touched
+  const int WP = orcai_padded_width(W, 3), nchunk = (7 * 62 + 64 + 2 * WP + 63) / 64, KG = ((Cin + 7) / 8 + 3) / 4, MTv = (Cout + 15) / 16;
+  const size_t lds = ((size_t)2 * nchunk * 64 + (size_t)KG * MTv * 64) * 16;
+  if (orcai_sepconv_tile_mode(-1) == 0 || nchunk > 24 || lds + 4096 > 64 * 1024 /*+ the kernel's static statistics slots*/ || (int64_t)((Cout + 7) / 8) * (H + 2) * WP >= (1ll << 27) ||
+      (int64_t)(H + 2) * WP >= (1ll << 29))
+    return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(shards, 0, sizeof(double) * 16 * ((Cout + 7) / 8) * 32, st);
+  if (e != hipSuccess) return (int)e;
+  SepArgsH a{(const h16*)in, (const h16*)dw, (const h16*)pwf, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, (h16*)u_out, shards};
+  return launch_sepconv_h_mt<3>(st, a);
 }
 
 int orcai_h_pool_res_add(const void* s, const void* prev, int B, int C, int Cp, int H, int W, int ksize, const void* wrf, const float* br, void* out, int xpooled,

@@ -437,7 +437,7 @@ class TrunkTrainer:
     def _sep_stats(self, x, Cin, H, W, relu_in, dw, pw, shift, Cout, out, u_out) -> bool:
         """Training forward of a k = 3 separable conv with the batch statistics of its output reduced in the kernel's epilogue (sums into
         self.scratch); False when the shape is not one of the strip-tile kernel's: the caller then runs the two separate launches."""
-        rc = self.lib.orcai_sepconv_planes_stats(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
+        rc = (self.lib.orcai_h_sepconv_stats if self.half else self.lib.orcai_sepconv_planes_stats)(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
                                                  out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
             return False
@@ -449,7 +449,7 @@ class TrunkTrainer:
         lib, P, st = self.lib, self.P, N.stream_ptr()
         mean, var = P.B(bn + "/mean"), P.B(bn + "/var")  # this step's batch statistics live in the flat buffer the EMA update reads
         if sums_in_shards:  # the producing kernel left the sums in self.scratch (orcai_sepconv_planes_stats)
-            N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), self.B, C, H, W, mean.data_ptr(), var.data_ptr(), st), "bn_finish_sharded")
+            N.check((lib.orcai_h_bn_finish_sharded if self.half else lib.orcai_bn_finish_sharded)(self.scratch.data_ptr(), self.B, C, H, W, mean.data_ptr(), var.data_ptr(), st), "bn_finish_sharded")
         else:
             N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
         self.stats[bn] = (mean, var)
@@ -569,7 +569,7 @@ class TrunkTrainer:
                 name = f"b{i}/sep_{tag}"
                 self.dwl[name] = self._w_dw(name)
                 # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
-                fused = self.stats_in_epilogue and not self.half and k == 3 and self._sep_stats(x, cin, h, w, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"),
+                fused = self.stats_in_epilogue and k == 3 and self._sep_stats(x, cin, h, w, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"),
                                                                                                 P.W(name + "/bias"), f, v, b[f"u_{tag}{i}"])
                 if not fused:
                     self._sep(x, cin, h, w, k, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])

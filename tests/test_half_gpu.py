@@ -72,6 +72,50 @@ def test_sepconv_h_layouts_exact_integers(Cin, Cout, k, H, W, tile_mode):
         lib.orcai_sepconv_tile_mode(prev_mode)
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W", [(16, 30, 21, 171), (30, 30, 9, 86), (10, 10, 8, 171), (20, 20, 5, 43), (24, 17, 1, 300), (30, 40, 8, 86), (50, 60, 6, 22), (40, 50, 70, 600)])
+def test_sepconv_h_with_statistics_in_the_epilogue(Cin, Cout, H, W):
+    """orcai_h_sepconv_stats + orcai_h_bn_finish_sharded (training forward with the BatchNorm batch statistics of the output reduced in the
+    flat-tile kernel's epilogue) on small integers (exact in f16 and in the f32 partial sums): both output tensors equal to
+    orcai_h_sepconv's bit for bit, mean / variance equal to numpy's on the integer reference; a plane too wide for the flat-tile kernel's
+    LDS: ORCAI_E_UNSUPPORTED with nothing touched."""
+    from orcai_amd import _native as N
+    from orcai_amd.half import pack_depthwise_octets, pack_pointwise_fragments
+
+    lib, k, B = N.lib(), 3, 3
+    rng = np.random.default_rng(Cin * 100 + Cout + W)
+    x = rng.integers(-2, 3, size=(B, Cin, H, W))
+    dwk = rng.integers(-1, 2, size=(k, k, Cin))
+    pw = rng.integers(-1, 3, size=(Cin, Cout)) * (rng.random((Cin, Cout)) < (0.5 if Cin <= 40 else 0.25))
+    WP, CO, COo = (W + 1 + 3) & ~3, (Cin + 7) // 8, (Cout + 7) // 8
+    ones, zeros = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    xin = torch.from_numpy(to_octet_planes(x.astype(np.float16), k)).cuda()
+    dwd = torch.from_numpy(pack_depthwise_octets(dwk[..., None].astype(np.float32))).cuda()
+    pwd = torch.from_numpy(pack_pointwise_fragments(pw.astype(np.float32))).cuda()
+    st = N.stream_ptr()
+    for relu_in in (0, 1):
+        want, _ = _sepconv_int_ref(x, dwk, pw, relu_in)
+        assert np.abs(want).max() < 2048
+        out_ref = torch.zeros((B, COo, H + 2, WP, 8), dtype=torch.float16, device="cuda")
+        u_ref = torch.zeros((B, CO, H + 2, WP, 8), dtype=torch.float16, device="cuda")
+        N.check(lib.orcai_h_sepconv(N.ptr(xin), B, Cin, H, W, k, k, relu_in, N.ptr(dwd), N.ptr(pwd), N.ptr(ones), N.ptr(zeros), Cout, 0, 0, 0, 0, N.ptr(out_ref),
+                                    N.ptr(u_ref), st), "h_sepconv")
+        out, u = torch.zeros_like(out_ref), torch.zeros_like(u_ref)
+        shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device="cuda")
+        rc = lib.orcai_h_sepconv_stats(N.ptr(xin), B, Cin, H, W, relu_in, N.ptr(dwd), N.ptr(pwd), N.ptr(ones), N.ptr(zeros), Cout, N.ptr(out), N.ptr(u), N.ptr(shards), st)
+        if W >= 600:
+            torch.cuda.synchronize()
+            assert rc == N.E_UNSUPPORTED and float(out.float().abs().max()) == 0 and float(shards.min()) == 7.0
+            continue
+        assert rc == 0
+        mean, var = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+        N.check(lib.orcai_h_bn_finish_sharded(N.ptr(shards), B, Cout, H, W, N.ptr(mean), N.ptr(var), st), "h_bn_finish_sharded")
+        torch.cuda.synchronize()
+        assert torch.equal(out, out_ref) and torch.equal(u, u_ref)
+        m64, v64 = want.mean(axis=(0, 2, 3)), want.var(axis=(0, 2, 3))
+        assert np.abs(mean[:Cout].cpu().numpy() - m64).max() <= 1e-6 * max(1.0, np.abs(m64).max())
+        assert (np.abs(var[:Cout].cpu().numpy() - v64) / (v64 + 1e-3)).max() <= 1e-5
+
+
 def _sepconv_h_exact(lib, N, pack_depthwise_octets, pack_pointwise_fragments, Cin, Cout, k, H, W):
     rng = np.random.default_rng(Cin * 100 + Cout)
     B = 2
