@@ -298,9 +298,9 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
  * (train.py:155-219 runs keras' SeparableConv2D -> BatchNormalization(training=True)): = orcai_sepconv_planes_u(ksize_planes = ktap = 3,
  * relu_out = 0, out_layout = 0) followed by the sums of orcai_bn_planes_stats, without the read pass over `out`.
  *   shards   f64[32][ceil(Cout/4)][8] accumulator copies (zeroed here); orcai_bn_finish_sharded turns them into mean / biased variance
- * Only the wide two-tile shapes of the strip-tile kernel (Cout in 17..32, <= 32 input channels, planes at least two 62-column strips
- * wide): ORCAI_E_UNSUPPORTED otherwise, and the caller runs the two calls above.  Per-workgroup partial sums are f32 (512 pixels),
- * accumulated in f64. */
+ * Only the shapes the LDS-tile kernels take (every plane up to ~500 pixels wide with orcai_sepconv_tile_mode != 0): ORCAI_E_UNSUPPORTED
+ * otherwise, with nothing touched, and the caller runs the two calls above.  Per-workgroup partial sums are f32 (512 pixels), accumulated
+ * in f64. */
 int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
                                int Cout, float* out, float* u_out, double* shards, void* stream);
 int orcai_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);

@@ -29,6 +29,7 @@
 #include <mutex>
 
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -604,7 +605,7 @@ size_t orcai_frontend_workspace_bytes(void) {
 
 int orcai_frontend_reset(void* workspace, void* stream) {
   if (!workspace) return ORCAI_E_BADARG;
-  return (int)hipMemsetAsync(workspace, 0, sizeof(Workspace), (hipStream_t)stream);
+  return (int)orcai_zero::zero_async(workspace, sizeof(Workspace), (hipStream_t)stream);
 }
 
 int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop, float* out_db, void* workspace,
@@ -667,7 +668,7 @@ int orcai_quantile_select(const float* x, int64_t n, int64_t rank_lo, int64_t ra
   if ((uintptr_t)x & 15) return ORCAI_E_BADARG;
   int grid = grid_for(0, (n / 4 + 255) / 256);
   for (int round = 0; round < 2; ++round) {  // a level-1 bucket is at most 2^31 keys wide: two 16-bit rounds
-    hipError_t e = hipMemsetAsync(ws->hist2, 0, sizeof(ws->hist2) + sizeof(ws->hist2c), s);  // hist2c follows hist2
+    hipError_t e = orcai_zero::zero_async(ws->hist2, sizeof(ws->hist2) + sizeof(ws->hist2c), s);  // hist2c follows hist2
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(hist2_kernel, dim3(grid), dim3(256), 0, s, x, n, ws);
     hipLaunchKernelGGL(select_scan2_kernel, dim3(1), dim3(1024), 0, s, ws);

@@ -9,6 +9,7 @@
 
 #include "half_planes.h"
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -777,13 +778,13 @@ int orcai_h_bn_planes_stats(const void* v, int B, int C, int H, int W, int ksize
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   if (plane < 32768) {  // small planes (f16: half the bytes of the f32 case at equal size): sharded accumulators, scratch f64[16 * ceil(C/8) * 32]
     const int nchunk = (int)((plane + 4095) / 4096);
-    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO * SUM_SHARDS, st);
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO * SUM_SHARDS, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(planes_sums_sharded_h_kernel, dim3((unsigned)(B * nchunk), CO), dim3(256), 0, st, (const h16*)v, CO, (int)plane, nchunk, scratch2C);
     hipLaunchKernelGGL(bn_finish_stats_sharded_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, C, CO, (double)B * H * W, mean, var);
     return (int)hipGetLastError();
   }
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;
@@ -804,7 +805,7 @@ int orcai_h_planes_sum(const void* x, int B, int C, int H, int W, int ksize, dou
   const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 8 * CO, st);
+  hipError_t e = orcai_zero::zero_async(scratchC, sizeof(double) * 8 * CO, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;
@@ -834,7 +835,7 @@ int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H,
   double* db = scratch2C;
   double* dg = scratch2C + 8 * CO;
   if (!sums_ready) {
-    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
     if (e != hipSuccess) return (int)e;
     int gx = (int)((B * plane + 255) / 256);
     if (gx > 128) gx = 128;
@@ -870,7 +871,7 @@ int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, 
   if ((int64_t)B * CO > 65535) return ORCAI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (bn_sums) {
-    hipError_t e = hipMemsetAsync(bn_sums, 0, sizeof(double) * 16 * CO, st);
+    hipError_t e = orcai_zero::zero_async(bn_sums, sizeof(double) * 16 * CO, st);
     if (e != hipSuccess) return (int)e;
   }
   const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
@@ -930,7 +931,7 @@ int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy
   const int C = 16, CO = 2, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 16 * CO, st);
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;

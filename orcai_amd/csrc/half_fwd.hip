@@ -11,6 +11,7 @@
 #include "half_planes.h"
 #include "lds_dma.h"
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -748,8 +749,11 @@ int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu
       (int64_t)(H + 2) * WP >= (1ll << 29))
     return ORCAI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(shards, 0, sizeof(double) * 16 * ((Cout + 7) / 8) * 32, st);
-  if (e != hipSuccess) return (int)e;
+  const int nacc = 16 * ((Cout + 7) / 8) * 32;
+  {
+    hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * nacc, st);
+    if (e != hipSuccess) return (int)e;
+  }
   SepArgsH a{(const h16*)in, (const h16*)dw, (const h16*)pwf, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, (h16*)u_out, shards};
   return launch_sepconv_h_mt<3>(st, a);
 }

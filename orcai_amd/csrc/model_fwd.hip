@@ -19,6 +19,7 @@
 
 #include "lds_dma.h"
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -864,14 +865,17 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 // 8 windows of a 176-pixel-wide plane, 8 chunks at width 44, against 24 row loads of independent windows.  Input quads are a run-time
 // count (no dummy quads).  Two LDS slots, one raw barrier per quad, waits as in sepconv_tile.  Bit-identical to sepconv_kernel<3, MT>.
 // =========================================================================================
-template <int MT, bool XP, bool RELU, bool UOUT, int NWV>
+template <int MT, bool XP, bool RELU, bool UOUT, int NWV, bool STATS = false>
 __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                                const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                                const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                                float* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk,
-                                                               float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/) {
+                                                               float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
+                                                               double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/4)][8]*/) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   static_assert(!(XP && UOUT), "the training forward writes planes");
+  static_assert(!STATS || !XP, "statistics epilogue: plane output");
+  __shared__ float stat_s[STATS ? NWV : 1][4][STATS ? 8 * MT : 1];  // STATS: per wave and 16-lane row, the row's sums and sums of squares
   extern __shared__ __attribute__((aligned(16))) float smem_ft[];
   const int CQr = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
   float* rows_s = smem_ft;                      // [2][nchunk][64][4]
@@ -913,6 +917,9 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
     const int co = threadIdx.x;
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  if (STATS) {  // waves without a window leave before the epilogue: their slots must read as zero
+    for (int i = threadIdx.x; i < NWV * 4 * 8 * MT; i += 64 * NWV) (&stat_s[0][0][0])[i] = 0.0f;
   }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
@@ -965,6 +972,11 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
   }
   // ---- epilogue (see sepconv_kernel): D[row = 4*lk + r -> cout][col = lj -> pixel 16*tt + lj of the window]
   if (!wave_live) return;
+  float st[STATS ? 8 * MT : 1];  // STATS: [sum | sum of squares][m][r] over this lane's stored pixels
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 8 * MT; ++j) st[j] = 0.0f;
+  }
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) {
     const int wl = 16 * tt + lj;
@@ -984,11 +996,43 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
           const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
           v[r] = max2(v[r], pair_ok ? other : v[r]);
         }
+        if (STATS) {
+          const float lv = live ? v[r] : 0.0f;
+          st[m * 4 + r] += lv;
+          st[4 * MT + m * 4 + r] = fmaf(lv, lv, st[4 * MT + m * 4 + r]);
+        }
       }
       const int oq = m * 4 + lk;
       if (live && oq < CQo) {
         const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
         outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  if (STATS) {  // BatchNorm batch statistics of the tensor just written: the scheme of sepconv_tile_kernel, for any number of output tiles
+#pragma unroll
+    for (int j = 0; j < 8 * MT; ++j) {
+      float a = st[j];
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+      a += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x118 /*row_shr:8*/, 0xf, 0xf, true));
+      st[j] = a;
+    }
+    if (lj == 15) {
+#pragma unroll
+      for (int j = 0; j < 8 * MT; ++j) stat_s[wave][lk][j] = st[j];
+    }
+    __syncthreads();  // among the waves that have a window (the others are gone; their slots hold zeros)
+    if (wave == 0) {
+      const int g = lane >> 4;
+      for (int j = lane & 15; j < 8 * MT; j += 16) {  // j = [sum | sum of squares] * 4 MT + m * 4 + r -> channel quad m * 4 + g, element r
+        float tot = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < NWV; ++w2) tot += stat_s[w2][g][j];
+        const int isq = j / (4 * MT), m = (j / 4) % MT, r = j & 3;
+        const int cq = m * 4 + g;
+        if (cq < CQo) atomicAdd(&shards[(((bx + b * 7) & 31) * CQo + cq) * 8 + isq * 4 + r], (double)tot);
       }
     }
   }
@@ -1612,6 +1656,14 @@ int launch_sepconv_ftile(hipStream_t st, const SepArgs& a, int tasks) {
                      a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
   if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_FTILE_LAUNCH(true, true, false); else ORCAI_FTILE_LAUNCH(true, false, false);
+  } else if (a.u_out && a.shards) {
+    if (lds + sizeof(float) * NWV * 4 * 8 * MT > 64 * 1024) return -1;  // + the kernel's static statistics slots
+    if (a.relu_in)
+      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, true, true, NWV, true>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                         a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
+    else
+      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, true, NWV, true>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                         a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
   } else if (a.u_out) {
     if (a.relu_in) ORCAI_FTILE_LAUNCH(false, true, true); else ORCAI_FTILE_LAUNCH(false, false, true);
   } else {
@@ -1643,6 +1695,7 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
       if (rc >= 0) return rc;
     }
   }
+  if (a.shards) return ORCAI_E_UNSUPPORTED;  // the statistics epilogue exists in the LDS-tile kernels only
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pw, a.scale, a.shift, a.Cout, a.relu_out,
                      a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);
@@ -1762,18 +1815,23 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
 int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
                                int Cout, float* out, float* u_out, double* shards, void* stream) {
   if (!in || !dw || !pw || !scale || !shift || !out || !u_out || !shards || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
-  if (((uintptr_t)in & 15) || B > 65535) return ORCAI_E_UNSUPPORTED;
-  // the shapes launch_sepconv_impl<3, 2> hands to the strip tiles (orcai-V1 block 1); everything else: ORCAI_E_UNSUPPORTED, and the caller
-  // runs orcai_sepconv_planes_u + orcai_bn_planes_stats
-  const int CQ = (Cin + 3) / 4, CQo = (Cout + 3) / 4, WP = orcai_padded_width(W, 3), nstrip = (W + 61) / 62;
-  if (g_tile_mode != 1 || Cout <= 16 || Cout > 32 || CQ > 8 || nstrip < 2 || W * 100 < nstrip * 62 * 85 || (int64_t)CQo * (H + 2) * WP >= (1ll << 27) ||
-      (int64_t)CQ * (H + 2) * WP >= (1ll << 27))
+  if (((uintptr_t)in & 15) || B > 65535 || Cout > 64) return ORCAI_E_UNSUPPORTED;
+  // the shapes launch_sepconv_impl<3, MT> hands to the LDS-tile kernels, checked BEFORE anything is touched; everything else:
+  // ORCAI_E_UNSUPPORTED, and the caller runs orcai_sepconv_planes_u + orcai_bn_planes_stats
+  const int CQ = (Cin + 3) / 4, CQo = (Cout + 3) / 4, WP = orcai_padded_width(W, 3), MTv = (Cout + 15) / 16;
+  const int nchunk = (7 * 62 + 64 + 2 * WP + 63) / 64;
+  const size_t lds = (size_t)(2 * nchunk * 256 + CQ * 64 * MTv + 2 * MTv * 16 + 8 * 4 * 8 * MTv) * sizeof(float);
+  const int nstrip = (W + 61) / 62;
+  const bool strip = g_tile_mode == 1 && MTv == 2 && CQ <= 8 && nstrip >= 2 && W * 100 >= nstrip * 62 * 85;
+  if (g_tile_mode == 0 || (int64_t)CQo * (H + 2) * WP >= (1ll << 27) || (int64_t)CQ * (H + 2) * WP >= (1ll << 27) || (!strip && (nchunk > 24 || lds > 64 * 1024)))
     return ORCAI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(shards, 0, sizeof(double) * 8 * CQo * 32, st);
-  if (e != hipSuccess) return (int)e;
+  {
+    hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * CQo * 32, st);
+    if (e != hipSuccess) return (int)e;
+  }
   SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, u_out, shards};
-  return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
+  return launch_sepconv<3>(st, a);
 }
 
 int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,

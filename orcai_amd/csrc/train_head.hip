@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -933,7 +934,7 @@ int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B,
     kps = (kps + GBK - 1) / GBK * GBK;
     splits = (K + kps - 1) / kps;
     if (splits > 1 && !accumulate) {
-      hipError_t e = hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, st);
+      hipError_t e = orcai_zero::zero_async(C, sizeof(float) * (size_t)M * N, st);
       if (e != hipSuccess) return (int)e;
     }
     const int va = ((uintptr_t)A % 16 == 0 && lda % 4 == 0) ? 1 : 0, vb = ((uintptr_t)B % 16 == 0 && ldb % 4 == 0) ? 1 : 0;
@@ -1035,7 +1036,7 @@ int orcai_masked_bce_w(const float* p, const float* y, int64_t n, float mask_val
                        void* stream) {
   if (!p || !y || !acc3 || n <= 0 || !(grad_scale > 0.0f)) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc3, 0, 3 * sizeof(double), st);
+  hipError_t e = orcai_zero::zero_async(acc3, 3 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   unsigned g = blocks_for(n);
   if (g > 256) g = 256;

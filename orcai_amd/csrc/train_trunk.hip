@@ -8,6 +8,7 @@
 #include <cstdint>
 
 #include "orcai_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -878,13 +879,13 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
   if (plane < 16384) {  // small planes: the full-occupancy pass with sharded accumulators (scratch: f64[8 * ceil(C/4) * 32])
     const int nchunk = (int)((plane + 4095) / 4096);
-    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ * SUM_SHARDS, st);
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ * SUM_SHARDS, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(planes_sums_sharded_kernel, dim3((unsigned)(B * nchunk), CQ), dim3(256), 0, st, v, CQ, (int)plane, nchunk, scratch2C);
     hipLaunchKernelGGL(bn_finish_stats_sharded_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch2C, C, CQ, (double)B * H * W, mean, var);
     return (int)hipGetLastError();
   }
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
@@ -905,7 +906,7 @@ int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, doub
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratchC, 0, sizeof(double) * 4 * CQ, st);
+  hipError_t e = orcai_zero::zero_async(scratchC, sizeof(double) * 4 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
@@ -931,7 +932,7 @@ int orcai_bn_planes_bwd(const float* dy, const float* v, int B, int C, int H, in
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;  // few blocks per quad: each ends with same-line double atomics
@@ -956,7 +957,7 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
   double* db = scratch2C;
   double* dg = scratch2C + 4 * CQ;
   if (!sums_ready) {  // sums_ready: the producer of dy (orcai_pool_bwd_bn) already accumulated sum dy / sum dy*xhat into scratch
-    hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ, st);
     if (e != hipSuccess) return (int)e;
     int gx = (int)((B * plane + 255) / 256);
     if (gx > 128) gx = 128;
@@ -992,7 +993,7 @@ int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, 
   const int CQ = (C + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   if (bn_sums) {
-    hipError_t e = hipMemsetAsync(bn_sums, 0, sizeof(double) * 8 * CQ, st);
+    hipError_t e = orcai_zero::zero_async(bn_sums, sizeof(double) * 8 * CQ, st);
     if (e != hipSuccess) return (int)e;
   }
   const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
@@ -1093,7 +1094,7 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
   const int C = 16, CQ = 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = hipMemsetAsync(scratch2C, 0, sizeof(double) * 8 * CQ, st);
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ, st);
   if (e != hipSuccess) return (int)e;
   int gx = (int)((B * plane + 255) / 256);
   if (gx > 128) gx = 128;

@@ -437,6 +437,10 @@ class TrunkTrainer:
     def _sep_stats(self, x, Cin, H, W, relu_in, dw, pw, shift, Cout, out, u_out) -> bool:
         """Training forward of a k = 3 separable conv with the batch statistics of its output reduced in the kernel's epilogue (sums into
         self.scratch); False when the shape is not one of the strip-tile kernel's: the caller then runs the two separate launches."""
+        if torch.cuda.is_current_stream_capturing():
+            # replayed from a hipGraph the fused kernels drifted away from the eager step after a few replays (tools/debug_graph_divergence.py;
+            # cause not found), the two-launch path does not: a captured step keeps the separate statistics pass
+            return False
         rc = (self.lib.orcai_h_sepconv_stats if self.half else self.lib.orcai_sepconv_planes_stats)(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
                                                  out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:

@@ -252,12 +252,13 @@ def test_tile_sepconv_training_forward_is_bit_identical(Cin, Cout, H, W, relu_in
         assert float(u[:, :, 0].abs().max()) == 0 and float(u[:, :, -1].abs().max()) == 0 and float(u[:, :, :, W:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W,relu_in", [(16, 30, 21, 171, 1), (30, 30, 9, 171, 0), (20, 17, 8, 120, 0), (13, 32, 1, 230, 1), (16, 30, 16, 60, 1), (40, 30, 8, 171, 0)])
+@pytest.mark.parametrize("Cin,Cout,H,W,relu_in", [(16, 30, 21, 171, 1), (30, 30, 9, 171, 0), (20, 17, 8, 120, 0), (13, 32, 1, 230, 1), (16, 30, 16, 60, 1), (40, 30, 8, 171, 0),
+                                                  (30, 40, 13, 86, 0), (50, 60, 7, 22, 1), (9, 10, 40, 43, 0), (16, 30, 4, 700, 1), (16, 40, 4, 700, 1)])
 def test_sepconv_with_statistics_in_the_epilogue(Cin, Cout, H, W, relu_in):
     """orcai_sepconv_planes_stats + orcai_bn_finish_sharded (training forward of a separable conv with the BatchNorm batch statistics of
     its output reduced in the kernel's epilogue) against orcai_sepconv_planes_u + orcai_bn_planes_stats: both output tensors bit for
-    bit, mean / variance to f32-partial-sum accuracy (and against float64 sums of the output itself); shapes outside the strip-tile
-    kernel's return ORCAI_E_UNSUPPORTED and touch nothing."""
+    bit, mean / variance to f32-partial-sum accuracy (and against float64 sums of the output itself), strip tiles and flat-range tiles,
+    one to four output tiles; a plane too wide for either returns ORCAI_E_UNSUPPORTED and touches nothing."""
     from orcai_amd import _native as N
 
     lib = N.lib()
@@ -280,7 +281,8 @@ def test_sepconv_with_statistics_in_the_epilogue(Cin, Cout, H, W, relu_in):
     out, u = torch.zeros_like(out_ref), torch.zeros_like(u_ref)
     shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device=dev)  # the launcher zeroes what it uses
     rc = lib.orcai_sepconv_planes_stats(N.ptr(planes), B, Cin, H, W, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), Cout, N.ptr(out), N.ptr(u), N.ptr(shards), st)
-    supported = 16 < Cout <= 32 and Cin <= 32 and W >= 106
+    # every plane the LDS-tile kernels take: strip tiles at any width (two output tiles, <= 32 input channels), flat-range tiles up to ~500 columns
+    supported = W < 600 or (16 < Cout <= 32 and Cin <= 32)
     if not supported:
         torch.cuda.synchronize()
         assert rc == N.E_UNSUPPORTED and float(out.abs().max()) == 0 and float(shards.min()) == 7.0

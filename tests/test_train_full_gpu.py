@@ -214,6 +214,10 @@ def test_training_step_replays_as_one_hip_graph():
     runs = {}
     for mode in ("eager", "graph"):
         tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.3, 64, seed=1), learning_rate=3e-3, seed=5)
+        # a captured step keeps the separate BatchNorm statistics pass (TrunkTrainer._sep_stats); the eager trainer is put on the same kernels, so
+        # that the two differ by float-atomic reordering only (the fused statistics differ from the separate pass in the seventh digit, which
+        # 24 steps of a dropout network at this learning rate amplify to 1e-2)
+        tr.trunk.stats_in_epilogue = False
         losses = []
         if mode == "eager":  # the graphed trainer runs two warm-up steps on batch 0 before it captures: mirror them
             for _ in range(2):
