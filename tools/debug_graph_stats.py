@@ -1,3 +1,6 @@
+"""orcai_sepconv_planes_stats + orcai_bn_finish_sharded eager against three replays of the same two calls captured in a hipGraph.  With the
+accumulators cleared by hipMemsetAsync (the first version of the launcher) replays 1 and 2 came back with every odd double of the
+accumulators 1.0 too low; with the kernel fill of csrc/zero_fill.h all replays are bit-identical to the eager launch."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
