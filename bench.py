@@ -251,9 +251,26 @@ def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
     return out
 
 
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`--gpus N` (N > 1) outside a launcher: start N fresh rank processes -- one per GPU, `python -m torch.distributed.run`, rendezvous on
+    127.0.0.1 -- BEFORE anything in this process touches the GPU, pass the children's output through (rank 0 prints the JSON line) and
+    return their exit code.  The driver's own `torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never comes here."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE of the launcher, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="predict" if "predict" in WORKLOADS else "frontend", choices=sorted(WORKLOADS))
@@ -266,9 +283,16 @@ def main():
     ap.add_argument("--curve-steps", type=int, default=200)
     args = ap.parse_args()
 
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: this process touches no GPU, starts N ranks and relays rank 0's line
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
     if args.one_device:
@@ -326,6 +350,8 @@ def main():
             "config": {"workload": wl.name, "units_per_step_per_gpu": round(wl.units_per_step, 3), "parallelism": f"independent recordings x{world}"},
             "roofline": wl.roofline(),
         }
+        if dist:  # the world size the process group itself reports (RCCL when backend is nccl)
+            line["rccl_ranks" if args.backend == "nccl" else "gloo_ranks"] = dist.get_world_size()
         if secondary is not None:
             line["secondary"] = secondary
         if secondary2 is not None:

@@ -104,7 +104,7 @@ class SnippetDataset:
 
 def load_dataset(path: Path | str, batch_size: int, compression: str = "GZIP", seed=None, rank: int = 0, world_size: int = 1) -> SnippetDataset:
     """Same call shape as the reference's load_dataset (io.py:150-184); `compression` is accepted and ignored (raw .npy).
-    A directory written by ``snippets.create_tvt_data`` (a snippet-table descriptor, nothing materialised) gives a
+    A directory holding ``snippet_table_dataset.json`` ({"snippet_table": <csv path>, "n_filters": n}: a descriptor, nothing materialised) gives a
     SnippetTableDataset that gathers its batches on the GPU from the recordings' arrays."""
     desc = Path(path) / "snippet_table_dataset.json"
     if desc.exists():

@@ -103,61 +103,65 @@ def test_table_dataset_equals_materialised_dataset_and_trains(tmp_path):
         SnippetTableDataset(bad, nf, 8)
 
 
-def test_data_preparation_commands_feed_training(tmp_path):
-    """The reference's data-preparation chain on synthetic recordings, through the CLI where it has one: label arrays ->
-    create-snippet-table -> create-tvt-snippet-tables -> create-tvt-data -> orcai train.  create-tvt-data materialises nothing;
-    train reads the descriptors and gathers its batches on the GPU from the recordings' arrays."""
+def test_reference_made_snippet_tables_feed_training(tmp_path):
+    """The training-data path from the reference's own tables to `orcai train`: tests/golden/snippet_tables.json holds the train / val / test
+    tables the reference's create_tvt_snippet_tables wrote for the fixture recordings (make_golden.gen_snippet_tables); the product reads
+    them through a dataset descriptor (nothing is materialised: the reference's create_tvt_data writes ~GBs of TF datasets here) and
+    gathers its batches on the GPU from the recordings' arrays.  Rows gathered == rows the table names, bit for bit."""
+    import importlib.util
     import json
 
     from click.testing import CliRunner
 
     from orcai_amd.cli import cli
     from orcai_amd.datasets import SnippetTableDataset, load_dataset
-    from tools.dataprep.cli import dataprep  # snippet-table tooling lives outside the product package
     from orcai_amd.io import read_json
 
+    golden = __import__("pathlib").Path(__file__).resolve().parent / "golden"
+    spec_ = importlib.util.spec_from_file_location("make_golden", golden / "make_golden.py")
+    G = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(G)  # helpers only; the reference is not touched at import
+    gold = json.loads((golden / "snippet_tables.json").read_text())
+    root = tmp_path / "data"
+    dirs = G.snippet_fixture_inputs(root)  # recA..recD: labels.npy + times.json, as the reference saw them
+    W = 16
     rng = np.random.default_rng(5)
-    calls = ["A", "B", "C"]
-    W, hop_s = 16, 0.05  # 20 frames per second
-    root = tmp_path / "recording_data"
-    for r, seconds in enumerate((130, 90)):
-        T = int(seconds / hop_s)
-        d = root / f"rec{r}"
-        (d / "spectrogram").mkdir(parents=True)
-        (d / "labels").mkdir()
+    for d in dirs:  # the spectrogram arrays the tables index (narrow: the model below takes any width)
+        T = json.loads((d / "spectrogram" / "times.json").read_text())["length"]
         np.save(d / "spectrogram" / "spectrogram.npy", rng.random((T, W), dtype=np.float32))
-        (d / "spectrogram" / "times.json").write_text(json.dumps({"min": 0.0, "max": (T - 1) * hop_s, "length": T}))
-        lab = (rng.random((T, len(calls))) < 0.3).astype(np.int16)
-        if r == 1:
-            lab[:, 2] = -1
-        np.save(d / "labels" / "labels.npy", lab)
-        (d / "labels" / "label_list.json").write_text(json.dumps({c: i for i, c in enumerate(calls)}))
-    table = tmp_path / "recordings.csv"
-    pd.DataFrame({"recording": ["rec0", "rec1", "rec2"], "base_dir_annotation": ["x", "x", "x"]}).to_csv(table, index=False)  # rec2 has no data directory
-    param = read_json(__import__("tools.dataprep.snippets", fromlist=["x"]).DEFAULT_ORCAI_PARAMETER)
+    tvt = tmp_path / "tvt"
+    tvt.mkdir()
+    nf = 4
+    for kind in ("train", "val", "test"):
+        text = gold["files"][f"{kind}.csv.gz"].replace("<ROOT>", str(root))
+        pd.read_csv(__import__("io").StringIO(text)).to_csv(tvt / f"{kind}.csv.gz", index=False)
+        (tvt / f"{kind}_dataset").mkdir()
+        (tvt / f"{kind}_dataset" / "snippet_table_dataset.json").write_text(json.dumps({"snippet_table": f"../{kind}.csv.gz", "n_filters": nf}))
+    calls = gold["param"]["calls"]
+    (tvt / "dataset_shapes.json").write_text(json.dumps({"spectrogram": [736, W, 1], "labels": [46, len(calls)]}))
+    ds = load_dataset(tvt / "train_dataset", 4, seed=[7, 3])
+    assert isinstance(ds, SnippetTableDataset) and len(ds) == gold["param"]["model"]["n_batch_train"]
+    table = pd.read_csv(tvt / "train.csv.gz")
+    plain = SnippetTableDataset(table, nf, 4, shuffle=False)
+    from oracle.train_ref import reshape_labels_ref
+
+    for bi, (x, y) in enumerate(plain):
+        assert tuple(x.shape) == (4, 736, W) and tuple(y.shape) == (4, 46, len(calls))
+        for j in range(4):
+            row = table.iloc[bi * 4 + j]
+            spec = np.load(row["recording_data_dir"] + "/spectrogram/spectrogram.npy", mmap_mode="r")
+            lab = np.load(row["recording_data_dir"] + "/labels/labels.npy", mmap_mode="r")
+            assert np.array_equal(x[j].cpu().numpy(), spec[row["row_start"] : row["row_stop"]])
+            assert np.array_equal(y[j].cpu().numpy(), reshape_labels_ref(np.asarray(lab[row["row_start"] : row["row_stop"]], dtype=np.float32), nf))
+    param = read_json(__import__("importlib.resources", fromlist=["files"]).files("orcai_amd.defaults").joinpath("default_orcai_parameter.json"))
     param.update({"name": "tiny", "seed": 3, "calls": calls})
-    param["model"].update({"filters": [8, 12], "lstm_units": 64, "batch_size": 4, "n_batch_train": 5, "n_batch_val": 2, "n_batch_test": 2, "epochs": 1,
+    param["model"].update({"filters": [8, 12, 12, 12], "lstm_units": 64, "batch_size": 4, "n_batch_train": 6, "n_batch_val": 2, "n_batch_test": 2, "epochs": 1,
                            "call_weights": None})
-    param["snippets"].update({"segment_duration": 40, "snippets_per_sec": 1, "snippet_duration": 1.7, "fraction_removal": 0.5})
     pfile = tmp_path / "param.json"
     pfile.write_text(json.dumps(param))
-    tvt = tmp_path / "tvt"
-    run = CliRunner()
-    for args in (["create-snippet-table", str(table), str(root), "-o", str(tvt), "-p", str(pfile), "-v", "0"],
-                 ["create-tvt-snippet-tables", str(tvt), "-p", str(pfile), "-uts", "-n_uts", "6", "-v", "0"],
-                 ["create-tvt-data", str(tvt), "-p", str(pfile), "-v", "0"]):
-        res = run.invoke(dataprep, args, catch_exceptions=False)
-        assert res.exit_code == 0, (args, res.output)
-    assert read_json(tvt / "dataset_shapes.json") == {"spectrogram": [32, W, 1], "labels": [8, len(calls)]}  # 1.7 s = 34 frames -> 32 (a multiple of 2**2 blocks)
-    assert sorted(p.name for p in tvt.iterdir() if p.is_dir()) == ["test_dataset", "test_unfiltered_dataset", "train_dataset", "val_dataset"]
-    assert sum(f.stat().st_size for f in tvt.rglob("*") if f.is_file()) < 200_000  # tables and descriptors only
-    ds = load_dataset(tvt / "train_dataset", 4, seed=[7, 3])
-    assert isinstance(ds, SnippetTableDataset) and len(ds) == 5
-    x, y = next(iter(ds))
-    assert tuple(x.shape) == (4, 32, W) and tuple(y.shape) == (4, 8, len(calls))
     out = tmp_path / "out"
     out.mkdir()
-    res = run.invoke(cli, ["train", str(tvt), str(out), "-p", str(pfile), "-v", "0"], catch_exceptions=False)
+    res = CliRunner().invoke(cli, ["train", str(tvt), str(out), "-p", str(pfile), "-v", "0"], catch_exceptions=False)
     assert res.exit_code == 0, res.output
     hist = read_json(out / "tiny" / "training_history.json")
     assert len(hist["loss"]) == 1 and np.isfinite(hist["loss"][0]) and np.isfinite(hist["val_MBA"][0])
