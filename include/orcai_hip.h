@@ -369,6 +369,15 @@ int orcai_dropout_mask_dev(float* mask, int64_t n, const uint64_t* counter, uint
 int orcai_adam_step_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
                         void* stream);
 int orcai_counter_advance(uint64_t* counter, void* stream);
+/* A voided step (the f16 path under its static loss scale: Keras' LossScaleOptimizer skips the update when a gradient is not finite).
+ *   orcai_step_ok: ok[0] = 1 if every value of g[0, ng) and stats[0, ns) (this step's BatchNorm batch statistics; ns may be 0) is
+ *   finite, else 0, and skipped[0] += 1; nothing returns to the host, so the decision stays inside a captured graph.
+ *   The *_guarded twins do nothing when ok[0] == 0: weights, Adam moments, moving statistics and the step counter keep their values. */
+int orcai_step_ok(const float* g, int64_t ng, const float* stats, int64_t ns, int32_t* ok, int64_t* skipped, void* stream);
+int orcai_adam_step_guarded(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter,
+                            float gscale, const int32_t* ok, void* stream);
+int orcai_ema_update_guarded(float* moving, const float* batch, int n, float momentum, const int32_t* ok, void* stream);
+int orcai_counter_advance_guarded(uint64_t* counter, const int32_t* ok, void* stream);
 
 /* Keras LSTM variables <-> the gate-column order of the recurrence kernels (orcai_lstm_recurrent), on the device, once per training
  * step (replaces the per-step framework index / cat / stack kernels; architectures.py:210-229 define the variables).

@@ -106,6 +106,10 @@ _SIGNATURES = {
     "orcai_dropout_mask_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
     "orcai_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_counter_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orcai_step_ok": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_adam_step_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "orcai_ema_update_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "orcai_counter_advance_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_pack_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_unpack_lstm_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),

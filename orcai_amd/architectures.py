@@ -77,6 +77,7 @@ class ResNetLSTM:
         if precision not in ("f32", "f16"):
             raise ValueError(f"precision must be 'f32' or 'f16', got {precision!r}")
         self.precision = precision
+        self.graph_step = bool(unused.get("graph_step", True))  # FitLoop: replay the training step as one hipGraph (single GPU)
         self._half_engine = None
         self.weights: dict[str, np.ndarray] = {}
         self._init_weights(np.random.default_rng(seed))
@@ -534,7 +535,7 @@ def res_net_LSTM_arch(input_shape, num_labels, filters, kernel_size, dropout_rat
                       lstm_initializer="glorot_uniform", **unused) -> ResNetLSTM:
     """architectures.py:120-241.  ``precision`` ("f32" | "f16") may ride along in **unused (an extra key of orcai_parameter["model"])."""
     return ResNetLSTM(input_shape, num_labels, filters, kernel_size, dropout_rate, lstm_units, conv_initializer, lstm_initializer,
-                      precision=unused.get("precision", "f32"), seed=unused.get("seed"))
+                      precision=unused.get("precision", "f32"), seed=unused.get("seed"), graph_step=unused.get("graph_step", True))
 
 
 class ResNet1DConv(ResNetLSTM):

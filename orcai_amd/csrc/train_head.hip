@@ -400,8 +400,10 @@ __global__ __launch_bounds__(256) void dropout_mask_dev_kernel(float* __restrict
 
 // Adam with the step number and the learning rate read from device memory (step = counter[0] + 1): alpha is formed once per block.
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        const float* __restrict__ lr, float b1, float b2, float eps, const uint64_t* __restrict__ counter, float gscale) {
+                                                        const float* __restrict__ lr, float b1, float b2, float eps, const uint64_t* __restrict__ counter, float gscale,
+                                                        const int32_t* __restrict__ ok = nullptr) {
   __shared__ float alpha_s;
+  if (ok && !ok[0]) return;  // a voided step (f16 overflow): weights, moments untouched
   if (threadIdx.x == 0) {
     const double t = (double)(counter[0] + 1);
     alpha_s = (float)((double)lr[0] * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
@@ -417,8 +419,24 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ w, co
   w[i] = w[i] - alpha_s * mi / (sqrtf(vi) + eps);
 }
 
-__global__ void counter_advance_kernel(uint64_t* counter) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1;
+__global__ void counter_advance_kernel(uint64_t* counter, const int32_t* ok = nullptr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(ok && !ok[0])) counter[0] += 1;
+}
+
+// ok[0] &= every value of a[0, n) is finite (ok is set to 1 by the launcher's first kernel); skipped[0] += !ok by the finishing kernel
+__global__ void flag_set_kernel(int32_t* ok) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) ok[0] = 1;
+}
+__global__ __launch_bounds__(256) void all_finite_kernel(const float* __restrict__ a, int64_t n, int32_t* __restrict__ ok) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t bits = __float_as_uint(a[i]);
+    bad |= (bits & 0x7f800000u) == 0x7f800000u;  // Inf or NaN
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(ok, 0);
+}
+__global__ void count_skipped_kernel(const int32_t* ok, int64_t* skipped) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !ok[0]) skipped[0] += 1;
 }
 
 // sum of squares (L2 penalty value): out += lambda * sum w^2
@@ -905,8 +923,9 @@ __global__ __launch_bounds__(256) void unpack_lstm_grad_kernel(const float* __re
 }
 
 // moving = moving * momentum + batch * (1 - momentum) over one flat buffer of all BatchNorm statistics
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ moving, const float* __restrict__ batch, int n, float momentum) {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ moving, const float* __restrict__ batch, int n, float momentum, const int32_t* __restrict__ ok = nullptr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (ok && !ok[0]) return;
   if (i < n) moving[i] = moving[i] * momentum + batch[i] * (1.0f - momentum);
 }
 
@@ -1022,13 +1041,13 @@ int orcai_dropout_mask_dev(float* mask, int64_t n, const uint64_t* counter, uint
 int orcai_adam_step_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
                         void* stream) {
   if (!w || !g || !m || !v || !lr || !counter || n <= 0) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr, b1, b2, eps, counter, gscale);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr, b1, b2, eps, counter, gscale, (const int32_t*)nullptr);
   return (int)hipGetLastError();
 }
 
 int orcai_counter_advance(uint64_t* counter, void* stream) {
   if (!counter) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
+  hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, (const int32_t*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1136,7 +1155,37 @@ int orcai_unpack_lstm_grad(const float* src, int ld_src, int col_off, int rows, 
 
 int orcai_ema_update(float* moving, const float* batch, int n, float momentum, void* stream) {
   if (!moving || !batch || n <= 0) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, moving, batch, n, momentum);
+  hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, moving, batch, n, momentum, (const int32_t*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int orcai_step_ok(const float* g, int64_t ng, const float* stats, int64_t ns, int32_t* ok, int64_t* skipped, void* stream) {
+  if (!g || !ok || !skipped || ng <= 0 || ns < 0 || (ns > 0 && !stats)) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, st, ok);
+  unsigned blocks = blocks_for(ng);
+  hipLaunchKernelGGL(all_finite_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, st, g, ng, ok);
+  if (ns > 0) hipLaunchKernelGGL(all_finite_kernel, dim3(blocks_for(ns) > 1024 ? 1024 : blocks_for(ns)), dim3(256), 0, st, stats, ns, ok);
+  hipLaunchKernelGGL(count_skipped_kernel, dim3(1), dim3(64), 0, st, ok, skipped);
+  return (int)hipGetLastError();
+}
+
+int orcai_adam_step_guarded(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
+                            const int32_t* ok, void* stream) {
+  if (!w || !g || !m || !v || !lr || !counter || !ok || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr, b1, b2, eps, counter, gscale, ok);
+  return (int)hipGetLastError();
+}
+
+int orcai_ema_update_guarded(float* moving, const float* batch, int n, float momentum, const int32_t* ok, void* stream) {
+  if (!moving || !batch || !ok || n <= 0) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, moving, batch, n, momentum, ok);
+  return (int)hipGetLastError();
+}
+
+int orcai_counter_advance_guarded(uint64_t* counter, const int32_t* ok, void* stream) {
+  if (!counter || !ok) return ORCAI_E_BADARG;
+  hipLaunchKernelGGL(counter_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, ok);
   return (int)hipGetLastError();
 }
 

@@ -114,8 +114,16 @@ def _epoch_logs(acc: np.ndarray, prefix: str = "") -> dict:
 
 
 class FitLoop:
-    def __init__(self, model, trainer: Trainer):
+    def __init__(self, model, trainer: Trainer, graph_step: bool | None = None):
         self.model, self.trainer, self.stop_training = model, trainer, False
+        # One GPU, ResNetLSTM, no class weights: the whole step is captured once as a hipGraph and replayed (Trainer.train_step_graphed) --
+        # what Keras' compiled train function is to the reference (train.py:201-219); the step then no longer depends on the host's launch
+        # rate.  orcai_parameter["model"]["graph_step"] = false or ORCAI_GRAPH_STEP=0 keeps eager launches.
+        if graph_step is None:
+            import os
+
+            graph_step = bool(getattr(model, "graph_step", True)) and os.environ.get("ORCAI_GRAPH_STEP", "1") != "0"
+        self.graph_step = bool(graph_step) and getattr(model, "architecture", "") == "ResNetLSTM"
 
     def evaluate(self, dataset) -> dict:
         """Inference-mode pass (moving BN statistics, no dropout): mean masked BCE + L2 and masked binary accuracy."""
@@ -150,16 +158,27 @@ class FitLoop:
                 cw[int(k)] = float(v)
         for cb in callbacks:
             cb.on_train_begin(self)
+        skipped_before = int(self.trainer.skipped.item()) if self.trainer.half else 0
         for epoch in range(epochs):
             tot = torch.zeros(4, dtype=torch.float64, device=self.trainer.dev)
             for xb, yb in train_dataset:
                 # Keras: sample weight of (snippet, step) = class_weight[argmax over the label axis of y_true]; a loss that returns a
                 # scalar (MaskedBinaryCrossentropy does) is multiplied by the batch mean of those weights
                 lw = None if cw is None else cw[yb.argmax(dim=-1)].mean().reshape(1)
-                out = self.trainer.train_step(xb.contiguous().view(-1), H * W, xb.shape[0], yb, world_size=world, loss_weight=lw)
+                if self.graph_step and world == 1 and lw is None:
+                    out = self.trainer.train_step_graphed(xb.contiguous().view(-1), H * W, xb.shape[0], yb)  # outputs valid until the next replay
+                else:
+                    out = self.trainer.train_step(xb.contiguous().view(-1), H * W, xb.shape[0], yb, world_size=world, loss_weight=lw)
                 tot[:3] += out["acc"][:3]
                 tot[3] = out["acc"][3]
             logs = _epoch_logs(tot.cpu().numpy())
+            if self.trainer.half:  # f16 path: steps the device voided because a gradient / batch statistic was not finite (static loss scale)
+                skipped = int(self.trainer.skipped.item())
+                logs["skipped_steps"] = skipped - skipped_before
+                if logs["skipped_steps"] * 2 > max(1, len(train_dataset)):
+                    raise RuntimeError(f"f16 training: {logs['skipped_steps']} of {len(train_dataset)} steps of epoch {epoch + 1} overflowed under the static loss scale; "
+                                       "train this model with precision 'f32'")
+                skipped_before = skipped
             if validation_data is not None:
                 logs.update({"val_" + k: v for k, v in self.evaluate(validation_data).items()})
             for cb in callbacks:

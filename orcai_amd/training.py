@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
     # ------------------------------------------------------------- helpers
@@ -437,10 +438,8 @@ class TrunkTrainer:
     def _sep_stats(self, x, Cin, H, W, relu_in, dw, pw, shift, Cout, out, u_out) -> bool:
         """Training forward of a k = 3 separable conv with the batch statistics of its output reduced in the kernel's epilogue (sums into
         self.scratch); False when the shape is not one of the strip-tile kernel's: the caller then runs the two separate launches."""
-        if torch.cuda.is_current_stream_capturing():
-            # replayed from a hipGraph the fused kernels drifted away from the eager step after a few replays (tools/debug_graph_divergence.py;
-            # cause not found), the two-launch path does not: a captured step keeps the separate statistics pass
-            return False
+        if not self.fused_stats_under_capture and torch.cuda.is_current_stream_capturing():
+            return False  # A/B switch of tools/debug_graph_divergence.py
         rc = (self.lib.orcai_h_sepconv_stats if self.half else self.lib.orcai_sepconv_planes_stats)(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
                                                  out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
@@ -711,7 +710,8 @@ class Trainer:
         self.trunk = TrunkTrainer(model, self.P, half=self.half)
         self.conv1d = getattr(model, "architecture", "") == "ResNet1DConv"
         self.head = Conv1DHeadTrainer(model, self.P) if self.conv1d else HeadTrainer(model, self.P, half=self.half, grad_scale=self.grad_scale)
-        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.dev)  # f16 path: steps whose gradients overflowed (zeroed, counted)
+        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.dev)  # f16 path: steps voided by a non-finite gradient / batch statistic
+        self.ok_dev = torch.ones(1, dtype=torch.int32, device=self.dev)  # this step's verdict (orcai_step_ok), read by the guarded update kernels
         # Step state the kernels read from DEVICE memory (so that a captured hipGraph of the step stays valid from replay to replay):
         # the number of applied steps (dropout seeds, Adam's bias correction) and the learning rate (callbacks change it between steps)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -798,21 +798,29 @@ class Trainer:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 self.P.g.copy_(g)
         self.step_count += 1
-        if self.half:  # a non-finite value anywhere (f16 overflow under the static loss scale) voids the step's gradients
-            ok = torch.isfinite(self.P.g).all()
-            self.P.g.copy_(torch.where(ok, self.P.g, torch.zeros_like(self.P.g)))
-            self.skipped += (~ok).to(torch.int64)
-        P, st = self.P, N.stream_ptr()
-        N.check(N.lib().orcai_adam_step_dev(P.w.data_ptr(), P.g.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.n_trainable, self.lr_dev.data_ptr(), 0.9, 0.999, 1e-7,
-                                            self.counter.data_ptr(), 1.0 / (world_size * self.grad_scale), st), "adam_step_dev")
+        P, st, lib = self.P, N.stream_ptr(), N.lib()
+        if self.half:
+            # f16 under a static loss scale: a non-finite gradient or batch statistic voids the WHOLE step on the device -- no Adam update
+            # (not even the momentum term), no moving-statistics update, no step-counter advance -- and is counted (Keras' LossScaleOptimizer
+            # skips such a step the same way).  The host mirror of the counter is re-read from the device where it matters (state_dict).
+            N.check(lib.orcai_step_ok(P.g.data_ptr(), P.n_trainable, P.batch_flat.data_ptr(), P.batch_flat.numel(), self.ok_dev.data_ptr(), self.skipped.data_ptr(), st), "step_ok")
+            N.check(lib.orcai_adam_step_guarded(P.w.data_ptr(), P.g.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.n_trainable, self.lr_dev.data_ptr(), 0.9, 0.999, 1e-7,
+                                                self.counter.data_ptr(), 1.0 / (world_size * self.grad_scale), self.ok_dev.data_ptr(), st), "adam_step_guarded")
+            N.check(lib.orcai_ema_update_guarded(P.stats_flat.data_ptr(), P.batch_flat.data_ptr(), P.stats_flat.numel(), BN_MOMENTUM, self.ok_dev.data_ptr(), st), "ema_update_guarded")
+            N.check(lib.orcai_counter_advance_guarded(self.counter.data_ptr(), self.ok_dev.data_ptr(), st), "counter_advance_guarded")
+            return
+        N.check(lib.orcai_adam_step_dev(P.w.data_ptr(), P.g.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.n_trainable, self.lr_dev.data_ptr(), 0.9, 0.999, 1e-7,
+                                        self.counter.data_ptr(), 1.0 / (world_size * self.grad_scale), st), "adam_step_dev")
         self.P.ema_all(BN_MOMENTUM)  # every BatchNorm's moving statistics in one launch
-        N.check(N.lib().orcai_counter_advance(self.counter.data_ptr(), st), "counter_advance")
+        N.check(lib.orcai_counter_advance(self.counter.data_ptr(), st), "counter_advance")
 
     def sync_model(self) -> None:
         """Copy the flat device parameters (and BN moving statistics) back into the model object (for predict / save)."""
         self.P.to_model(self.model)
 
     def state_dict(self) -> dict:
+        if self.half:  # voided steps do not advance the device counter: the device value is the truth
+            self.step_count = int(self.counter.item())
         return {"w": self.P.w.clone(), "m": self.P.m.clone(), "v": self.P.v.clone(), "stats": {k: t.clone() for k, t in self.P.stats.items()},
                 "step": self.step_count, "lr": self.lr}
 
@@ -830,14 +838,19 @@ class Trainer:
 
     def train_step_graphed(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor) -> dict:
         """The whole single-GPU step -- dropout masks, forward, loss, backward, Adam, moving statistics, step counter -- as ONE
-        hipGraph: captured on the first call for this batch geometry (after two eager warm-up steps that size every workspace),
-        replayed afterwards on the batch copied into the graph's input buffers.  The C ABI's promise (nothing allocates, frees or
-        synchronises; include/orcai_hip.h) is what makes the capture legal; what changes per step lives in device memory
-        (self.counter, self.lr_dev).  Returns the graph's output tensors: valid until the next replay."""
+        hipGraph: captured on the first call for this batch geometry (after two eager warm-up steps that size every workspace; the
+        trainer's state is put back afterwards, so a graphed run is step-for-step the eager run), replayed afterwards on the batch
+        copied into the graph's input buffers.  The C ABI's promise (nothing allocates, frees or synchronises; include/orcai_hip.h) is
+        what makes the capture legal; what changes per step lives in device memory (self.counter, self.lr_dev).  Every accumulator the
+        library clears inside the step is cleared by a KERNEL node: a captured hipMemsetAsync node re-reads its fill pattern at replay
+        from kernel-argument memory the graph does not own (HIP 7.0.51831 as bundled with torch 2.10; tools/debug_graph_memset_torch.py).
+        Returns the graph's output tensors: valid until the next replay."""
         key = (int(snippet_stride), int(B), tuple(labels.shape))
         if self._graph is None or self._graph["key"] != key:
             x_in = src[: (B - 1) * snippet_stride + self.model.input_hw[0] * self.model.input_hw[1]].clone()
             y_in = labels.clone()
+            saved = self.state_dict()
+            saved_batch, saved_skipped = self.P.batch_flat.clone(), self.skipped.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -848,8 +861,11 @@ class Trainer:
                 with torch.cuda.graph(g, stream=side):
                     out = self.train_step(x_in, snippet_stride, B, y_in)
             torch.cuda.current_stream().wait_stream(side)
-            # the warm-up and the capture pass each advanced the host mirror of the step counter; only the two warm-up steps ran
-            self.step_count -= 1
+            # the two warm-up steps moved weights, Adam moments, moving statistics and the step counter (the capture pass ran nothing):
+            # back to the state the caller handed in
+            self.load_state_dict(saved)
+            self.P.batch_flat.copy_(saved_batch)
+            self.skipped.copy_(saved_skipped)
             self._graph = {"key": key, "graph": g, "x": x_in, "y": y_in, "out": out}
         G = self._graph
         G["x"].copy_(src[: G["x"].numel()])

@@ -512,3 +512,34 @@ def test_pool_bwd_h_vs_f32_twin(C, H, W):
     for i, name in enumerate(("dy", "sum dy", "sum dy*xhat")):
         a, b = out[True][i], out[False][i]
         assert np.abs(a - b).max() <= 3e-3 * max(1.0, np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_overflowing_step_is_voided_on_the_device():
+    """A non-finite gradient (f16 overflow under the static loss scale) voids the whole step, as Keras' LossScaleOptimizer does: weights, Adam
+    moments, BatchNorm moving statistics and the step counter keep their values, the step is counted in Trainer.skipped -- decided on the
+    device (orcai_step_ok + the *_guarded update kernels), so it also holds inside a captured graph.  The next clean step is a normal one."""
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.random((4, 32, 12), dtype=np.float32)).cuda().view(-1)
+    y = torch.from_numpy((rng.random((4, 8, 3)) > 0.5).astype(np.float32)).cuda()
+    tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=1, precision="f16"), learning_rate=1e-2, seed=3)
+    tr.train_step(x, 32 * 12, 4, y)
+    assert int(tr.skipped.item()) == 0 and int(tr.counter.item()) == 1
+    before = {k: getattr(tr.P, k).clone() for k in ("w", "m", "v", "stats_flat")}
+    tr.forward_backward(x, 32 * 12, 4, y)
+    tr.P.g[123] = float("inf")  # what an f16 overflow in the backward leaves behind
+    tr.apply()
+    assert int(tr.skipped.item()) == 1 and int(tr.counter.item()) == 1 and int(tr.ok_dev.item()) == 0
+    for k, t in before.items():
+        assert torch.equal(getattr(tr.P, k), t), k  # not even the momentum term moved the weights
+    tr.forward_backward(x, 32 * 12, 4, y)
+    tr.P.batch_flat[5] = float("nan")  # an overflowed forward activation shows in the batch statistics
+    tr.apply()
+    assert int(tr.skipped.item()) == 2 and int(tr.counter.item()) == 1
+    assert torch.equal(tr.P.stats_flat, before["stats_flat"]) and bool(torch.isfinite(tr.P.stats_flat).all())
+    tr.train_step(x, 32 * 12, 4, y)
+    assert int(tr.skipped.item()) == 2 and int(tr.counter.item()) == 2 and int(tr.ok_dev.item()) == 1
+    assert not torch.equal(tr.P.w, before["w"]) and bool(torch.isfinite(tr.P.w).all())
+    assert tr.state_dict()["step"] == 2  # the host mirror follows the device counter

@@ -198,15 +198,55 @@ def test_multi_step_trajectory_matches_oracle():
 
 
 def test_training_step_replays_as_one_hip_graph():
-    """The whole step (dropout masks, forward, loss, backward, Adam, BatchNorm moving statistics, step counter) captured once as a
-    hipGraph and replayed: the per-step state lives in device memory (Trainer.counter, lr_dev), so replays draw fresh dropout
-    masks, advance Adam's bias correction and honour a learning-rate change made between replays.  Two trainers from the same seed
-    -- one stepping eagerly, one replaying the graph -- stay together to float-atomic reordering (weight gradients are summed with
-    atomics), and both learn."""
+    """The whole step (dropout masks, forward with the BatchNorm statistics in the conv epilogues, loss, backward, Adam, BatchNorm moving
+    statistics, step counter) captured once as a hipGraph and replayed: the per-step state lives in device memory (Trainer.counter,
+    lr_dev), so replays draw fresh dropout masks, advance Adam's bias correction and honour a learning-rate change made between replays.
+    (1) Step by step: before every step the eager trainer's state is copied into the graph trainer; one step each on the same batch must
+    give the same loss and batch statistics and the same gradients up to the float-atomic reordering that two EAGER steps show as well --
+    a replay that computes anything else than the eager step fails here at the replay where it happens, unamplified (a 24-step
+    trajectory of this dropout network amplifies 1e-7 to 1e-2 between two eager runs too: tools/debug_graph_divergence.py).
+    (2) Trajectories on a network small enough to stay together: eager and graph trainers from the same seed, both learn."""
     from orcai_amd.architectures import ResNetLSTM
     from orcai_amd.training import Trainer
 
-    rng = np.random.default_rng(0)
+    def state_to(src, dst):
+        dst.P.w.copy_(src.P.w); dst.P.m.copy_(src.P.m); dst.P.v.copy_(src.P.v); dst.P.stats_flat.copy_(src.P.stats_flat)
+        dst.P.batch_flat.copy_(src.P.batch_flat); dst.counter.copy_(src.counter)
+        dst.step_count, dst.lr = src.step_count, src.lr
+
+    # (1) a shape that reaches the strip-tile kernel with the statistics epilogue (two strips of 62 columns) and the flat-range one
+    rng = np.random.default_rng(1)
+    B, H, W = 4, 64, 171
+    xs = [torch.from_numpy(rng.random((B, H, W), dtype=np.float32)).cuda().view(-1) for _ in range(3)]
+    ys = [torch.from_numpy((rng.random((B, 16, 3)) > 0.5).astype(np.float32)).cuda() for _ in range(3)]
+    E, G = (Trainer(ResNetLSTM((H, W, 1), 3, [30, 40], 3, 0.3, 64, seed=1), learning_rate=3e-3, seed=5) for _ in range(2))
+    assert E.trunk.stats_in_epilogue and G.trunk.stats_in_epilogue and G.trunk.fused_stats_under_capture
+    masks_seen = []
+    for step in range(12):
+        if step == 6:
+            E.lr = 1e-3
+        state_to(E, G)
+        w_before = E.P.w.clone()
+        oe = E.train_step(xs[step % 3], H * W, B, ys[step % 3])
+        ge, be = E.P.g.clone(), E.P.batch_flat.clone()
+        og = G.train_step_graphed(xs[step % 3], H * W, B, ys[step % 3])
+        ae, ag = oe["acc"].cpu().numpy(), og["acc"].cpu().numpy()
+        assert abs(ae[0] / ae[1] - ag[0] / ag[1]) <= 1e-6 and ae[1] == ag[1], (step, ae, ag)
+        assert float((be - G.P.batch_flat).abs().max()) <= 1e-6 * float(be.abs().max()), step
+        for n, (o, k, _) in E.P.offsets.items():
+            a, b = ge[o : o + k], G.P.g[o : o + k]
+            assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6), (step, n)
+        # the replayed Adam used the eager one's bias correction and learning rate: same update from the same state
+        assert float((E.P.w - G.P.w).abs().max()) <= 2e-5, step
+        assert float((E.P.w - w_before).abs().max()) > 0
+        assert int(E.counter.item()) == int(G.counter.item()) == step + 1 and G.step_count == step + 1
+        masks_seen.append(float(og["probs"].sum()))
+    assert len(set(np.round(masks_seen, 5))) > 6  # replays are not repeating one frozen step
+
+    # (2) free-running: eager and graph trainers from the same seed (the capture's warm-up steps leave no trace in the trainer's state).  The
+    # first steps agree to float-atomic noise; later ones are only required to learn -- whether a 24-step trajectory of a dropout network
+    # under Adam stays within 1e-7 or wanders off by 1e-2 is decided by the reordering noise alone (two EAGER trainers do both:
+    # profiles/r03_graph_divergence.log), so trajectory equality is not a property a test can hold a replay to; (1) is.
     x = rng.random((4, 8, 32, 12), dtype=np.float32)
     y = (x.reshape(4, 8, 8, 4, 12).mean(axis=(3, 4))[..., None] > 0.5).astype(np.float32).repeat(3, axis=3)
     xs = [torch.from_numpy(x[b]).cuda().view(-1) for b in range(4)]
@@ -214,24 +254,16 @@ def test_training_step_replays_as_one_hip_graph():
     runs = {}
     for mode in ("eager", "graph"):
         tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.3, 64, seed=1), learning_rate=3e-3, seed=5)
-        # a captured step keeps the separate BatchNorm statistics pass (TrunkTrainer._sep_stats); the eager trainer is put on the same kernels, so
-        # that the two differ by float-atomic reordering only (the fused statistics differ from the separate pass in the seventh digit, which
-        # 24 steps of a dropout network at this learning rate amplify to 1e-2)
-        tr.trunk.stats_in_epilogue = False
         losses = []
-        if mode == "eager":  # the graphed trainer runs two warm-up steps on batch 0 before it captures: mirror them
-            for _ in range(2):
-                tr.train_step(xs[0], 32 * 12, 8, ys[0])
         for step in range(24):
             if step == 12:
                 tr.lr = 1e-3  # ReduceLROnPlateau-style change between steps: read from device memory by the replayed Adam
             out = tr.train_step(xs[step % 4], 32 * 12, 8, ys[step % 4]) if mode == "eager" else tr.train_step_graphed(xs[step % 4], 32 * 12, 8, ys[step % 4])
             a = out["acc"].cpu().numpy()
             losses.append(a[0] / a[1])
-        runs[mode] = (np.array(losses), tr.P.w.cpu().numpy(), int(tr.counter.item()), tr.step_count)
+        runs[mode] = (np.array(losses), int(tr.counter.item()), tr.step_count)
     le, lg = runs["eager"][0], runs["graph"][0]
-    assert runs["eager"][2] == runs["graph"][2] == 26 and runs["graph"][3] == 26
-    assert np.isfinite(lg).all() and lg[-4:].mean() < 0.95 * lg[:4].mean()
-    assert np.abs(le - lg).max() <= 2e-3 * max(1.0, np.abs(le).max()), np.abs(le - lg).max()
-    assert np.abs(runs["eager"][1] - runs["graph"][1]).max() <= 2e-3
-    assert len(set(np.round(lg[:8], 6))) > 4  # replays are not repeating one frozen step
+    assert runs["eager"][1] == runs["graph"][1] == 24 and runs["graph"][2] == 24  # no trace of the warm-up steps
+    assert np.abs(le - lg)[:4].max() <= 1e-5, np.abs(le - lg)
+    assert np.isfinite(lg).all() and lg[-4:].mean() < 0.95 * lg[:4].mean() and le[-4:].mean() < 0.95 * le[:4].mean()
+    assert len(set(np.round(lg[:8], 6))) > 4
