@@ -56,6 +56,28 @@ def cli_predict(**kwargs):
     predict(**kwargs)
 
 
+@cli.command(name="init-weights", short_help="Writes seeded, UNTRAINED weights into a model directory.", no_args_is_help=True, epilog=EPILOG,
+             help="Writes <name>.weights.npz with seeded random weights of the architecture described by MODEL_DIR/orcai_parameter.json and "
+                  "model_shape.json (the architecture's initialisers; BatchNorm statistics at their initial values).  For plumbing runs where the "
+                  "trained orcai-v1.keras is not available: the predictions of such a model mean nothing.  Not a reference command.")
+@click.argument("model_dir", type=DirW)
+@click.option("--seed", "-s", type=int, default=1, show_default=True, help="Seed of the weight draw.")
+@click.option("--overwrite", "-ow", is_flag=True, help="Overwrite an existing weights file.")
+def cli_init_weights(model_dir, seed, overwrite):
+    from orcai_amd.architectures import build_model
+    from orcai_amd.io import WEIGHTS_SUFFIX, read_json
+
+    param = read_json(model_dir.joinpath("orcai_parameter.json"))
+    shape = read_json(model_dir.joinpath("model_shape.json"))
+    out = model_dir.joinpath(param["name"] + WEIGHTS_SUFFIX)
+    if out.exists() and not overwrite:
+        raise click.ClickException(f"{out} exists (use --overwrite)")
+    param = {**param, "model": {**param["model"], "seed": seed}}
+    model = build_model(tuple(shape["input_shape"]), param, msgr=Messenger(verbosity=0))
+    model.save_weights(out)
+    click.echo(f"wrote {out} (seed {seed}, untrained)")
+
+
 @cli.command(name="create-spectrograms", short_help="Creates spectrograms for all files in a recording table.", no_args_is_help=True, epilog=EPILOG,
              help="Creates spectrograms for all files in the recording table at RECORDING_TABLE_PATH and saves them to OUTPUT_DIR.")
 @click.argument("recording_table_path", type=FileR)

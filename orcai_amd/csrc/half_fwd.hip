@@ -503,9 +503,6 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
   };
   issue(0);
   for (int i = threadIdx.x; i < KG * MT * 64; i += 64 * NWV) pw_s[i] = reinterpret_cast<const h16x8*>(pwf)[i];
-  if (STATS) {  // waves without a window leave before the epilogue: their slots must read as zero
-    for (int i = threadIdx.x; i < NWV * 4 * 8 * MT; i += 64 * NWV) (&stat_s[0][0][0])[i] = 0.0f;
-  }
   __syncthreads();
 
   const int task = bx * NWV + wave;
@@ -554,7 +551,7 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
       for (int t = 0; t < 4; ++t) acc[m][t] = mfma_h(a, as_h(d[t]), acc[m][t]);
     }
   }
-  if (!wave_live) return;
+  if (!STATS && !wave_live) return;  // with the statistics epilogue every wave stays for its workgroup barrier (no barrier behind a divergent return); a wave without a window contributes zeros
 
   // ---- epilogue of sepconv_h_kernel, plane (0) and x-pooled (2) layouts
   float sc_r[MT][4], sh_r[MT][4];
@@ -577,13 +574,13 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
     const int wl = 16 * (tp + (lk & 1)) + lj, flat = qbase + wl;
     const int row = (int)__umulhi((uint32_t)flat, magic_WP);
     const int x = flat - row * WP;
-    const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H;
+    const bool live = wave_live && wl >= lo && wl < 64 - lo && x < W && row < R + H;
     bool live0 = false, live1 = false;  // STATS: the pixels of column tiles tp and tp + 1 this lane holds BEFORE the octet exchange
     if (STATS) {
       const int w0 = 16 * tp + lj, w1 = w0 + 16, g0 = qbase + w0, g1 = qbase + w1;
       const int y0 = (int)__umulhi((uint32_t)g0, magic_WP), y1 = (int)__umulhi((uint32_t)g1, magic_WP);
-      live0 = w0 >= lo && w0 < 64 - lo && (g0 - y0 * WP) < W && y0 < R + H;
-      live1 = w1 >= lo && w1 < 64 - lo && (g1 - y1 * WP) < W && y1 < R + H;
+      live0 = wave_live && w0 >= lo && w0 < 64 - lo && (g0 - y0 * WP) < W && y0 < R + H;
+      live1 = wave_live && w1 >= lo && w1 < 64 - lo && (g1 - y1 * WP) < W && y1 < R + H;
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -631,7 +628,7 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
 #pragma unroll
       for (int j = 0; j < 8 * MT; ++j) stat_s[wave][lk][j] = st[j];
     }
-    __syncthreads();  // among the waves that have a window (the others are gone; their slots hold zeros)
+    __syncthreads();  // all NWV waves (those without a window wrote zeros)
     if (wave == 0) {
       const int g = lane >> 4;
       for (int j = lane & 15; j < 8 * MT; j += 16) {  // j = [sum | sum of squares] * 4 MT + m * 4 + r -> channel m * 16 + g * 4 + r

@@ -750,7 +750,6 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
   }
-  if (STATS && threadIdx.x < TR * 64) (&stat_s[0][0][0])[threadIdx.x] = 0.0f;  // waves past the last image row leave before the epilogue
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int row = r0 + wave;  // this wave's image row
@@ -792,7 +791,10 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
     }
   }
   // ---- epilogue: D[row = 4*lk + r -> cout][col = lj -> tile column 16*tt + lj]
-  if (row >= H) return;
+  // Waves past the last image row: without the statistics epilogue they are done; with it they stay for its workgroup barrier
+  // (a barrier behind a divergent return is undefined in HIP) and contribute nothing: `live` is false for all their lanes.
+  const bool row_ok = row < H;
+  if (!STATS && !row_ok) return;
   float st[STATS ? 16 : 1];  // STATS: [sum | sum of squares][m][r] over this lane's stored pixels
   if (STATS) {
 #pragma unroll
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
   for (int tt = 0; tt < 4; ++tt) {
     const int wl = 16 * tt + lj;
     const int x = c0 - lo + wl;
-    const bool live = wl >= lo && wl < 64 - lo && x < W && (!XP || (x & 1) == 0);
+    const bool live = row_ok && wl >= lo && wl < 64 - lo && x < W && (!XP || (x & 1) == 0);
     const bool pair_ok = x + 1 < W;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(&stat_s[wave][lk][j]) = make_float4(st[j], st[j + 1], st[j + 2], st[j + 3]);
     }
-    __syncthreads();  // among the waves that have an image row (the others are gone; their slots hold zeros)
+    __syncthreads();  // all TR waves (those past the last image row wrote zeros)
     if (wave == 0) {
       const int g = lane >> 4, j = lane & 15;  // channel quad (j >> 2 & 1) * 4 + g, element (j >> 3) * 4 + (j & 3) of its 8 doubles
       float tot = 0.0f;
@@ -918,9 +920,6 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
   }
-  if (STATS) {  // waves without a window leave before the epilogue: their slots must read as zero
-    for (int i = threadIdx.x; i < NWV * 4 * 8 * MT; i += 64 * NWV) (&stat_s[0][0][0])[i] = 0.0f;
-  }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int task = bx * NWV + wave;
@@ -971,7 +970,7 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
       for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
   }
   // ---- epilogue (see sepconv_kernel): D[row = 4*lk + r -> cout][col = lj -> pixel 16*tt + lj of the window]
-  if (!wave_live) return;
+  if (!STATS && !wave_live) return;  // with the statistics epilogue every wave stays for its workgroup barrier; `live` is false for all lanes of a wave without a window
   float st[STATS ? 8 * MT : 1];  // STATS: [sum | sum of squares][m][r] over this lane's stored pixels
   if (STATS) {
 #pragma unroll
@@ -983,7 +982,7 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
     const int flat = qbase + wl;
     const int row = (int)__umulhi((uint32_t)flat, magic_WP);
     const int x = flat - row * WP;
-    const bool live = wl >= lo && wl < 64 - lo && x < W && row < R + H && (!XP || (x & 1) == 0);
+    const bool live = wave_live && wl >= lo && wl < 64 - lo && x < W && row < R + H && (!XP || (x & 1) == 0);
     const bool pair_ok = x + 1 < W;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -1023,7 +1022,7 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < 8 * MT; ++j) stat_s[wave][lk][j] = st[j];
     }
-    __syncthreads();  // among the waves that have a window (the others are gone; their slots hold zeros)
+    __syncthreads();  // all NWV waves (those without a window wrote zeros)
     if (wave == 0) {
       const int g = lane >> 4;
       for (int j = lane & 15; j < 8 * MT; j += 16) {  // j = [sum | sum of squares] * 4 MT + m * 4 + r -> channel quad m * 4 + g, element r

@@ -36,11 +36,35 @@ def save_dataset(spectrograms: np.ndarray, labels: np.ndarray, path: Path | str,
     np.save(path / "labels.npy", np.ascontiguousarray(labels, dtype=np.float32))
 
 
+def rank_batches(order: np.ndarray, batch_size: int, rank: int, world_size: int, dp_batch: str) -> list:
+    """Which snippets of an epoch's shuffled `order` this rank sees, step by step.
+    "replicate" (throughput mode): `batch_size` is the PER-RANK batch; the global batch list is dealt round-robin, every rank
+        takes len // world full batches -- the optimiser sees batch_size x world snippets per step and 1 / world of the steps.
+    "split" (the reference's MirroredStrategy contract, hpsearch.py:170-205): `batch_size` is the GLOBAL batch; every global batch is
+        cut into world contiguous slices of batch_size / world snippets, one per rank -- same number of steps per epoch as one GPU,
+        same snippets per optimiser step; gradients are averaged over the ranks, BatchNorm statistics stay per replica."""
+    nb = len(order) // batch_size
+    batches = [order[i * batch_size : (i + 1) * batch_size] for i in range(nb)]
+    if dp_batch == "split":
+        per = batch_size // world_size
+        return [b[rank * per : (rank + 1) * per] for b in batches]
+    return batches[rank::world_size][: nb // world_size]
+
+
+def check_dp_batch(dp_batch: str, batch_size: int, world_size: int) -> str:
+    if dp_batch not in ("replicate", "split"):
+        raise ValueError(f"dp_batch must be 'replicate' or 'split', got {dp_batch!r}")
+    if dp_batch == "split" and batch_size % world_size:
+        raise ValueError(f"dp_batch 'split': the global batch size {batch_size} is not divisible by the {world_size} ranks")
+    return dp_batch
+
+
 class SnippetDataset:
     """Iterable of (spectrogram cuda f32 [B][H][W], labels cuda f32 [B][T][L]) batches."""
 
-    def __init__(self, path: Path | str, batch_size: int, seed=None, shuffle: bool = True, rank: int = 0, world_size: int = 1):
+    def __init__(self, path: Path | str, batch_size: int, seed=None, shuffle: bool = True, rank: int = 0, world_size: int = 1, dp_batch: str = "replicate"):
         path = Path(path)
+        self.dp_batch = check_dp_batch(dp_batch, int(batch_size), world_size)
         self.x = np.load(path / "spectrogram.npy", mmap_mode="r")
         self.y = np.load(path / "labels.npy", mmap_mode="r")
         if self.x.ndim == 4:
@@ -52,7 +76,8 @@ class SnippetDataset:
         self.rank, self.world_size = rank, world_size
 
     def __len__(self) -> int:
-        return (len(self.x) // self.batch_size) // self.world_size
+        nb = len(self.x) // self.batch_size
+        return nb if self.dp_batch == "split" else nb // self.world_size
 
     def _order(self) -> np.ndarray:
         n = len(self.x)
@@ -76,9 +101,7 @@ class SnippetDataset:
     def __iter__(self):
         order = self._order()
         self.epoch += 1
-        nb = len(order) // self.batch_size
-        batches = [order[i * self.batch_size : (i + 1) * self.batch_size] for i in range(nb)]
-        batches = batches[self.rank :: self.world_size][: len(self)]  # each rank its own batches, same count on all ranks
+        batches = rank_batches(order, self.batch_size, self.rank, self.world_size, self.dp_batch)  # same count on all ranks
         q: queue.Queue = queue.Queue(maxsize=3)
 
         def producer():
@@ -102,7 +125,8 @@ class SnippetDataset:
                 yield xb, yb
 
 
-def load_dataset(path: Path | str, batch_size: int, compression: str = "GZIP", seed=None, rank: int = 0, world_size: int = 1) -> SnippetDataset:
+def load_dataset(path: Path | str, batch_size: int, compression: str = "GZIP", seed=None, rank: int = 0, world_size: int = 1,
+                 dp_batch: str = "replicate") -> SnippetDataset:
     """Same call shape as the reference's load_dataset (io.py:150-184); `compression` is accepted and ignored (raw .npy).
     A directory holding ``snippet_table_dataset.json`` ({"snippet_table": <csv path>, "n_filters": n}: a descriptor, nothing materialised) gives a
     SnippetTableDataset that gathers its batches on the GPU from the recordings' arrays."""
@@ -114,8 +138,8 @@ def load_dataset(path: Path | str, batch_size: int, compression: str = "GZIP", s
 
         d = json.loads(desc.read_text())
         table = pd.read_csv((Path(path) / d["snippet_table"]).resolve())
-        return SnippetTableDataset(table, d["n_filters"], batch_size, seed=seed, shuffle=True, rank=rank, world_size=world_size)
-    return SnippetDataset(path, batch_size, seed=seed, shuffle=True, rank=rank, world_size=world_size)
+        return SnippetTableDataset(table, d["n_filters"], batch_size, seed=seed, shuffle=True, rank=rank, world_size=world_size, dp_batch=dp_batch)
+    return SnippetDataset(path, batch_size, seed=seed, shuffle=True, rank=rank, world_size=world_size, dp_batch=dp_batch)
 
 
 def make_synthetic_dataset(path: Path | str, n: int, seed: int = 4, input_shape=(736, 171), out_steps: int = 46, n_labels: int = 7, overwrite: bool = True) -> None:
@@ -197,7 +221,7 @@ class SnippetTableDataset:
     DataLoader takes, io.py:20-37).  Same iteration contract as SnippetDataset (shuffle buffer, drop remainder, rank slicing)."""
 
     def __init__(self, snippet_table, n_filters: int, batch_size: int, seed=None, shuffle: bool = True, rank: int = 0, world_size: int = 1,
-                 store: RecordingStore | None = None):
+                 store: RecordingStore | None = None, dp_batch: str = "replicate"):
         from orcai_amd import _native as N
 
         self._N = N
@@ -217,9 +241,11 @@ class SnippetTableDataset:
         self.seed = int(np.random.SeedSequence(seed).generate_state(1)[0])
         self.epoch = 0
         self.rank, self.world_size = rank, world_size
+        self.dp_batch = check_dp_batch(dp_batch, self.batch_size, world_size)
 
     def __len__(self) -> int:
-        return (len(self.starts) // self.batch_size) // self.world_size
+        nb = len(self.starts) // self.batch_size
+        return nb if self.dp_batch == "split" else nb // self.world_size
 
     _order = SnippetDataset._order
 
@@ -242,7 +268,5 @@ class SnippetTableDataset:
     def __iter__(self):
         order = self._order()
         self.epoch += 1
-        nb = len(order) // self.batch_size
-        batches = [order[i * self.batch_size : (i + 1) * self.batch_size] for i in range(nb)]
-        for idx in batches[self.rank :: self.world_size][: len(self)]:
+        for idx in rank_batches(order, self.batch_size, self.rank, self.world_size, self.dp_batch):
             yield self.batch(torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(self.store.device))

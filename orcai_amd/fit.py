@@ -74,6 +74,9 @@ class ModelCheckpoint(Callback):
 
     def __init__(self, filepath, monitor="val_MBA", save_best_only=True, mode="max", verbose=0):
         self.filepath, self.monitor, self.best_only, self.mode, self.best = Path(filepath), monitor, save_best_only, mode, None
+        # JSON files written next to the checkpoint whenever it is saved ({file name: object}).  The reference's .keras file carries the
+        # architecture; a weights file does not, so a search over architectures (hpsearch) records the trial's resolved parameters here
+        self.sidecar: dict = {}
 
     def on_epoch_end(self, loop, epoch, logs):
         cur = logs.get(self.monitor)
@@ -83,6 +86,10 @@ class ModelCheckpoint(Callback):
                 loop.trainer.sync_model()
                 self.filepath.parent.mkdir(parents=True, exist_ok=True)
                 loop.model.save(self.filepath)
+                for name, obj in self.sidecar.items():
+                    import json
+
+                    self.filepath.parent.joinpath(name).write_text(json.dumps(obj, indent=1))
 
 
 class ReduceLROnPlateau(Callback):

@@ -98,8 +98,13 @@ def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_pa
         starting from `resume` (the Trainer state its previous rung ended in) when it was promoted.  -> (score, end state)"""
         p = _apply(hp, orcai_parameter, hps_parameter)
         bs = p["model"]["batch_size"]
-        train_ds = load_dataset(data_dir.joinpath("train_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_TEST_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
-        val_ds = load_dataset(data_dir.joinpath("val_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
+        # --parallel is the reference's MirroredStrategy (hpsearch.py:170-205): the batch size of the search space is the GLOBAL batch, split
+        # over the ranks (dp_batch "split"; orcai_parameter["model"]["dp_batch"] = "replicate" makes it the per-GPU batch instead)
+        dpb = p["model"].get("dp_batch", "split")
+        train_ds = load_dataset(data_dir.joinpath("train_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_TEST_DATA, orcai_parameter["seed"]], rank=rank, world_size=world, dp_batch=dpb)
+        val_ds = load_dataset(data_dir.joinpath("val_dataset"), bs, compression=data_compression, seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world, dp_batch=dpb)
+        # the checkpoint is one weights file for trials of different architectures: the trial that writes it leaves its parameters beside it
+        checkpoint.sidecar = {"orcai_parameter.json": p, "model_shape.json": {"input_shape": list(dataset_shape["spectrogram"]), "num_labels": len(p["calls"]), "hyperparameters": hp}}
         model = build_model(tuple(dataset_shape["spectrogram"]), p, msgr=Messenger(verbosity=0))
         model.compile(learning_rate=p["model"]["learning_rate"], seed=seed)  # in a process group the Trainer broadcasts rank 0's initial weights
         trainer = model._loop.trainer

@@ -77,4 +77,9 @@ def load_orcai_model(model_dir: Path):
             f"{model_dir} holds Keras weights ({name}.keras / model_weights.h5) but no {name}{WEIGHTS_SUFFIX}; convert them once with "
             f"`python tools/keras_to_npz.py {model_dir}` (needs h5py)"
         )
-    raise ValueError(f"Couldn't find model weights ({name}{WEIGHTS_SUFFIX}) in {model_dir}")
+    raise ValueError(
+        f"Couldn't find model weights ({name}{WEIGHTS_SUFFIX}) in {model_dir}.  The trained orcai-V1 weights are a large blob the reference "
+        f"ships outside its source tree ({name}.keras); put that file into the directory and convert it once with "
+        f"`python tools/keras_to_npz.py {model_dir}` (needs h5py), or -- to exercise the pipeline with UNTRAINED weights of the same "
+        f"architecture -- run `orcai init-weights {model_dir} --seed 1`."
+    )

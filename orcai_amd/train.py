@@ -52,10 +52,13 @@ def train(data_dir: Path | str, output_dir: Path | str, orcai_parameter: (Path |
     else:
         msgr.info("Using default OrcAI dataset shapes")
         dataset_shape = {"spectrogram": [736, 171, 1], "labels": [46, 7]}
+    # more than one rank (torchrun; the reference trains on one device, train.py:155): "replicate" = batch_size per GPU (throughput mode, the
+    # optimiser sees batch_size x world), "split" = batch_size is the global batch as under the reference's MirroredStrategy
+    dp_batch = model_parameter.get("dp_batch", "replicate")
     train_dataset = load_dataset(data_dir.joinpath("train_dataset"), model_parameter["batch_size"], compression=data_compression,
-                                 seed=[SEED_ID_LOAD_TRAIN_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
+                                 seed=[SEED_ID_LOAD_TRAIN_DATA, orcai_parameter["seed"]], rank=rank, world_size=world, dp_batch=dp_batch)
     val_dataset = load_dataset(data_dir.joinpath("val_dataset"), model_parameter["batch_size"], compression=data_compression,
-                               seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world)
+                               seed=[SEED_ID_LOAD_VAL_DATA, orcai_parameter["seed"]], rank=rank, world_size=world, dp_batch=dp_batch)
     if model_parameter.get("call_weights") is not None:
         call_weights = read_json(data_dir.joinpath("call_weights.json"))
         if list(call_weights.keys()) != label_calls:
@@ -63,7 +66,7 @@ def train(data_dir: Path | str, output_dir: Path | str, orcai_parameter: (Path |
         call_weights_int = {n: call_weights[key] for n, key in enumerate(call_weights)}
     else:
         call_weights_int = None
-    msgr.info(f"Batch size {model_parameter['batch_size']}" + (f" per GPU x {world} GPUs" if world > 1 else ""))
+    msgr.info(f"Batch size {model_parameter['batch_size']}" + ((f" per GPU x {world} GPUs" if dp_batch == "replicate" else f" split over {world} GPUs") if world > 1 else ""))
     model_dir = output_dir.joinpath(model_name)
 
     if load_model:

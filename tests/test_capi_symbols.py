@@ -56,3 +56,23 @@ def test_library_exports_every_declared_symbol():
     for name in header_prototypes():
         assert getattr(lib, name) is not None
     assert b"gfx950" in lib.orcai_version()
+
+
+def test_bench_kernel_symbols_are_in_the_newest_pmc_traffic_table():
+    """bench.py's `roofline.traffic` is looked up by kernel symbol in profiles/rNN_pmc_traffic.json.  The symbol bench_predict.kernel_symbol()
+    builds for the bracketed layers must be one the newest table (made from rocprofv3 --pmc passes of the same command at the same
+    kernels) knows -- a renamed template argument list would otherwise turn `traffic` into a silent None or, worse, a stale hit."""
+    import json
+
+    import bench_predict as bp
+
+    f = bp.traffic_file()
+    assert f is not None
+    kernels = json.loads(f.read_text())["predict"]["kernels"]
+    for label in ("conv0+b1/sep_a", "b1/sep_b", "b2/sep_a", "b2/sep_b", "b1/pool_res"):  # labels the inference step launches (b1/sep_a alone only without the entry fusion)
+        sym = bp.PredictWorkload.kernel_symbol(label)
+        assert sym in kernels, (label, sym, f.name, sorted(k for k in kernels if "sepconv" in k or "conv0" in k))
+    fe = json.loads(f.read_text())["frontend"]["kernels"]
+    import bench
+
+    assert bench.FrontendWorkload.kernel_symbol in fe, (bench.FrontendWorkload.kernel_symbol, sorted(fe))

@@ -139,7 +139,7 @@ def test_cli_surface_matches_reference_options():
         "hpsearch": {"-p", "-hp", "-pl", "-dc", "-v"},
         "test": {"-tu", "-o", "-dc", "-v"},
     }
-    assert set(cli.commands) == set(expect)
+    assert set(cli.commands) - {"init-weights"} == set(expect)  # init-weights: this package's own helper (seeded untrained weights), not a reference command
     for name, flags in expect.items():
         have = {o for p in cli.commands[name].params for o in getattr(p, "opts", []) if o.startswith("-") and not o.startswith("--")}
         assert have == flags, (name, have ^ flags)
@@ -349,3 +349,53 @@ def test_callbacks_follow_keras_conventions():
             del os.environ["WORLD_SIZE"]
         else:
             os.environ["WORLD_SIZE"] = old
+
+
+def test_dp_batch_split_and_replicate_partition_an_epoch():
+    """MirroredStrategy's contract (reference hpsearch.py:170-205) against the throughput mode: "split" cuts every GLOBAL batch into
+    world contiguous slices (same steps per epoch as one GPU, the ranks' slices of a step re-assemble the one-GPU batch); "replicate"
+    deals whole batches round-robin (batch_size per rank, 1 / world of the steps)."""
+    from orcai_amd.datasets import check_dp_batch, rank_batches
+
+    order = np.random.default_rng(0).permutation(70)
+    one = rank_batches(order, 8, 0, 1, "split")
+    assert len(one) == 8 and all(len(b) == 8 for b in one)
+    for world in (2, 4):
+        per_rank = [rank_batches(order, 8, r, world, "split") for r in range(world)]
+        assert all(len(p) == len(one) for p in per_rank)
+        for step, b in enumerate(one):
+            assert np.array_equal(np.concatenate([per_rank[r][step] for r in range(world)]), b)
+        rep = [rank_batches(order, 8, r, world, "replicate") for r in range(world)]
+        assert all(len(p) == len(one) // world and all(len(b) == 8 for b in p) for p in rep)
+        seen = np.concatenate([b for p in rep for b in p])
+        assert len(set(seen.tolist())) == len(seen)  # no snippet twice
+    with pytest.raises(ValueError, match="not divisible"):
+        check_dp_batch("split", 8, 3)
+    with pytest.raises(ValueError, match="dp_batch"):
+        check_dp_batch("mirror", 8, 2)
+
+
+def test_init_weights_command_makes_the_default_model_loadable(tmp_path):
+    """The bundled orcai-V1 directory ships without the trained weights (a large blob outside the reference's source tree): the loader's error
+    says so and names both ways out; `orcai init-weights` writes seeded untrained weights, after which load_orcai_model works."""
+    import shutil
+    from importlib.resources import files
+
+    from click.testing import CliRunner
+
+    from orcai_amd.cli import cli
+    from orcai_amd.io import load_orcai_model
+
+    src = files("orcai_amd.models").joinpath("orcai-V1")
+    d = tmp_path / "orcai-V1"
+    shutil.copytree(src, d)
+    for f in d.glob("*.npz"):
+        f.unlink()
+    with pytest.raises(ValueError, match="init-weights"):
+        load_orcai_model(d)
+    res = CliRunner().invoke(cli, ["init-weights", str(d), "--seed", "3"], catch_exceptions=False)
+    assert res.exit_code == 0 and "untrained" in res.output
+    model, param, shape = load_orcai_model(d)
+    assert model.count_params() == 996039 and tuple(shape["input_shape"]) == (736, 171, 1)
+    res = CliRunner().invoke(cli, ["init-weights", str(d)])
+    assert res.exit_code != 0 and "exists" in res.output

@@ -71,15 +71,15 @@ def _oracle_pipeline(y48, p):
     return agg, cnt, P.labels_to_tsv_ref(labels, times[1] - times[0]), times[1] - times[0]
 
 
-@pytest.mark.parametrize("sr", [48000, 22050])
-def test_predict_wav_end_to_end(tmp_path, sr):
+@pytest.mark.parametrize("sr,seconds", [(48000, 14.0), (22050, 60.0)])  # the second one is BASELINE configs[0]: one 60 s 22.05 kHz recording, 29 snippets
+def test_predict_wav_end_to_end(tmp_path, sr, seconds):
     from oracle.resample_ref import resample_ref
     from orcai_amd.predict import predict
     from orcai_amd.synthetic import pcm16_to_float, synth_recording
     from orcai_amd.wavio import write_wav_pcm16
 
     model_dir, p = _model_dir(tmp_path)
-    pcm = synth_recording(14.0, sr, seed=9)
+    pcm = synth_recording(seconds, sr, seed=9)
     wav = tmp_path / "rec.wav"
     write_wav_pcm16(wav, np.stack([pcm, pcm[::-1]]), sr)  # 2 channels: channel 1 is used
     out = tmp_path / "rec_pred.txt"

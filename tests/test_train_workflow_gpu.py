@@ -259,6 +259,27 @@ def _dp_worker(rank, world, port, backend, mode, q):
         from orcai_amd.training import Trainer
 
         tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=21), learning_rate=3e-3)
+    if mode == "split":  # dp_batch "split": the SAME global batch of 8 on every world size, rank r trains on its contiguous slice of 8 / world snippets
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.datasets import rank_batches
+        from orcai_amd.training import Trainer
+
+        tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=21), learning_rate=3e-3)
+        rng = np.random.default_rng(11)
+        xa, ya = rng.random((8, 32, 12), dtype=np.float32), (rng.random((8, 8, 3)) > 0.6).astype(np.float32)
+        ya[:, :, 2][:3] = -1.0  # masked cells in some snippets: the replicas' unmasked counts differ
+        mine = rank_batches(np.arange(8), 8, rank, world, "split")[0]
+        losses, n = [], len(mine)
+        xs, ys = torch.from_numpy(xa[mine]).cuda().view(-1), torch.from_numpy(ya[mine]).cuda()
+        for _ in range(4):
+            out = tr.train_step(xs, 32 * 12, n, ys, world_size=world)
+            a = out["acc"].cpu().numpy()
+            losses.append(float(a[0] / a[1] + a[3]))
+        q.put((rank, w_before, tr.P.w.cpu().numpy(), {k: v.cpu().numpy() for k, v in tr.P.stats.items()}, losses))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     losses = []
     for _ in range(4):
         out = tr.train_step(x, 32 * 12, 8, y, world_size=world)
@@ -318,6 +339,40 @@ def test_loss_trajectory_is_world_size_invariant(backend):
             assert np.array_equal(r[2], res[0][2])
 
 
+def test_split_batch_is_the_mirrored_strategy_contract():
+    """dp_batch "split" (reference hpsearch.py:170-205, MirroredStrategy): a global batch of 8 on two ranks = each rank's loss / gradient on
+    its 4 snippets with ITS OWN BatchNorm batch statistics, gradients averaged, one Adam step.  Emulated on one process -- two
+    forward_backward calls on the halves with the same weights, the two gradient buffers averaged, one apply -- the weights after four steps
+    must equal the two-rank run's (to float reordering); against the undivided batch of 8 on one GPU the difference is the per-replica
+    BatchNorm statistics and the mean-of-means loss, reported and bounded, not zero."""
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.training import Trainer
+
+    two = _run_dp(2, "gloo", "split")
+    assert np.array_equal(two[0][2], two[1][2])  # replicas stay identical
+    one = _run_dp(1, "gloo", "split")[0]
+    rng = np.random.default_rng(11)
+    xa, ya = rng.random((8, 32, 12), dtype=np.float32), (rng.random((8, 8, 3)) > 0.6).astype(np.float32)
+    ya[:, :, 2][:3] = -1.0
+    tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=21), learning_rate=3e-3)
+    halves = [(torch.from_numpy(xa[h]).cuda().view(-1), torch.from_numpy(ya[h]).cuda()) for h in (slice(0, 4), slice(4, 8))]
+    rank_losses = [[], []]
+    for _ in range(4):
+        g = torch.zeros_like(tr.P.g)
+        for r, (xs, ys) in enumerate(halves):
+            a = tr.forward_backward(xs, 32 * 12, 4, ys)["acc"].cpu().numpy()
+            rank_losses[r].append(float(a[0] / a[1] + a[3]))
+            g += tr.P.g
+        tr.P.g.copy_(g * 0.5)  # what the all-reduce (sum) and Adam's 1 / world scaling make of the two replicas' gradients
+        tr.apply(world_size=1)  # the EMA takes the last replica's batch statistics (moving statistics are per replica anyway)
+    assert np.abs(tr.P.w.cpu().numpy() - two[0][2]).max() <= 2e-5
+    for r in range(2):
+        assert np.abs(np.array(two[r][4]) - np.array(rank_losses[r])).max() <= 1e-5, (r, two[r][4], rank_losses[r])
+    dev = np.abs(np.mean([two[0][4], two[1][4]], axis=0) - np.array(one[4]))
+    print("split over 2 ranks vs the undivided batch (per-replica BatchNorm statistics, mean of means): |dloss| per step", dev)
+    assert dev[0] > 0 and dev.max() <= 0.05 and one[4][-1] < one[4][0]
+
+
 def test_hpsearch_f16_sweep_checkpoints_and_resumes(tmp_path):
     """BASELINE configs[4] through the reference's entry point: hyperparameter_search (hpsearch.py:110-257) over two width variants
     with model precision "f16".  The best model of the whole search is checkpointed under <out>/<name>/hps/ (hpsearch.py:227-242),
@@ -345,6 +400,9 @@ def test_hpsearch_f16_sweep_checkpoints_and_resumes(tmp_path):
     assert ckpt.exists()
     with np.load(ckpt) as z:
         assert "conv0/kernel" in z.files and all(np.isfinite(z[k]).all() for k in z.files)
+    # the trial that wrote the checkpoint left its resolved parameters beside it: the directory loads like any model directory
+    m2, p2, sh2 = load_orcai_model(ckpt.parent)
+    assert p2["model"]["filters"] in ([10, 20], [12, 24]) and sh2["hyperparameters"]["filters"] in ("set1", "set2") and p2["model"]["precision"] == "f16"
 
 
 def test_class_weight_scales_the_loss_like_keras():
