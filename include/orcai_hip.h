@@ -338,6 +338,14 @@ int orcai_pool_bwd_bn(const float* dout, const float* v, int B, int C, int H, in
 int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                            const float* beta, float eps, int relu, double* scratch, int sums_ready, float* dbeta, float* dgamma, const float* wt, int Cin,
                            float* dv, float* du, void* stream);
+/* orcai_bn_bwd_pointwise + the pointwise weight gradient of the same separable conv in ONE pass (train.py:201-219 computes these inside Keras):
+ * dv is formed per pixel, multiplied by the transposed pointwise weights (du) AND contracted with the depthwise output u of the forward
+ * pass (dWpw[ci][co] += sum_pixels u[ci] dv[co]); dv itself is never written.  workspace: per-wave partial products
+ * (>= 4 * Cin * C floats per workgroup).  ORCAI_E_UNSUPPORTED (before anything is touched) when ceil(Cin/16) + ceil(C/16) > 4: the caller
+ * then runs orcai_bn_bwd_pointwise and orcai_outer_reduce. */
+int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
+                                 const float* wt, int Cin, float* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream);
 /* out[c] (=|+=) sum over snippets and pixels of x[c] (bias gradients); scratch: f64[4*ceil(C/4)] */
 int orcai_planes_sum(const float* x, int B, int C, int H, int W, int ksize, double* scratch, float* out, int accumulate, void* stream);
 /* gradient of MaxPooling2D((3,2), 2, "same"): dy[y][x] = sum of dout over the windows whose maximum is ybn[y][x] */

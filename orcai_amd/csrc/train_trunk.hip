@@ -319,6 +319,141 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_kernel(const float* dy, const f
   }
 }
 
+
+// ---------------------------------------------------------------- BN backward apply + du = Wpw dv + pointwise weight gradient, one pass
+// bn_bwd_pw_kernel forms dv per pixel, stores it, and orcai_outer_reduce reads it back (with the depthwise output u) for
+// dWpw[ci][co] = sum_pixels u[ci][p] dv[co][p]: dv is written and read once for nothing else.  Here the wave that forms dv also contracts it
+// with u: dv and u of its 64-pixel window go through a WAVE-PRIVATE LDS image [channel][pixel] (pitch 66: the 16 channel rows x 2 pixels of a
+// half-wave hit 32 distinct banks), read back as MFMA operands with k = pixel (k-step s takes pixels {4 s + lk}).  No workgroup barrier:
+// a wave reads only what it wrote.  Waves walk the windows of one snippet (grid.y) with a stride, accumulate the MT x NT weight-gradient
+// tiles in registers and write one partial product each; add_partials_kernel sums them into dWpw.  dv never reaches HBM (one write and one
+// read of the widest gradient tensor of every separable conv less per step).  Channels: Cin <= 16 MT, C <= 16 NT, (MT + NT) * 16.5 KiB of
+// LDS per workgroup -- used for MT + NT <= 4 (blocks 1 of orcai-V1: 62 % of the trunk's bytes); wider layers keep the two kernels.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ u /*[B][CQi][HP][WP][4]*/, int C,
+                                                               int H, int W, int WP, int R, const float* __restrict__ mean, const float* __restrict__ var,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                               const double* __restrict__ dbeta, const double* __restrict__ dgamma, float inv_count,
+                                                               const float* __restrict__ wt /*[C][Cin]*/, int Cin, float* __restrict__ du /*[B][CQi][HP][WP][4]*/,
+                                                               int tasks, uint32_t magic_WP, float* __restrict__ part /*[gridDim.y][gridDim.x][4][Cin*C]*/) {
+  constexpr int P = 66, MAXQ = 4 * (MT > NT ? MT : NT);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lk = lane >> 4, lj = lane & 15;
+  float* As = smem + wave * (MT + NT) * 16 * P;  // [MT*16][P]: u, rows past Cin stay zero
+  float* Bs = As + MT * 16 * P;                  // [NT*16][P]: dv
+  for (int i = lane; i < (MT + NT) * 16 * P; i += 64) As[i] = 0.0f;
+  const int b = blockIdx.y;
+  const int CQ = (C + 3) >> 2, CQi = (Cin + 3) >> 2;
+  const int plane = (H + 2 * R) * WP;
+  f32x4 wacc[MT * NT];
+#pragma unroll
+  for (int i = 0; i < MT * NT; ++i) wacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float4* dyb = reinterpret_cast<const float4*>(dy) + (int64_t)b * CQ * plane;
+  const float4* vb = reinterpret_cast<const float4*>(v) + (int64_t)b * CQ * plane;
+  const float4* ub = reinterpret_cast<const float4*>(u) + (int64_t)b * CQi * plane;
+  float4* dub = reinterpret_cast<float4*>(du) + (int64_t)b * CQi * plane;
+
+  for (int task = blockIdx.x * 4 + wave; task < tasks; task += gridDim.x * 4) {
+    const int qbase = R * WP + task * 64;  // interior rows only; 1 KiB-aligned windows
+    const int q = qbase + lane;
+    const int row = (int)__umulhi((uint32_t)q, magic_WP);
+    const bool live = (q - row * WP) < W && row < R + H;
+    const int qc = q < plane ? q : plane - 1;
+    float4 ru[MAXQ];  // the depthwise output of this pixel, every input quad: all requested up front
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i)
+      if (i < CQi) ru[i] = ub[(int64_t)i * plane + qc];
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 nd = dyb[qc], nv = vb[qc];
+    for (int cq = 0; cq < CQ; ++cq) {
+      const float4 d4 = nd, v4 = nv;
+      if (cq + 1 < CQ) {
+        nd = dyb[(int64_t)(cq + 1) * plane + qc];
+        nv = vb[(int64_t)(cq + 1) * plane + qc];
+      }
+      float afrag[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = cq * 4 + lk, ci = m * 16 + lj;  // k = conv-output channel, row = conv-input channel
+        const bool ok = co < C && ci < Cin;
+        const float av = wt[ok ? co * Cin + ci : 0];
+        afrag[m] = ok ? av : 0.0f;
+      }
+      const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = cq * 4 + k;  // wave-uniform: the per-channel constants are scalar loads
+        if (c < C) {
+          const float inv = rsqrtf(var[c] + eps);
+          const float xh = (vv[k] - mean[c]) * inv;
+          float de = dd[k];
+          if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+          o[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
+        } else {
+          o[k] = 0.0f;
+        }
+        Bs[(4 * cq + k) * P + lane] = o[k];
+      }
+      swap32t(o[0], o[2]);
+      swap32t(o[1], o[3]);
+      swap16t(o[0], o[1]);
+      swap16t(o[2], o[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], o[t], acc[m][t]);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i)
+      if (i < CQi) {
+        As[(4 * i + 0) * P + lane] = ru[i].x; As[(4 * i + 1) * P + lane] = ru[i].y; As[(4 * i + 2) * P + lane] = ru[i].z; As[(4 * i + 3) * P + lane] = ru[i].w;
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int flat = qbase + 16 * t + lj;
+      const int r2 = (int)__umulhi((uint32_t)flat, magic_WP);
+      if (!((flat - r2 * WP) < W && r2 < R + H)) continue;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oq = m * 4 + lk;
+        if (oq < CQi) dub[(int64_t)oq * plane + flat] = make_float4(acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]);
+      }
+    }
+    // dWpw tile (mt, nt) += sum over this window's 64 pixels: A[i = ci][k = pixel] B[k = pixel][j = co]; the image was written by this
+    // wave alone (LDS operations of one wave complete in order)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* ar = As + (mt * 16 + lj) * P + lk;
+        const float* br = Bs + (nt * 16 + lj) * P + lk;
+        f32x4 c0 = wacc[mt * NT + nt], c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+          c0 = mfma16(ar[4 * s], br[4 * s], c0);
+          c1 = mfma16(ar[4 * s + 4], br[4 * s + 4], c1);
+        }
+        wacc[mt * NT + nt] = c0 + c1;
+      }
+  }
+  float* mine = part + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * Cin * C;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
+        if (ca < Cin && cb < C) mine[ca * C + cb] = wacc[mt * NT + nt][r];
+      }
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ a, float* __restrict__ b, int n, int accumulate) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i < n) b[i] = accumulate ? b[i] + (float)a[i] : (float)a[i];
@@ -977,6 +1112,59 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_BBP
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
+  return (int)hipGetLastError();
+}
+
+int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
+                                 const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
+                                 const float* wt, int Cin, float* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!dy || !v || !u || !du || !wt || !scratch2C || !dbeta || !dgamma || !dWpw || !workspace || B <= 0 || C <= 0 || Cin <= 0 || C > 64 || Cin > 64) return ORCAI_E_BADARG;
+  const int MTv = (Cin + 15) / 16, NTv = (C + 15) / 16;
+  if (MTv + NTv > 4 || B > 65535) return ORCAI_E_UNSUPPORTED;  // checked before anything is touched: the caller runs orcai_bn_bwd_pointwise + orcai_outer_reduce
+  hipStream_t st = (hipStream_t)stream;
+  const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+  const int tasks = (H * WP + 63) / 64;
+  // waves per snippet: enough workgroups for two per compute unit over the whole grid, at least ~16 windows per wave
+  int gx = (512 + B - 1) / B;
+  if (gx < 1) gx = 1;
+  if (gx * 4 * 16 > tasks) gx = (tasks + 63) / 64;
+  while ((int64_t)gx * B * 4 * Cin * C > workspace_floats && gx > 1) --gx;
+  if ((int64_t)gx * B * 4 * Cin * C > workspace_floats) return ORCAI_E_UNSUPPORTED;
+  double* db = scratch2C;
+  double* dg = scratch2C + 4 * CQ;
+  if (!sums_ready) {
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * CQ, st);
+    if (e != hipSuccess) return (int)e;
+    int gs = (int)((B * plane + 255) / 256);
+    if (gs > 128) gs = 128;
+    hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gs, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  }
+  const size_t lds = (size_t)4 * (MTv + NTv) * 16 * 66 * sizeof(float);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+  dim3 grid(gx, B);
+#define ORCAI_BBW(MT_, NT_)                                                                                                                            \
+  {                                                                                                                                                    \
+    static bool attr_set = false;                                                                                                                      \
+    if (!attr_set) {                                                                                                                                   \
+      hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_pw_wgrad_kernel<MT_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      if (e != hipSuccess) return (int)e;                                                                                                              \
+      attr_set = true;                                                                                                                                 \
+    }                                                                                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_pw_wgrad_kernel<MT_, NT_>), grid, dim3(256), lds, st, dy, v, u, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg, \
+                       inv_count, wt, Cin, du, tasks, magic_for(WP), workspace);                                                                        \
+  }
+  if (MTv == 1 && NTv == 1) ORCAI_BBW(1, 1)
+  else if (MTv == 1 && NTv == 2) ORCAI_BBW(1, 2)
+  else if (MTv == 2 && NTv == 1) ORCAI_BBW(2, 1)
+  else if (MTv == 2 && NTv == 2) ORCAI_BBW(2, 2)
+  else if (MTv == 1 && NTv == 3) ORCAI_BBW(1, 3)
+  else if (MTv == 3 && NTv == 1) ORCAI_BBW(3, 1)
+  else return ORCAI_E_UNSUPPORTED;
+#undef ORCAI_BBW
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Cin * C), 8), dim3(256), 0, st, workspace, gx * B * 4, Cin * C, dWpw);
   hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }

@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
         self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
@@ -609,12 +610,22 @@ class TrunkTrainer:
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
         wt = self._w_pwT(name + "/pointwise", Cin, Cout)  # pointwise^T [Cout][Cin]
+        if self.fused_pw_wgrad and not self.half:
+            # one pass: dv formed per pixel, du = Wpw dv, AND the pointwise weight gradient u (x) dv -- dv is never written or re-read
+            rc = lib.orcai_bn_bwd_pointwise_wgrad(dy.data_ptr(), v.data_ptr(), u.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                                  P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
+                                                  P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, du.data_ptr(), P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                                  self.partials.numel(), st)
+            if rc != N.E_UNSUPPORTED:
+                N.check(rc, "bn_bwd_pointwise_wgrad")
+                self._sep_backward(name, x, relu_in, Cin, Cout, H, W, None, u, du, dr, have_du=True, have_pw_wgrad=True)
+                return
         N.check(self._fn("bn_bwd_pointwise")(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
         self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True)
 
-    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False):
+    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False):
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
@@ -629,8 +640,9 @@ class TrunkTrainer:
             # read-only, and a read-only pass runs faster behind a kernel that wrote ANOTHER tensor (dr) than directly behind the writer
             # of its own input (dv, du) -- DESIGN.md 4.4
             self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
-        N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
-                                         self.partials.numel(), st), "outer_reduce")
+        if not have_pw_wgrad:
+            N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                             self.partials.numel(), st), "outer_reduce")
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
         N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
         if not self.dgrad_first:
@@ -858,7 +870,9 @@ class Trainer:
                     self.train_step(x_in, snippet_stride, B, y_in)
                 side.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                # thread-local capture mode: the dataset's producer thread keeps pinning and uploading the next batches meanwhile (a global-mode
+                # capture is invalidated by another thread's hipHostMalloc and the process aborts)
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                     out = self.train_step(x_in, snippet_stride, B, y_in)
             torch.cuda.current_stream().wait_stream(side)
             # the two warm-up steps moved weights, Adam moments, moving statistics and the step counter (the capture pass ran nothing):

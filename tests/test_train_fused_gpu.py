@@ -1,0 +1,99 @@
+"""Round-3 fusions of the f32 training step, each against the launches it replaces and against float64 arithmetic.
+
+orcai_bn_bwd_pointwise_wgrad: BatchNorm backward apply + du = Wpw dv + the pointwise weight gradient u (x) dv in one pass (dv is never
+written) against orcai_bn_bwd_pointwise + orcai_outer_reduce."""
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _quad_planes(x, ksize):
+    B, C, H, W = x.shape
+    R = ksize // 2
+    WP = (W + R + 3) & ~3
+    CQ = (C + 3) // 4
+    out = np.zeros((B, CQ * 4, H + 2 * R, WP), dtype=np.float32)
+    out[:, :C, R : R + H, :W] = x
+    return np.ascontiguousarray(out.reshape(B, CQ, 4, H + 2 * R, WP).transpose(0, 1, 3, 4, 2))
+
+
+def _from_quad(p, C, H, W, ksize):
+    B, CQ, HP, WP, _ = p.shape
+    R = ksize // 2
+    return p.transpose(0, 1, 4, 2, 3).reshape(B, CQ * 4, HP, WP)[:, :C, R : R + H, :W]
+
+
+@pytest.mark.parametrize("C,Cin,H,W,B,relu,ready", [(30, 16, 12, 21, 2, 1, 0), (30, 30, 37, 171, 3, 0, 1), (10, 12, 9, 14, 5, 1, 0), (20, 30, 8, 70, 2, 0, 0),
+                                                   (32, 32, 5, 6, 1, 1, 0), (16, 40, 7, 9, 2, 0, 0)])
+def test_bn_bwd_pointwise_wgrad_vs_two_kernels(C, Cin, H, W, B, relu, ready):
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C * 7 + Cin + H)
+    k = 3
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    dy, v, u = f(B, C, H, W), 2.0 * f(B, C, H, W), f(B, Cin, H, W)
+    mean, var = 0.3 * f(C), (0.5 + rng.random(C)).astype(np.float32)
+    gamma, beta = 1 + 0.3 * f(C), 0.2 * f(C)
+    wt = f(C, Cin) / 4  # pointwise^T [Cout][Cin]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    md, vd, gd, bd, wd = dev(mean), dev(var), dev(gamma), dev(beta), dev(wt)
+    dyd, vdv, ud = dev(_quad_planes(dy, k)), dev(_quad_planes(v, k)), dev(_quad_planes(u, k))
+    CQi = (Cin + 3) // 4
+    # float64 reference of the sums, dv, du, dWpw
+    inv = 1.0 / np.sqrt(var.astype(np.float64) + 1e-3)
+    xh = (v.astype(np.float64) - mean[None, :, None, None]) * inv[None, :, None, None]
+    de = dy.astype(np.float64)
+    if relu:
+        de = np.where(xh * gamma[None, :, None, None] + beta[None, :, None, None] > 0, de, 0.0)
+    n = B * H * W
+    dbeta_ref, dgamma_ref = de.sum(axis=(0, 2, 3)), (de * xh).sum(axis=(0, 2, 3))
+    dv_ref = (gamma * inv)[None, :, None, None] * (de - dbeta_ref[None, :, None, None] / n - xh * dgamma_ref[None, :, None, None] / n)
+    du_ref = np.einsum("bchw,ci->bihw", dv_ref, wt.astype(np.float64))
+    dW_ref = np.einsum("bihw,bchw->ic", u.astype(np.float64), dv_ref)
+
+    def sums(scratch):  # what orcai_pool_bwd_bn leaves behind when sums_ready = 1
+        s = np.zeros(128)
+        CQ = (C + 3) // 4
+        s[:C], s[4 * CQ : 4 * CQ + C] = dbeta_ref, dgamma_ref
+        scratch.copy_(torch.from_numpy(s))
+
+    out = {}
+    for fused in (False, True):
+        dv = torch.zeros_like(dyd)
+        du = torch.zeros((B, CQi) + tuple(dyd.shape[2:]), dtype=torch.float32, device="cuda")
+        scratch = torch.zeros(128, dtype=torch.float64, device="cuda")
+        if ready:
+            sums(scratch)
+        dbeta, dgamma = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dW = torch.full((Cin, C), 0.5, dtype=torch.float32, device="cuda")  # the entry points ACCUMULATE into the gradient buffer
+        ws = torch.empty(512 * 64 * 64, dtype=torch.float32, device="cuda")
+        st = N.stream_ptr()
+        if fused:
+            rc = lib.orcai_bn_bwd_pointwise_wgrad(N.ptr(dyd), N.ptr(vdv), N.ptr(ud), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(scratch), ready,
+                                                  N.ptr(dbeta), N.ptr(dgamma), N.ptr(wd), Cin, N.ptr(du), N.ptr(dW), N.ptr(ws), ws.numel(), st)
+            if (Cin + 15) // 16 + (C + 15) // 16 > 4:
+                assert rc == N.E_UNSUPPORTED and float(du.abs().max()) == 0.0 and float((dW - 0.5).abs().max()) == 0.0  # refused before anything was touched
+                return
+            N.check(rc, "bn_bwd_pointwise_wgrad")
+        else:
+            N.check(lib.orcai_bn_bwd_pointwise(N.ptr(dyd), N.ptr(vdv), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(scratch), ready, N.ptr(dbeta),
+                                               N.ptr(dgamma), N.ptr(wd), Cin, N.ptr(dv), N.ptr(du), st), "bn_bwd_pointwise")
+            N.check(lib.orcai_outer_reduce(N.ptr(ud), Cin, N.ptr(dv), C, B, H, W, k, 0, 0, 0, N.ptr(dW), N.ptr(ws), ws.numel(), st), "outer_reduce")
+        torch.cuda.synchronize()
+        out[fused] = (_from_quad(du.cpu().numpy(), Cin, H, W, k), dW.cpu().numpy() - 0.5, dbeta.cpu().numpy(), dgamma.cpu().numpy(), du.cpu().numpy())
+    a, b = out[True], out[False]
+    assert np.array_equal(a[0], b[0])  # du: the same arithmetic in the same order
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    scale = max(1.0, np.abs(dW_ref).max())
+    assert np.abs(a[1] - dW_ref).max() <= 2e-5 * scale * np.sqrt(n / 64 + 1), (np.abs(a[1] - dW_ref).max(), scale)
+    assert np.abs(b[1] - dW_ref).max() <= 2e-5 * scale * np.sqrt(n / 64 + 1)
+    assert np.abs(a[0] - du_ref).max() <= 1e-4 * max(1.0, np.abs(du_ref).max())
+    # pads of du stay untouched (zero): the next kernels rely on them
+    pads = a[4].copy()
+    R, CQi_ = 1, (Cin + 3) // 4
+    pads[:, :, R : R + H, :W, :] = 0
+    assert float(np.abs(pads).max()) == 0.0
