@@ -272,8 +272,8 @@ def launch_ranks(n: int, argv: list[str]) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE of the launcher, else 1)")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 200 for the 0.7 ms front-end step)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 3; 50 for the front end: its step is too short to bring the clocks up)")
     ap.add_argument("--workload", default="predict" if "predict" in WORKLOADS else "frontend", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the training-throughput measurement attached to the predict line")
@@ -286,6 +286,10 @@ def main():
 
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.steps is None:
+        args.steps = 200 if args.workload == "frontend" else 20
+    if args.warmup is None:
+        args.warmup = 50 if args.workload == "frontend" else 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without an outer launcher: this process touches no GPU, starts N ranks and relays rank 0's line
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))

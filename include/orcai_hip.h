@@ -71,6 +71,8 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
 
 /* Level-1 selection histogram of an arbitrary f32 array (used when the dB array comes from the
  * caller, i.e. the drop-in preprocess_spectrogram(spectrogram, ...) entry, spectrogram.py:58). */
+int orcai_stft_blocks(int blocks); /* experiments: persistent workgroups of the STFT launch (default 1536); <= 0 queries; returns the previous value */
+int orcai_stft_occupancy(void);     /* workgroups of the STFT kernel per compute unit as the runtime computes it */
 int orcai_hist_level1(const float* x, int64_t n, void* workspace, void* stream);
 
 /* Exact order statistics: the rank_lo-th and rank_hi-th smallest (0-based) of x[0..n), i.e. what
@@ -303,6 +305,17 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
  * in f64. */
 int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
                                int Cout, float* out, float* u_out, double* shards, void* stream);
+/* The input-gradient pass of a k = 3 separable conv (flipped depthwise taps, identity pointwise factor, plane output) with an epilogue that
+ * reads a reference tensor `ref` of the OUTPUT's layout where it stores (train.py:201-219: inside Keras' backward):
+ *   epi 2: the output is the gradient dy of a BatchNorm whose pre-normalisation input is ref: the BatchNorm backward sums
+ *          dbeta = sum g, dgamma = sum g * xhat (g = relu ? dy * [gamma * xhat + beta > 0] : dy) are reduced where dy is stored and left in
+ *          `shards` as scratch2C = dbeta[4 CQo] | dgamma[4 CQo] doubles (shards: 32 * 8 * CQo doubles of workspace): the next
+ *          orcai_bn_bwd_pointwise(_wgrad) call takes sums_ready = 1 and the read pass over (dy, v) is gone;
+ *   epi 3: out = ref > 0 ? out : 0 (the ReLU in front of the conv, folded: no separate orcai_planes_relu_bwd pass).
+ * ORCAI_E_UNSUPPORTED (before anything is touched) for shapes the LDS-tile kernels do not take: the caller runs the separate passes. */
+int orcai_sepconv_planes_epi(const float* in, int B, int Cin, int H, int W, const float* dw, const float* pw, const float* scale, const float* shift, int Cout, float* out,
+                             int epi, const float* ref, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu, double* shards,
+                             void* stream);
 int orcai_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);
 /* The f16 twins (octet planes; shards f64[32][ceil(Cout/8)][16]; flat-tile kernel, any plane width and channel count it handles; the sums are
  * taken on the f32 values before their rounding to f16). */
@@ -341,8 +354,9 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
 /* orcai_bn_bwd_pointwise + the pointwise weight gradient of the same separable conv in ONE pass (train.py:201-219 computes these inside Keras):
  * dv is formed per pixel, multiplied by the transposed pointwise weights (du) AND contracted with the depthwise output u of the forward
  * pass (dWpw[ci][co] += sum_pixels u[ci] dv[co]); dv itself is never written.  workspace: per-wave partial products
- * (>= 4 * Cin * C floats per workgroup).  ORCAI_E_UNSUPPORTED (before anything is touched) when ceil(Cin/16) + ceil(C/16) > 4: the caller
+ * (>= 4 * Cin * C floats per workgroup).  ORCAI_E_UNSUPPORTED (before anything is touched) when ceil(Cin/16) + ceil(C/16) > 6: the caller
  * then runs orcai_bn_bwd_pointwise and orcai_outer_reduce. */
+int orcai_pw_wgrad_tiles(int tiles); /* experiments: widest layer (in 16-channel tiles, both operands) the fused entry accepts, 0 = never; < 0 queries; returns the previous value */
 int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
                                  const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
                                  const float* wt, int Cin, float* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream);

@@ -22,6 +22,8 @@ _SIGNATURES = {
     "orcai_frontend_workspace_bytes": (C.c_size_t, []),
     "orcai_frontend_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orcai_stft_db": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_stft_blocks": (C.c_int, [C.c_int]),
+    "orcai_stft_occupancy": (C.c_int, []),
     "orcai_hist_level1": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_quantile_select": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p]),
     "orcai_frontend_finalize": (C.c_int, [C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
@@ -64,6 +66,7 @@ _SIGNATURES = {
     "orcai_freq_mean_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_conv1d_bwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 3),
     "orcai_bn_bwd_pointwise": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
+    "orcai_pw_wgrad_tiles": (C.c_int, [C.c_int]),
     "orcai_bn_bwd_pointwise_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [c_i64, C.c_void_p]),
     "orcai_pool_res_add_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]),
     "orcai_pool_bwd_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
@@ -74,6 +77,7 @@ _SIGNATURES = {
     "orcai_sepconv_planes": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_u": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
+    "orcai_sepconv_planes_epi": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "orcai_h_sepconv_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_h_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),

@@ -84,6 +84,16 @@ __device__ __forceinline__ int bucket1(uint32_t key) {
   const int hi = 1281 + min(k16 - 0xBE00, 0x4FF);
   return k16 >= 0xBE00 ? hi : lo;
 }
+// The same bucket straight from the float (bucket1(f2key(f)) == bucket1f(f) for every float; tests/test_host_logic.py restates both and checks all 2^16
+// high halves): magnitude bits m16 = bits[30:16], t = clamp(m16 - 0x3DFF, 0, 0x500) counts 1/128-octave steps above 0.125 (0 below),
+// bucket = 1280 +- t by the sign.  7 integer instructions instead of 13 in the STFT kernel's per-bin tail.
+__device__ __forceinline__ int bucket1f(float f) {
+  const int u = (int)__float_as_uint(f);
+  const int sgn = u >> 31;  // 0 or -1
+  const int m16 = (int)(((uint32_t)u >> 16) & 0x7FFFu);  // v_bfe_u32
+  const int t = min(max(m16 - 0x3DFF, 0), 0x500);         // v_med3_i32
+  return 1280 + ((t ^ sgn) - sgn);
+}
 __device__ __forceinline__ void bucket1_range(int b, uint32_t& klo, uint64_t& width) {
   if (b == 0) { klo = 0u; width = 0x3D010000ull; }
   else if (b < 1280) { klo = (0x3D00u + (uint32_t)b) << 16; width = 65536ull; }
@@ -157,6 +167,8 @@ constexpr int ROW_BYTES = 144;               // 16 complex (128 B) + 16 B pad: c
 constexpr int FRAME_BYTES = 16 * ROW_BYTES;  // 2304
 constexpr int WAVE_BYTES = 4 * FRAME_BYTES;  // 9216, also holds the 4 x k_crop output staging (<= 4112 B)
 
+int g_stft_blocks = 1536;  // persistent workgroups of the STFT launch (orcai_stft_blocks): six per compute unit, three resident (profiles/r03_ab_stft_blocks.log: 768 -> 1536 = -3 %)
+
 struct __attribute__((aligned(16))) StftLds {
   unsigned char tile[4][WAVE_BYTES];  // per wave: PCM staging (5 hops) -> 16x16 transpose tile -> output staging
   float2 tw256[256];
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
 
   // One group of 4 frames per wave.  FAST (compile-time): hop 256, all 4 frames inside the recording, the 1280 samples they
   // cover inside the PCM array and 16-byte aligned -> no per-element predicates anywhere in the body.
-  auto process = [&](auto fast_tag, int64_t t0w) {
+  auto process = [&](auto fast_tag, int64_t t0w, const float4& p0, const float4& p1, const float4& p2, const float4& p3, const float4& p4 /*FAST_ONLY: this group's 5 x 16 B per lane, requested one group ahead*/) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int64_t t = t0w + fsub;
     const bool valid = FAST ? true : (t < n_frames);
@@ -211,8 +223,16 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     if constexpr (FAST) {
       float* st = reinterpret_cast<float*>(my_tile);
       const float4* gp = reinterpret_cast<const float4*>(pcm + w0);
+      if constexpr (FAST_ONLY) {
+        reinterpret_cast<float4*>(st)[lane] = p0;
+        reinterpret_cast<float4*>(st)[lane + 64] = p1;
+        reinterpret_cast<float4*>(st)[lane + 128] = p2;
+        reinterpret_cast<float4*>(st)[lane + 192] = p3;
+        reinterpret_cast<float4*>(st)[lane + 256] = p4;
+      } else {
 #pragma unroll
-      for (int u = 0; u < 5; ++u) reinterpret_cast<float4*>(st)[lane + 64 * u] = gp[lane + 64 * u];
+        for (int u = 0; u < 5; ++u) reinterpret_cast<float4*>(st)[lane + 64 * u] = gp[lane + 64 * u];
+      }
       wave_lds_fence();
       const float* fr = st + fsub * 256;
 #pragma unroll
@@ -251,18 +271,27 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     fft16(z);
     wave_lds_fence();  // all lanes have read the tile before it is reused as output staging
 
-    // step 5: real-FFT split.  A = Z[k], B = Z[256-k]: lane (16-k2)&15, register 15-k1 (k2 != 0) or (16-k1)&15 (k2 == 0).
+    // step 5: real-FFT split.  A = Z[k], B = Z[256-k] (lane (16-k2)&15, register 15-k1 for k2 != 0, (16-k1)&15 for k2 == 0): every lane
+    // parks its 16 bins in the wave's tile ([frame][k] complex, 2 KiB + 128 B per frame) and reads the mirrored ones back with a per-lane address --
+    // 16 ds_write_b64 + 16 ds_read_b64 (both conflict-free: the 16 lanes of a frame touch 16 consecutive bins) where round 2 had 32
+    // ds_bpermute + 32 selects for the k2 == 0 lane.
     //   2 X[k] = (A + conj B) + (c - i s)(-i)(A - conj B)        with (c, s) = tw512[k]
-    // in packed form: E = A + conj B, O = (A.im + B.im, B.re - A.re), 2 X = E + (c O.re + s O.im, c O.im - s O.re); power = |2X|^2 / 4.
-    const int src_lane = (lane & 48) | ((16 - l16) & 15);
-    float* stage = reinterpret_cast<float*>(my_tile) + fsub * k_crop;
+    // in packed form: E = A + conj B, O = (A.im + B.im, B.re - A.re), 2 X = E + (c O.re + s O.im, c O.im - s O.re); power = |2X|^2 / 4:
+    // the 1/4 is applied once to the running maximum and, in the dB value, to the argument of the logarithm's clamp (0.25 s >= 1e-10
+    // <=> s >= 4e-10) and as log2(s) - 2 (exact scaling by a power of two; the sum rounds like log2(0.25 s) up to one ulp).
+    c2* zt = reinterpret_cast<c2*>(my_tile + fsub * 2176);  // 257 bins (Z[256] = Z[0]) + pad: frames 0 / 1 (and 2 / 3) of a half-wave land in different bank halves
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) zt[16 * k1 + l16] = z[P16(k1)];
+    if (l16 == 0) zt[256] = z[P16(0)];  // so that bin 256 - k needs no wrap: the mirrored address is one per-lane base + a compile-time offset
+    wave_lds_fence();
+    const c2* zm = zt + (16 - l16);  // Z[256 - (16 k1 + k2)] = zm[16 (15 - k1)]
+    float Lk[(KC > 0 ? (KC + 15) / 16 : 16)];
     const c2 z0 = z[P16(0)];
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
       const c2 A = z[P16(k1)];
-      c2 Bv = (c2){__shfl(z[P16(15 - k1)].x, src_lane, 64), __shfl(z[P16(15 - k1)].y, src_lane, 64)};
-      if (l16 == 0) Bv = z[P16((16 - k1) & 15)];
       const int k = 16 * k1 + l16;
+      const c2 Bv = zm[16 * (15 - k1)];
       const c2 cs = *reinterpret_cast<const c2*>(&lds.tw512[k]);
       c2 E, O, P, T;
       asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(E) : "v"(A), "v"(Bv));                                              // (A.re + B.re, A.im - B.im)
@@ -270,23 +299,30 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
       asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(T) : "v"(O), "v"(cs));                              // (c O.re, c O.im)
       asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(P) : "v"(O), "v"(cs), "v"(T));  // (s O.im + ., -s O.re + .)
       const c2 X2 = E + P;
-      const float p = 0.25f * (X2.x * X2.x + X2.y * X2.y);
-      if (valid) pmax = fmaxf(pmax, p);
-      if (k < k_crop) {
-        const float L = power_to_db(p);
-        stage[k] = L;
-        if (valid) atomicAdd(&lds.hist[bucket1(f2key(L))], 1u);
-      }
+      const float p4 = fmaf(X2.x, X2.x, X2.y * X2.y);  // 4 |X|^2
+      if (valid) pmax = fmaxf(pmax, p4);
+      if (KC > 0 ? (16 * k1 < KC) : true) Lk[KC > 0 ? k1 : k1] = (__builtin_amdgcn_logf(fmaxf(p4, 4.0f * AMIN_POW)) - 2.0f) * DB_PER_LOG2;
     }
+    float Lnyq = 0.0f;
     if (l16 == 0) {  // Nyquist bin 256: X = Re Z0 - Im Z0
       const float x = z0.x - z0.y;
-      const float p = x * x;
-      if (valid) pmax = fmaxf(pmax, p);
-      if (256 < k_crop) {
-        const float L = power_to_db(p);
-        stage[256] = L;
-        if (valid) atomicAdd(&lds.hist[bucket1(f2key(L))], 1u);
+      const float p4 = 4.0f * x * x;
+      if (valid) pmax = fmaxf(pmax, p4);
+      Lnyq = (__builtin_amdgcn_logf(fmaxf(p4, 4.0f * AMIN_POW)) - 2.0f) * DB_PER_LOG2;
+    }
+    wave_lds_fence();  // every mirrored read is done before the tile becomes the output staging
+    float* stage = reinterpret_cast<float*>(my_tile) + fsub * k_crop;
+#pragma unroll
+    for (int k1 = 0; k1 < (KC > 0 ? (KC + 15) / 16 : 16); ++k1) {
+      const int k = 16 * k1 + l16;
+      if (k < k_crop) {
+        stage[k] = Lk[k1];
+        if (valid) atomicAdd(&lds.hist[bucket1f(Lk[k1])], 1u);
       }
+    }
+    if (l16 == 0 && 256 < k_crop) {
+      stage[256] = Lnyq;
+      if (valid) atomicAdd(&lds.hist[bucket1f(Lnyq)], 1u);
     }
     wave_lds_fence();
 
@@ -299,24 +335,52 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
     const int n4 = count >> 2;
     for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
     for (int i = (n4 << 2) + lane; i < count; i += 64) dst[i] = src[i];
-    wave_lds_fence();
+    // The staging tile may be overwritten once its reads have returned (the stores carry their data in registers).  An LDS-only wait:
+    // wave_lds_fence() here made every group end by waiting for its own output stores to be acknowledged (a release fence drains vmcnt).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   };
-  for (int64_t g = g_begin + blockIdx.x; g < g_end; g += gridDim.x) {
-    const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
-    if constexpr (FAST_ONLY) {
-      process(std::true_type{}, t0w);
-    } else {
+  if constexpr (FAST_ONLY) {
+    // The PCM of the NEXT group is requested before the current one is transformed (a wave otherwise starts every group by waiting a full
+    // HBM round trip with only two other waves of its SIMD to cover it): two register sets, the loop unrolled by two so that no set with
+    // loads in flight is ever moved; the request past the last group is clamped to the last one (unconditional, never used).
+    const int64_t G = gridDim.x, g_last = g_end - 1;
+    auto base = [&](int64_t g) {
+      const int64_t gc = g < g_end ? g : g_last;
+      return reinterpret_cast<const float4*>(pcm + (((gc << 4) + (wave << 2)) * (int64_t)hop - (NFFT / 2))) + lane;
+    };
+    int64_t g = g_begin + blockIdx.x;
+    if (g < g_end) {
+      const float4* gp = base(g);
+      float4 a0 = gp[0], a1 = gp[64], a2 = gp[128], a3 = gp[192], a4 = gp[256];
+      while (true) {
+        gp = base(g + G);
+        const float4 b0 = gp[0], b1 = gp[64], b2 = gp[128], b3 = gp[192], b4 = gp[256];
+        process(std::true_type{}, (g << 4) + (wave << 2), a0, a1, a2, a3, a4);
+        g += G;
+        if (g >= g_end) break;
+        gp = base(g + G);
+        a0 = gp[0]; a1 = gp[64]; a2 = gp[128]; a3 = gp[192]; a4 = gp[256];
+        process(std::true_type{}, (g << 4) + (wave << 2), b0, b1, b2, b3, b4);
+        g += G;
+        if (g >= g_end) break;
+      }
+    }
+  } else {
+    for (int64_t g = g_begin + blockIdx.x; g < g_end; g += gridDim.x) {
+      const int64_t t0w = (g << 4) + (wave << 2);  // first frame of this wave
       const int64_t w0 = t0w * (int64_t)hop - (NFFT / 2);
       const bool fast = EVEN_HOP && hop == 256 && w0 >= 0 && ((w0 & 3) == 0) && (w0 + 1280 <= n_samples) && (t0w + 3 < n_frames);
-      if (fast) process(std::true_type{}, t0w);  // wave-uniform
-      else process(std::false_type{}, t0w);
+      const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (fast) process(std::true_type{}, t0w, none, none, none, none, none);  // wave-uniform
+      else process(std::false_type{}, t0w, none, none, none, none, none);
     }
   }
 
   // wave max -> one atomic per wave
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, off, 64));
-  if (lane == 0) atomicMax(&ws->pmax_bits, __float_as_uint(pmax));
+  if (lane == 0) atomicMax(&ws->pmax_bits, __float_as_uint(0.25f * pmax));  // the loop tracked 4 |X|^2 (exact scaling)
   __syncthreads();
   for (int i = tid; i < NB1; i += 256) {
     uint32_t c = lds.hist[i];
@@ -619,7 +683,7 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
   const int64_t n_groups = (n_frames + 15) / 16;
   Workspace* ws = (Workspace*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  auto grid_for_groups = [](int64_t n) { return dim3((unsigned)(n < 256 * 3 ? n : 256 * 3)); };
+  auto grid_for_groups = [](int64_t n) { return dim3((unsigned)(n < g_stft_blocks ? n : g_stft_blocks)); };
   if ((hop & 1) != 0) {
     hipLaunchKernelGGL((stft_db_kernel<false, false, 0>), grid_for_groups(n_groups), dim3(256), 0, st, pcm, n_samples, hop, n_frames, k_crop, out_db, ws,
                        (int64_t)0, n_groups);
@@ -651,6 +715,18 @@ int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64
                        n_groups);
   }
   return (int)hipGetLastError();
+}
+
+int orcai_stft_blocks(int blocks) {  // experiments: workgroups of the persistent STFT launch (default 1536 = twice the three resident per compute unit); < 0 queries
+  const int prev = g_stft_blocks;
+  if (blocks > 0) g_stft_blocks = blocks;
+  return prev;
+}
+
+int orcai_stft_occupancy(void) {  // workgroups of stft_db_kernel<true, true, 171> the runtime says fit one compute unit (LDS: 52 KiB each)
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)stft_db_kernel<true, true, 171>, 256, 0) != hipSuccess) return -1;
+  return n;
 }
 
 int orcai_hist_level1(const float* x, int64_t n, void* workspace, void* stream) {

@@ -697,16 +697,31 @@ __global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* _
 using orcai_lds::glds16;
 using orcai_lds::wait_vm_barrier;
 
-template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, bool STATS = false>
+// EPI (epilogue extras, all on plane output): 0 none; 1 BatchNorm batch statistics of the output (sums / sums of squares -> shards: the training
+// forward); 2 BatchNorm BACKWARD sums of the output taken as the gradient dy of a BatchNorm whose input `ref` has the output's layout: sum g and
+// sum g * xhat with g = dy * [relu gate], xhat = (ref - mean) * inv -> shards (the input-gradient pass of a block's second separable conv
+// produces dy_a: the separate read pass over (dy_a, v_a) is gone); 3 out = ref > 0 ? out : 0 (ReLU backward folded into the
+// input-gradient pass of a block's first separable conv).
+struct EpiRef {
+  const float* ref = nullptr;                                                        // EPI 2, 3: [B][CQo][HP][WP][4]
+  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;  // EPI 2
+  float eps = 0.0f;
+  int relu = 0;
+};
+
+template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, int EPI = 0>
 __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                              float* __restrict__ out, int nstrip, float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
-                                                             double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/4)][8] sums / sums of squares of the output*/) {
+                                                             double* __restrict__ shards = nullptr /*EPI 1, 2: [32][ceil(Cout/4)][8] sums / sums of squares of the output*/,
+                                                             EpiRef er = EpiRef{}) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  constexpr bool STATS = EPI == 1 || EPI == 2;
   static_assert(TR == 4 || TR == 8, "rows (= waves) per workgroup");
-  static_assert(!STATS || (!XP && MT == 2), "statistics epilogue: plane output, two output tiles");
+  static_assert(EPI == 0 || (!XP && MT == 2), "epilogue extras: plane output, two output tiles");
   __shared__ float stat_s[STATS ? TR : 1][4][16];  // STATS: per wave and 16-lane row, the row's 8 sums and 8 sums of squares
+  __shared__ __attribute__((aligned(16))) float bn_s[EPI == 2 ? 4 : 1][EPI == 2 ? MT * 16 : 4];  // EPI 2: mean, inv, gamma, beta per output channel
   static_assert(!(XP && UOUT), "the training forward writes planes");
   __shared__ __attribute__((aligned(16))) float rows_s[2][TR + 2][256];  // [slot][tile row][lane][4]
   __shared__ float pw_s[CQ * 4 * 16 * MT];                               // [(ci * 16 + lj)][m]: a lane's MT A-fragment values are contiguous
@@ -749,6 +764,13 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
     const int co = threadIdx.x;
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
+    if (EPI == 2) {
+      const int cc = co < Cout ? co : 0;
+      bn_s[0][co] = er.mean[cc];
+      bn_s[1][co] = rsqrtf(er.var[cc] + er.eps);
+      bn_s[2][co] = er.gamma[cc];
+      bn_s[3][co] = er.beta[cc];
+    }
   }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
@@ -817,17 +839,32 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
           const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
           v[r] = max2(v[r], pair_ok ? other : v[r]);
         }
-        if (STATS) {
+        if (EPI == 1) {
           const float lv = live ? v[r] : 0.0f;
           st[(MT == 2 ? m : 0) * 4 + r] += lv;
           st[8 + (MT == 2 ? m : 0) * 4 + r] = fmaf(lv, lv, st[8 + (MT == 2 ? m : 0) * 4 + r]);
         }
       }
       const int oq = m * 4 + lk;
-      if (live && oq < CQo) {
-        const int idx = XP ? ((oq * H + row) * WPx + (x >> 1)) : (oq * plane + (R + row) * WP + x);
-        outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      const bool st_ok = live && oq < CQo;
+      const int idx = XP ? ((oq * H + row) * WPx + (x >> 1)) : (oq * plane + (R + row) * WP + x);
+      if (EPI == 2) {
+        float4 rv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st_ok) rv4 = (reinterpret_cast<const float4*>(er.ref) + (int64_t)b * CQo * plane)[idx];
+        const float4 mu4 = reinterpret_cast<const float4*>(bn_s[0])[m * 4 + lk], in4 = reinterpret_cast<const float4*>(bn_s[1])[m * 4 + lk];
+        const float4 g4 = reinterpret_cast<const float4*>(bn_s[2])[m * 4 + lk], b4 = reinterpret_cast<const float4*>(bn_s[3])[m * 4 + lk];
+        const float rvv[4] = {rv4.x, rv4.y, rv4.z, rv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, iv[4] = {in4.x, in4.y, in4.z, in4.w};
+        const float gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (rvv[r] - mu[r]) * iv[r];
+          const bool gate = !er.relu || fmaf(xh, gm[r], bt[r]) > 0.0f;
+          const float gg = (st_ok && gate) ? v[r] : 0.0f;
+          st[m * 4 + r] += gg;
+          st[8 + m * 4 + r] = fmaf(gg, xh, st[8 + m * 4 + r]);
+        }
       }
+      if (st_ok) outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   if (STATS) {
@@ -867,17 +904,19 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 // 8 windows of a 176-pixel-wide plane, 8 chunks at width 44, against 24 row loads of independent windows.  Input quads are a run-time
 // count (no dummy quads).  Two LDS slots, one raw barrier per quad, waits as in sepconv_tile.  Bit-identical to sepconv_kernel<3, MT>.
 // =========================================================================================
-template <int MT, bool XP, bool RELU, bool UOUT, int NWV, bool STATS = false>
+template <int MT, bool XP, bool RELU, bool UOUT, int NWV, int EPI = 0>
 __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                                const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                                const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                                float* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk,
                                                                float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
-                                                               double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/4)][8]*/) {
+                                                               double* __restrict__ shards = nullptr /*EPI 1, 2: [32][ceil(Cout/4)][8]*/, EpiRef er = EpiRef{}) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
+  constexpr bool STATS = EPI == 1 || EPI == 2;
   static_assert(!(XP && UOUT), "the training forward writes planes");
-  static_assert(!STATS || !XP, "statistics epilogue: plane output");
+  static_assert(EPI == 0 || !XP, "epilogue extras: plane output");
   __shared__ float stat_s[STATS ? NWV : 1][4][STATS ? 8 * MT : 1];  // STATS: per wave and 16-lane row, the row's sums and sums of squares
+  __shared__ __attribute__((aligned(16))) float bn_s[EPI == 2 ? 4 : 1][EPI == 2 ? MT * 16 : 4];  // EPI 2: mean, inv, gamma, beta per output channel
   extern __shared__ __attribute__((aligned(16))) float smem_ft[];
   const int CQr = (Cin + 3) >> 2, CQo = (Cout + 3) >> 2;
   float* rows_s = smem_ft;                      // [2][nchunk][64][4]
@@ -919,6 +958,13 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
     const int co = threadIdx.x;
     sc_s[co] = co < Cout ? scale[co] : 0.0f;
     sh_s[co] = co < Cout ? shift[co] : 0.0f;
+    if (EPI == 2) {
+      const int cc = co < Cout ? co : 0;
+      bn_s[0][co] = er.mean[cc];
+      bn_s[1][co] = rsqrtf(er.var[cc] + er.eps);
+      bn_s[2][co] = er.gamma[cc];
+      bn_s[3][co] = er.beta[cc];
+    }
   }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
@@ -995,17 +1041,37 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
           const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
           v[r] = max2(v[r], pair_ok ? other : v[r]);
         }
-        if (STATS) {
+        if (EPI == 1) {
           const float lv = live ? v[r] : 0.0f;
           st[m * 4 + r] += lv;
           st[4 * MT + m * 4 + r] = fmaf(lv, lv, st[4 * MT + m * 4 + r]);
         }
       }
       const int oq = m * 4 + lk;
-      if (live && oq < CQo) {
-        const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
-        outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      const bool st_ok = live && oq < CQo;
+      const int idx = XP ? ((oq * H + (row - R)) * WPx + (x >> 1)) : (oq * plane + flat);
+      if (EPI == 2 || EPI == 3) {
+        float4 rv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st_ok) rv4 = (reinterpret_cast<const float4*>(er.ref) + (int64_t)b * CQo * plane)[idx];
+        const float rvv[4] = {rv4.x, rv4.y, rv4.z, rv4.w};
+        if (EPI == 3) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rvv[r] > 0.0f ? v[r] : 0.0f;
+        } else {
+          const float4 mu4 = reinterpret_cast<const float4*>(bn_s[0])[m * 4 + lk], in4 = reinterpret_cast<const float4*>(bn_s[1])[m * 4 + lk];
+          const float4 g4 = reinterpret_cast<const float4*>(bn_s[2])[m * 4 + lk], b4 = reinterpret_cast<const float4*>(bn_s[3])[m * 4 + lk];
+          const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, iv[4] = {in4.x, in4.y, in4.z, in4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = (rvv[r] - mu[r]) * iv[r];
+            const bool gate = !er.relu || fmaf(xh, gm[r], bt[r]) > 0.0f;
+            const float gg = (st_ok && gate) ? v[r] : 0.0f;
+            st[m * 4 + r] += gg;
+            st[4 * MT + m * 4 + r] = fmaf(gg, xh, st[4 * MT + m * 4 + r]);
+          }
+        }
       }
+      if (st_ok) outb[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
   if (STATS) {  // BatchNorm batch statistics of the tensor just written: the scheme of sepconv_tile_kernel, for any number of output tiles
@@ -1600,12 +1666,27 @@ __global__ __launch_bounds__(512) void conv1d_sigmoid_kernel(const float* __rest
   }
 }
 
+// EPI 2 leaves 32 accumulator copies [32][CQ][8] (sum g | sum g * xhat per channel quad); the BatchNorm backward kernels read
+// scratch2C = dbeta[4 CQ] | dgamma[4 CQ] (doubles): summed and compacted in place by one workgroup (all reads before the first write).
+__global__ __launch_bounds__(256) void bn_bwd_sums_compact_kernel(double* __restrict__ shards, int CQ) {
+  const int t = threadIdx.x;  // output element: t < 4 CQ -> dbeta[t], else dgamma[t - 4 CQ]
+  double tot = 0.0;
+  if (t < 8 * CQ) {
+    const int which = t >= 4 * CQ, c = which ? t - 4 * CQ : t;
+    for (int sh = 0; sh < 32; ++sh) tot += shards[((int64_t)sh * CQ + (c >> 2)) * 8 + which * 4 + (c & 3)];
+  }
+  __syncthreads();
+  if (t < 8 * CQ) shards[t] = tot;
+}
+
 struct SepArgs {
   const float *in, *dw, *pw, *scale, *shift;
   float* out;
   int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
   float* u_out = nullptr;
   double* shards = nullptr;  // strip tiles with the depthwise-output store: BatchNorm statistics of the output in the epilogue
+  int epi = 0;               // 2 / 3: the epilogue extras of the input-gradient passes (EpiRef er), no depthwise-output store
+  EpiRef er;
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
@@ -1621,15 +1702,21 @@ int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
 #define ORCAI_TILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
   hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
-  if (a.out_layout == 2) {
+  if (a.epi == 2) {  // input-gradient pass with the BatchNorm backward sums of its output (no ReLU on load, no depthwise-output store)
+    if constexpr (MT == 2)
+      hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, false, TR, false, 2>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                         a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards, a.er);
+  } else if (a.epi) {
+    return -1;  // EPI 3 lives in the flat-tile kernel only
+  } else if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
   } else if (a.u_out && a.shards) {
     if constexpr (MT == 2) {
       if (a.relu_in)
-        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, true, TR, true, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, true, TR, true, 1>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                            a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards);
       else
-        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, false, TR, true, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, false, TR, true, 1>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                            a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards);
     }
   } else if (a.u_out) {
@@ -1653,15 +1740,22 @@ int launch_sepconv_ftile(hipStream_t st, const SepArgs& a, int tasks) {
 #define ORCAI_FTILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
   hipLaunchKernelGGL((sepconv_ftile_kernel<MT, XP, RELU, UOUT, NWV>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
-  if (a.out_layout == 2) {
+  if (a.epi == 2) {
+    if (lds + sizeof(float) * (NWV * 4 * 8 * MT + 4 * MT * 16) > 64 * 1024) return -1;  // + the kernel's static statistics slots and BatchNorm constants
+    hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, false, NWV, 2>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                       a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards, a.er);
+  } else if (a.epi == 3) {
+    hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, false, NWV, 3>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                       a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards, a.er);
+  } else if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_FTILE_LAUNCH(true, true, false); else ORCAI_FTILE_LAUNCH(true, false, false);
   } else if (a.u_out && a.shards) {
     if (lds + sizeof(float) * NWV * 4 * 8 * MT > 64 * 1024) return -1;  // + the kernel's static statistics slots
     if (a.relu_in)
-      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, true, true, NWV, true>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, true, true, NWV, 1>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                          a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
     else
-      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, true, NWV, true>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, true, NWV, 1>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                          a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
   } else if (a.u_out) {
     if (a.relu_in) ORCAI_FTILE_LAUNCH(false, true, true); else ORCAI_FTILE_LAUNCH(false, false, true);
@@ -1687,14 +1781,14 @@ int launch_sepconv_impl(hipStream_t st, const SepArgs& a) {
         (int64_t)CQ * (a.H + 2) * a.WP < (1ll << 27)) {
       if constexpr (MT == 2) {
         const int VALt = a.out_layout == 2 ? 60 : 62, nstrip = (a.W + VALt - 1) / VALt;
-        if (g_tile_mode == 1 && CQ <= 8 && nstrip >= 2 && a.W * 100 >= nstrip * VALt * 85)
+        if (g_tile_mode == 1 && a.epi != 3 && CQ <= 8 && nstrip >= 2 && a.W * 100 >= nstrip * VALt * 85)
           return CQ <= 4 ? launch_sepconv_tile<2, 4>(st, a, nstrip) : launch_sepconv_tile<2, 8>(st, a, nstrip);
       }
       const int rc = launch_sepconv_ftile<MT>(st, a, tasks);
       if (rc >= 0) return rc;
     }
   }
-  if (a.shards) return ORCAI_E_UNSUPPORTED;  // the statistics epilogue exists in the LDS-tile kernels only
+  if (a.shards || a.epi) return ORCAI_E_UNSUPPORTED;  // the epilogue extras exist in the LDS-tile kernels only
   dim3 grid((tasks + 3) / 4, a.B);
   hipLaunchKernelGGL((sepconv_kernel<KS, MT>), grid, dim3(256), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pw, a.scale, a.shift, a.Cout, a.relu_out,
                      a.out_layout, a.out, tasks, magic_for(a.WP), lo, a.RP, a.H2, a.WP2, a.u_out);
@@ -1831,6 +1925,35 @@ int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, in
   }
   SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, u_out, shards};
   return launch_sepconv<3>(st, a);
+}
+
+int orcai_sepconv_planes_epi(const float* in, int B, int Cin, int H, int W, const float* dw, const float* pw, const float* scale, const float* shift, int Cout, float* out,
+                             int epi, const float* ref, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int relu, double* shards,
+                             void* stream) {
+  if (!in || !dw || !pw || !scale || !shift || !out || !ref || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (epi != 2 && epi != 3)) return ORCAI_E_BADARG;
+  if (epi == 2 && (!mean || !var || !gamma || !beta || !shards)) return ORCAI_E_BADARG;
+  if (((uintptr_t)in & 15) || ((uintptr_t)ref & 15) || B > 65535 || Cout > 64) return ORCAI_E_UNSUPPORTED;
+  // the shapes launch_sepconv_impl<3, MT> hands to the LDS-tile kernels, checked BEFORE anything is touched (as orcai_sepconv_planes_stats)
+  const int CQ = (Cin + 3) / 4, CQo = (Cout + 3) / 4, WP = orcai_padded_width(W, 3), MTv = (Cout + 15) / 16;
+  const int nchunk = (7 * 62 + 64 + 2 * WP + 63) / 64;
+  const size_t lds = (size_t)(2 * nchunk * 256 + CQ * 64 * MTv + 2 * MTv * 16 + 8 * 4 * 8 * MTv + 4 * MTv * 16) * sizeof(float);
+  const int nstrip = (W + 61) / 62;
+  const bool strip = epi == 2 && g_tile_mode == 1 && MTv == 2 && CQ <= 8 && nstrip >= 2 && W * 100 >= nstrip * 62 * 85;
+  if (g_tile_mode == 0 || (int64_t)CQo * (H + 2) * WP >= (1ll << 27) || (int64_t)CQ * (H + 2) * WP >= (1ll << 27) || (!strip && (nchunk > 24 || lds > 64 * 1024)))
+    return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (epi == 2) {
+    hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * CQo * 32, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, WP, 1, Cout, 0, 0, 0, 0, 0, nullptr, epi == 2 ? shards : nullptr};
+  a.epi = epi;
+  a.er.ref = ref;
+  a.er.mean = mean; a.er.var = var; a.er.gamma = gamma; a.er.beta = beta; a.er.eps = eps; a.er.relu = relu;
+  const int rc = launch_sepconv<3>(st, a);
+  if (rc != 0) return rc;
+  if (epi == 2) hipLaunchKernelGGL(bn_bwd_sums_compact_kernel, dim3(1), dim3(256), 0, st, shards, CQo);
+  return (int)hipGetLastError();
 }
 
 int orcai_sepconv_planes_u(const float* in, int B, int Cin, int H, int W, int ksize_planes, int ktap, int relu_in, const float* dw, const float* pw,

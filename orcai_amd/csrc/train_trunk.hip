@@ -328,14 +328,16 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_kernel(const float* dy, const f
 // a wave reads only what it wrote.  Waves walk the windows of one snippet (grid.y) with a stride, accumulate the MT x NT weight-gradient
 // tiles in registers and write one partial product each; add_partials_kernel sums them into dWpw.  dv never reaches HBM (one write and one
 // read of the widest gradient tensor of every separable conv less per step).  Channels: Cin <= 16 MT, C <= 16 NT, (MT + NT) * 16.5 KiB of
-// LDS per workgroup -- used for MT + NT <= 4 (blocks 1 of orcai-V1: 62 % of the trunk's bytes); wider layers keep the two kernels.
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ u /*[B][CQi][HP][WP][4]*/, int C,
+// LDS per four-wave workgroup; beyond MT + NT = 4 workgroups of two waves (three per compute unit at 5 tiles, ~21 KiB per wave) -- used up to
+// MT + NT = 6; measured (profiles/r03_ab_pw_wgrad_tiles.log): a win of 0.42 ms per step at MT + NT <= 4 (block 1 of orcai-V1), a LOSS of 0.28 + 0.10 ms with block 2 on the two-wave
+// workgroups (1.5 waves per SIMD), so the launcher accepts MT + NT <= 4 by default and wider layers keep the two kernels.
+template <int MT, int NT, int NW /*waves per workgroup: 4, or 2 where four wave images would leave one workgroup per compute unit*/>
+__global__ __launch_bounds__(64 * NW) void bn_bwd_pw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ u /*[B][CQi][HP][WP][4]*/, int C,
                                                                int H, int W, int WP, int R, const float* __restrict__ mean, const float* __restrict__ var,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
                                                                const double* __restrict__ dbeta, const double* __restrict__ dgamma, float inv_count,
                                                                const float* __restrict__ wt /*[C][Cin]*/, int Cin, float* __restrict__ du /*[B][CQi][HP][WP][4]*/,
-                                                               int tasks, uint32_t magic_WP, float* __restrict__ part /*[gridDim.y][gridDim.x][4][Cin*C]*/) {
+                                                               int tasks, uint32_t magic_WP, float* __restrict__ part /*[gridDim.y][gridDim.x][NW][Cin*C]*/) {
   constexpr int P = 66, MAXQ = 4 * (MT > NT ? MT : NT);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_kernel(const float* __res
   const float4* ub = reinterpret_cast<const float4*>(u) + (int64_t)b * CQi * plane;
   float4* dub = reinterpret_cast<float4*>(du) + (int64_t)b * CQi * plane;
 
-  for (int task = blockIdx.x * 4 + wave; task < tasks; task += gridDim.x * 4) {
+  for (int task = blockIdx.x * NW + wave; task < tasks; task += gridDim.x * NW) {
     const int qbase = R * WP + task * 64;  // interior rows only; 1 KiB-aligned windows
     const int q = qbase + lane;
     const int row = (int)__umulhi((uint32_t)q, magic_WP);
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_kernel(const float* __res
         wacc[mt * NT + nt] = c0 + c1;
       }
   }
-  float* mine = part + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * Cin * C;
+  float* mine = part + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * Cin * C;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1116,23 +1118,32 @@ int orcai_bn_bwd_pointwise(const float* dy, const float* v, int B, int C, int H,
   return (int)hipGetLastError();
 }
 
+static int g_pw_wgrad_tiles = 4;  // widest layer (ceil(Cin/16) + ceil(C/16)) orcai_bn_bwd_pointwise_wgrad accepts (orcai_pw_wgrad_tiles: experiments)
+
+int orcai_pw_wgrad_tiles(int tiles) {
+  const int prev = g_pw_wgrad_tiles;
+  if (tiles >= 0) g_pw_wgrad_tiles = tiles > 6 ? 6 : tiles;
+  return prev;
+}
+
 int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
                                  const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
                                  const float* wt, int Cin, float* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream) {
   if (!dy || !v || !u || !du || !wt || !scratch2C || !dbeta || !dgamma || !dWpw || !workspace || B <= 0 || C <= 0 || Cin <= 0 || C > 64 || Cin > 64) return ORCAI_E_BADARG;
   const int MTv = (Cin + 15) / 16, NTv = (C + 15) / 16;
-  if (MTv + NTv > 4 || B > 65535) return ORCAI_E_UNSUPPORTED;  // checked before anything is touched: the caller runs orcai_bn_bwd_pointwise + orcai_outer_reduce
+  if (MTv + NTv > g_pw_wgrad_tiles || B > 65535) return ORCAI_E_UNSUPPORTED;  // checked before anything is touched: the caller runs orcai_bn_bwd_pointwise + orcai_outer_reduce
+  const int NWv = MTv + NTv <= 4 ? 4 : 2;
   hipStream_t st = (hipStream_t)stream;
   const int CQ = (C + 3) / 4, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
   const int tasks = (H * WP + 63) / 64;
-  // waves per snippet: enough workgroups for two per compute unit over the whole grid, at least ~16 windows per wave
-  int gx = (512 + B - 1) / B;
+  // workgroups per snippet: two (four-wave) / three-four (two-wave) workgroups per compute unit over the whole grid, at least ~16 windows per wave
+  int gx = ((NWv == 4 ? 512 : 1024) + B - 1) / B;
   if (gx < 1) gx = 1;
-  if (gx * 4 * 16 > tasks) gx = (tasks + 63) / 64;
-  while ((int64_t)gx * B * 4 * Cin * C > workspace_floats && gx > 1) --gx;
-  if ((int64_t)gx * B * 4 * Cin * C > workspace_floats) return ORCAI_E_UNSUPPORTED;
+  if (gx * NWv * 16 > tasks) gx = (tasks + NWv * 16 - 1) / (NWv * 16);
+  while ((int64_t)gx * B * NWv * Cin * C > workspace_floats && gx > 1) --gx;
+  if ((int64_t)gx * B * NWv * Cin * C > workspace_floats) return ORCAI_E_UNSUPPORTED;
   double* db = scratch2C;
   double* dg = scratch2C + 4 * CQ;
   if (!sums_ready) {
@@ -1142,29 +1153,37 @@ int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u
     if (gs > 128) gs = 128;
     hipLaunchKernelGGL(bn_planes_bwd_sums_kernel, dim3(gs, CQ), dim3(256), 0, st, dy, v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
   }
-  const size_t lds = (size_t)4 * (MTv + NTv) * 16 * 66 * sizeof(float);
+  const size_t lds = (size_t)NWv * (MTv + NTv) * 16 * 66 * sizeof(float);
   const float inv_count = (float)(1.0 / ((double)B * H * W));
   dim3 grid(gx, B);
-#define ORCAI_BBW(MT_, NT_)                                                                                                                            \
+#define ORCAI_BBW(MT_, NT_, NW_)                                                                                                                       \
   {                                                                                                                                                    \
     static bool attr_set = false;                                                                                                                      \
     if (!attr_set) {                                                                                                                                   \
-      hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_pw_wgrad_kernel<MT_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+      hipError_t e = hipFuncSetAttribute((const void*)bn_bwd_pw_wgrad_kernel<MT_, NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                                                              \
       attr_set = true;                                                                                                                                 \
     }                                                                                                                                                  \
-    hipLaunchKernelGGL((bn_bwd_pw_wgrad_kernel<MT_, NT_>), grid, dim3(256), lds, st, dy, v, u, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, dg, \
-                       inv_count, wt, Cin, du, tasks, magic_for(WP), workspace);                                                                        \
+    hipLaunchKernelGGL((bn_bwd_pw_wgrad_kernel<MT_, NT_, NW_>), grid, dim3(64 * NW_), lds, st, dy, v, u, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, \
+                       dg, inv_count, wt, Cin, du, tasks, magic_for(WP), workspace);                                                                    \
   }
-  if (MTv == 1 && NTv == 1) ORCAI_BBW(1, 1)
-  else if (MTv == 1 && NTv == 2) ORCAI_BBW(1, 2)
-  else if (MTv == 2 && NTv == 1) ORCAI_BBW(2, 1)
-  else if (MTv == 2 && NTv == 2) ORCAI_BBW(2, 2)
-  else if (MTv == 1 && NTv == 3) ORCAI_BBW(1, 3)
-  else if (MTv == 3 && NTv == 1) ORCAI_BBW(3, 1)
-  else return ORCAI_E_UNSUPPORTED;
+  const int key = MTv * 10 + NTv;
+  switch (key) {
+    case 11: ORCAI_BBW(1, 1, 4) break;
+    case 12: ORCAI_BBW(1, 2, 4) break;
+    case 21: ORCAI_BBW(2, 1, 4) break;
+    case 22: ORCAI_BBW(2, 2, 4) break;
+    case 13: ORCAI_BBW(1, 3, 4) break;
+    case 31: ORCAI_BBW(3, 1, 4) break;
+    case 23: ORCAI_BBW(2, 3, 2) break;
+    case 32: ORCAI_BBW(3, 2, 2) break;
+    case 33: ORCAI_BBW(3, 3, 2) break;
+    case 14: ORCAI_BBW(1, 4, 2) break;
+    case 24: ORCAI_BBW(2, 4, 2) break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
 #undef ORCAI_BBW
-  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Cin * C), 8), dim3(256), 0, st, workspace, gx * B * 4, Cin * C, dWpw);
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for((int64_t)Cin * C), 8), dim3(256), 0, st, workspace, gx * B * NWv, Cin * C, dWpw);
   hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }

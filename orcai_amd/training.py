@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
         self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
         self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
@@ -604,9 +605,10 @@ class TrunkTrainer:
             S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
 
     # ------------------------------------------------------------- backward
-    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr, sums_ready=0):
+    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr, sums_ready=0, epi=None):
         """BatchNorm backward (in place on dy -> dv) fused with the first step of the separable conv's backward (du = Wpw dv),
-        then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv."""
+        then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv.
+        epi: epilogue extra of the input-gradient pass (see _dgrad); returns whether it ran."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
         wt = self._w_pwT(name + "/pointwise", Cin, Cout)  # pointwise^T [Cout][Cin]
@@ -618,14 +620,37 @@ class TrunkTrainer:
                                                   self.partials.numel(), st)
             if rc != N.E_UNSUPPORTED:
                 N.check(rc, "bn_bwd_pointwise_wgrad")
-                self._sep_backward(name, x, relu_in, Cin, Cout, H, W, None, u, du, dr, have_du=True, have_pw_wgrad=True)
-                return
+                return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, None, u, du, dr, have_du=True, have_pw_wgrad=True, epi=epi)
         N.check(self._fn("bn_bwd_pointwise")(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
-        self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True)
+        return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True, epi=epi)
 
-    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False):
+    def _dgrad(self, name, du, Cin, H, W, dr, epi=None) -> bool:
+        """dr = depthwise conv of du with the flipped taps (identity pointwise factor): the gradient w.r.t. the separable conv's input.
+        epi ("bsums", v_ref, bn, relu): dr is the gradient dy of BatchNorm `bn` (pre-normalisation tensor v_ref): its backward sums are reduced
+        in the kernel's epilogue and left in self.scratch; ("relu", x_ref): dr is masked by x_ref > 0 (the ReLU in front of the conv).
+        Returns True when the epilogue ran (k = 3, f32, a shape of the LDS-tile kernels); otherwise the plain pass ran and the caller
+        does the separate launches."""
+        k, P = self.k, self.P
+        dw, eye, zeros = self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64)
+        if epi is not None and self.dgrad_epilogues and k == 3 and not self.half:
+            if epi[0] == "bsums":
+                _, ref, bn, relu = epi
+                mean, var = self.stats[bn]
+                rc = self.lib.orcai_sepconv_planes_epi(du.data_ptr(), self.B, Cin, H, W, dw.data_ptr(), eye.data_ptr(), self._ones(64).data_ptr(), zeros.data_ptr(), Cin, dr.data_ptr(), 2,
+                                                       ref.data_ptr(), mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(), P.W(bn + "/beta").data_ptr(), BN_EPS, relu,
+                                                       self.scratch.data_ptr(), N.stream_ptr())
+            else:
+                rc = self.lib.orcai_sepconv_planes_epi(du.data_ptr(), self.B, Cin, H, W, dw.data_ptr(), eye.data_ptr(), self._ones(64).data_ptr(), zeros.data_ptr(), Cin, dr.data_ptr(), 3,
+                                                       epi[1].data_ptr(), None, None, None, None, 0.0, 0, None, N.stream_ptr())
+            if rc != N.E_UNSUPPORTED:
+                N.check(rc, "sepconv_planes_epi")
+                return True
+        self._sep(du, Cin, H, W, k, 0, dw, eye, zeros, Cin, dr)
+        return False
+
+    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False, epi=None):
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
@@ -635,19 +660,20 @@ class TrunkTrainer:
         if not have_du:  # du = Wpw dv   (pointwise conv with the transposed weights)
             wt = self._w_pwT(name + "/pointwise", Cin, Cout)
             self._sep(dv, Cout, H, W, 1, 0, self._w_ones_dw(Cout), wt, self._zeros(64), Cin, du)
+        epi_ran = False
         if self.dgrad_first:
             # the input gradient (the only kernel of this layer the next layer waits for) first; the two weight-gradient passes are
             # read-only, and a read-only pass runs faster behind a kernel that wrote ANOTHER tensor (dr) than directly behind the writer
             # of its own input (dv, du) -- DESIGN.md 4.4
-            self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
+            epi_ran = self._dgrad(name, du, Cin, H, W, dr, epi)
         if not have_pw_wgrad:
             N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                              self.partials.numel(), st), "outer_reduce")
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
         N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
         if not self.dgrad_first:
-            # dr = depthwise conv of du with the flipped taps (identity pointwise)
-            self._sep(du, Cin, H, W, k, 0, self._w_dw(name, reverse=True), self._w_eye(Cin), self._zeros(64), Cin, dr)
+            epi_ran = self._dgrad(name, du, Cin, H, W, dr, epi)
+        return epi_ran
 
     def backward(self, dfeatv: torch.Tensor) -> None:
         """dfeatv: gradient w.r.t. the pre-BN output of the final separable conv, Keras Reshape layout [B][T][W*36]."""
@@ -682,11 +708,16 @@ class TrunkTrainer:
             if self.dgrad_first:  # behind the kernel that wrote dyb, not behind the one that wrote dout (see _sep_backward)
                 residual_wgrad()
             dya = b[f"dya{i}"]
-            self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1)
+            # the input-gradient pass of sep_b writes dy_a = the gradient of bn_a's output: bn_a's backward sums are reduced in its epilogue
+            sums_a = self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1,
+                                           epi=("bsums", b[f"va{i}"], f"b{i}/bn_a", 1))
             dr = b[f"dr{i}"]
-            self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr)
-            # through the ReLU in front of sep_a, then add the residual branch (scatter-add to the even pixels)
-            if i > 1:  # for block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward applies anyway (mask*mask = mask)
+            # through the ReLU in front of sep_a (folded into the input-gradient pass of sep_a where its kernel has the epilogue), then add the
+            # residual branch (scatter-add to the even pixels).  For block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward
+            # applies anyway (mask * mask = mask)
+            relu_done = self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr,
+                                              sums_ready=1 if sums_a else 0, epi=("relu", x_in) if i > 1 else None)
+            if i > 1 and not relu_done:
                 N.check(self._fn("planes_relu_bwd")(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
                 N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")

