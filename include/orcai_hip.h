@@ -305,6 +305,13 @@ int orcai_bn_planes_stats(const float* v, int B, int C, int H, int W, int ksize,
  * in f64. */
 int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
                                int Cout, float* out, float* u_out, double* shards, void* stream);
+/* orcai_sepconv_planes_stats whose input planes hold the PRE-normalisation tensor v of the BatchNorm (+ ReLU) in front of the conv
+ * (architectures.py:176-183: bn_a + ReLU feed the second separable conv of a block): y = max(fma(v, gamma * inv, beta - mean * gamma * inv), 0)
+ * is formed on load -- the arithmetic of orcai_bn_planes_apply, bit for bit -- and zero outside the image, so the normalised tensor is never
+ * written or re-read.  Same refusal rule (ORCAI_E_UNSUPPORTED before anything is touched). */
+int orcai_sepconv_planes_stats_bn(const float* v_in, int B, int Cin, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                                  float in_eps, const float* dw, const float* pw, const float* scale, const float* shift, int Cout, float* out, float* u_out, double* shards,
+                                  void* stream);
 /* The input-gradient pass of a k = 3 separable conv (flipped depthwise taps, identity pointwise factor, plane output) with an epilogue that
  * reads a reference tensor `ref` of the OUTPUT's layout where it stores (train.py:201-219: inside Keras' backward):
  *   epi 2: the output is the gradient dy of a BatchNorm whose pre-normalisation input is ref: the BatchNorm backward sums
@@ -375,6 +382,9 @@ int orcai_outer_reduce_pixels(int pixels);
 /* dW[tap][c] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient, written in the Keras
  * kernel layout (k, k, C, 1), i.e. straight into the flat gradient buffer) */
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
+/* the same (k = 3) with r = the BatchNorm + ReLU of the pre-normalisation tensor v, formed on load (see orcai_sepconv_planes_stats_bn) */
+int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                      float in_eps, float* dW, void* stream);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);
 /* Keras-Reshape layout f32[B][H][W*C] -> padded channel-quad planes (gradient entering the final separable conv) */

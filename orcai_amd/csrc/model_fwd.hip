@@ -709,16 +709,26 @@ struct EpiRef {
   int relu = 0;
 };
 
-template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, int EPI = 0>
+// BNIN: the input planes hold the PRE-normalisation tensor v of a BatchNorm (+ ReLU): y = max(fma(v, gamma * inv, beta - mean * gamma * inv), 0)
+// is formed where a row leaves LDS -- the same two roundings as orcai_bn_planes_apply, so the conv sees bit for bit the tensor that pass
+// would have materialised -- and forced to zero outside the image (the planes' pads hold v = 0, but "same" padding pads y).
+struct InBn {
+  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;
+  float eps = 0.0f;
+};
+
+template <int MT, int CQ, bool XP, bool RELU, int TR, bool UOUT, int EPI = 0, bool BNIN = false>
 __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                              const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                              float* __restrict__ out, int nstrip, float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
                                                              double* __restrict__ shards = nullptr /*EPI 1, 2: [32][ceil(Cout/4)][8] sums / sums of squares of the output*/,
-                                                             EpiRef er = EpiRef{}) {
+                                                             EpiRef er = EpiRef{}, InBn ib = InBn{}) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   constexpr bool STATS = EPI == 1 || EPI == 2;
   static_assert(TR == 4 || TR == 8, "rows (= waves) per workgroup");
+  static_assert(!BNIN || !RELU, "BNIN carries its own ReLU");
+  __shared__ __attribute__((aligned(16))) float inbn_s[BNIN ? 2 : 1][BNIN ? CQ * 4 : 4];  // BNIN: folded scale, shift per input channel
   static_assert(EPI == 0 || (!XP && MT == 2), "epilogue extras: plane output, two output tiles");
   __shared__ float stat_s[STATS ? TR : 1][4][16];  // STATS: per wave and 16-lane row, the row's 8 sums and 8 sums of squares
   __shared__ __attribute__((aligned(16))) float bn_s[EPI == 2 ? 4 : 1][EPI == 2 ? MT * 16 : 4];  // EPI 2: mean, inv, gamma, beta per output channel
@@ -772,6 +782,12 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
       bn_s[3][co] = er.beta[cc];
     }
   }
+  if (BNIN && threadIdx.x < CQ * 4) {
+    const int ci = threadIdx.x, cc = ci < Cin ? ci : 0;
+    const float sc = ib.gamma[cc] * rsqrtf(ib.var[cc] + ib.eps);  // exactly bn_planes_apply_kernel's arithmetic
+    inbn_s[0][ci] = ci < Cin ? sc : 0.0f;
+    inbn_s[1][ci] = ci < Cin ? ib.beta[cc] - ib.mean[cc] * sc : 0.0f;
+  }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int row = r0 + wave;  // this wave's image row
@@ -794,6 +810,18 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
       float4 rows[3];
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&rows_s[cq & 1][wave + dy][lane * 4]);
+      if (BNIN) {
+        const float4 s4 = reinterpret_cast<const float4*>(inbn_s[0])[cq], t4 = reinterpret_cast<const float4*>(inbn_s[1])[cq];
+        const bool colok = xl >= 0 && xl < W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const bool ok = colok && (row + dy - 1) >= 0 && (row + dy - 1) < H;  // image row of tile row wave + dy
+          rows[dy].x = ok ? fmaxf(fmaf(rows[dy].x, s4.x, t4.x), 0.0f) : 0.0f;
+          rows[dy].y = ok ? fmaxf(fmaf(rows[dy].y, s4.y, t4.y), 0.0f) : 0.0f;
+          rows[dy].z = ok ? fmaxf(fmaf(rows[dy].z, s4.z, t4.z), 0.0f) : 0.0f;
+          rows[dy].w = ok ? fmaxf(fmaf(rows[dy].w, s4.w, t4.w), 0.0f) : 0.0f;
+        }
+      }
       float afrag[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
@@ -904,15 +932,18 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 // 8 windows of a 176-pixel-wide plane, 8 chunks at width 44, against 24 row loads of independent windows.  Input quads are a run-time
 // count (no dummy quads).  Two LDS slots, one raw barrier per quad, waits as in sepconv_tile.  Bit-identical to sepconv_kernel<3, MT>.
 // =========================================================================================
-template <int MT, bool XP, bool RELU, bool UOUT, int NWV, int EPI = 0>
+template <int MT, bool XP, bool RELU, bool UOUT, int NWV, int EPI = 0, bool BNIN = false>
 __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __restrict__ in /*[B][CQ][HP][WP][4]*/, int Cin, int H, int W, int WP,
                                                                const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
                                                                const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                                float* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk,
                                                                float* __restrict__ u_out /*UOUT: [B][CQ][HP][WP][4]*/,
-                                                               double* __restrict__ shards = nullptr /*EPI 1, 2: [32][ceil(Cout/4)][8]*/, EpiRef er = EpiRef{}) {
+                                                               double* __restrict__ shards = nullptr /*EPI 1, 2: [32][ceil(Cout/4)][8]*/, EpiRef er = EpiRef{},
+                                                               InBn ib = InBn{}) {
   constexpr int KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   constexpr bool STATS = EPI == 1 || EPI == 2;
+  static_assert(!BNIN || !RELU, "BNIN carries its own ReLU");
+  __shared__ __attribute__((aligned(16))) float inbn_s[BNIN ? 2 : 1][BNIN ? 64 : 4];  // BNIN: folded scale, shift per input channel (<= 64)
   static_assert(!(XP && UOUT), "the training forward writes planes");
   static_assert(EPI == 0 || !XP, "epilogue extras: plane output");
   __shared__ float stat_s[STATS ? NWV : 1][4][STATS ? 8 * MT : 1];  // STATS: per wave and 16-lane row, the row's sums and sums of squares
@@ -966,6 +997,12 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
       bn_s[3][co] = er.beta[cc];
     }
   }
+  if (BNIN && threadIdx.x < 64) {
+    const int ci = threadIdx.x, cc = ci < Cin ? ci : 0;
+    const float sc = ib.gamma[cc] * rsqrtf(ib.var[cc] + ib.eps);  // exactly bn_planes_apply_kernel's arithmetic
+    inbn_s[0][ci] = ci < Cin ? sc : 0.0f;
+    inbn_s[1][ci] = ci < Cin ? ib.beta[cc] - ib.mean[cc] * sc : 0.0f;
+  }
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int task = bx * NWV + wave;
@@ -982,6 +1019,13 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
   // skipped by a whole wave whose live lanes all sit in the padding columns -> such waves wait for vmcnt(0), see below)
   const bool u_any = UOUT && __builtin_amdgcn_readfirstlane((int)(__ballot(u_live) != 0ull)) != 0;
   const float* rbase = rows_s + (wave * VAL + lane) * 4;
+  int bn_row = 0;
+  bool bn_colok = false;
+  if (BNIN) {  // this lane's pixel of the flat padded plane: row / column once per window
+    const int qq = q < 0 ? 0 : q;
+    bn_row = (int)__umulhi((uint32_t)qq, magic_WP);
+    bn_colok = q >= 0 && (qq - bn_row * WP) < W;
+  }
 
   f32x4 acc[MT][4];
 #pragma unroll
@@ -998,6 +1042,17 @@ __global__ __launch_bounds__(64 * NWV) void sepconv_ftile_kernel(const float* __
     float4 rows[3];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(rs + dy * WP * 4);
+    if (BNIN) {
+      const float4 s4 = reinterpret_cast<const float4*>(inbn_s[0])[cq], t4 = reinterpret_cast<const float4*>(inbn_s[1])[cq];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const bool ok = bn_colok && (bn_row + dy - 1) >= R && (bn_row + dy - 1) < R + H;  // padded-plane row of this lane's pixel, one up / same / one down
+        rows[dy].x = ok ? fmaxf(fmaf(rows[dy].x, s4.x, t4.x), 0.0f) : 0.0f;
+        rows[dy].y = ok ? fmaxf(fmaf(rows[dy].y, s4.y, t4.y), 0.0f) : 0.0f;
+        rows[dy].z = ok ? fmaxf(fmaf(rows[dy].z, s4.z, t4.z), 0.0f) : 0.0f;
+        rows[dy].w = ok ? fmaxf(fmaf(rows[dy].w, s4.w, t4.w), 0.0f) : 0.0f;
+      }
+    }
     float afrag[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
@@ -1687,6 +1742,7 @@ struct SepArgs {
   double* shards = nullptr;  // strip tiles with the depthwise-output store: BatchNorm statistics of the output in the epilogue
   int epi = 0;               // 2 / 3: the epilogue extras of the input-gradient passes (EpiRef er), no depthwise-output store
   EpiRef er;
+  InBn ib;                   // ib.mean != nullptr: BatchNorm + ReLU of the input applied on load (training forward with the statistics epilogue)
 };
 
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
@@ -1712,7 +1768,10 @@ int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
     if (a.relu_in) ORCAI_TILE_LAUNCH(true, true, false); else ORCAI_TILE_LAUNCH(true, false, false);
   } else if (a.u_out && a.shards) {
     if constexpr (MT == 2) {
-      if (a.relu_in)
+      if (a.ib.mean)
+        hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, false, TR, true, 1, true>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                           a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards, EpiRef{}, a.ib);
+      else if (a.relu_in)
         hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, false, true, TR, true, 1>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                            a.Cout, a.relu_out, a.out, nstrip, a.u_out, a.shards);
       else
@@ -1750,8 +1809,11 @@ int launch_sepconv_ftile(hipStream_t st, const SepArgs& a, int tasks) {
   } else if (a.out_layout == 2) {
     if (a.relu_in) ORCAI_FTILE_LAUNCH(true, true, false); else ORCAI_FTILE_LAUNCH(true, false, false);
   } else if (a.u_out && a.shards) {
-    if (lds + sizeof(float) * NWV * 4 * 8 * MT > 64 * 1024) return -1;  // + the kernel's static statistics slots
-    if (a.relu_in)
+    if (lds + sizeof(float) * (NWV * 4 * 8 * MT + (a.ib.mean ? 128 : 0)) > 64 * 1024) return -1;  // + the kernel's static statistics slots (and folded input BatchNorm)
+    if (a.ib.mean)
+      hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, false, true, NWV, 1, true>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
+                         a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards, EpiRef{}, a.ib);
+    else if (a.relu_in)
       hipLaunchKernelGGL((sepconv_ftile_kernel<MT, false, true, true, NWV, 1>), grid, dim3(64 * NWV), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, a.shift,
                          a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
     else
@@ -1905,15 +1967,15 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
   return orcai_sepconv_planes(in, B, Cin, H, W, ksize, ksize, relu_in, dw, pw, scale, shift, Cout, relu_out, out_layout, 0, 0, out, stream);
 }
 
-int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
-                               int Cout, float* out, float* u_out, double* shards, void* stream) {
+static int sepconv_planes_stats_impl(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
+                                     int Cout, float* out, float* u_out, double* shards, const InBn& ib, void* stream) {
   if (!in || !dw || !pw || !scale || !shift || !out || !u_out || !shards || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
-  if (((uintptr_t)in & 15) || B > 65535 || Cout > 64) return ORCAI_E_UNSUPPORTED;
+  if (((uintptr_t)in & 15) || B > 65535 || Cout > 64 || Cin > 64) return ORCAI_E_UNSUPPORTED;
   // the shapes launch_sepconv_impl<3, MT> hands to the LDS-tile kernels, checked BEFORE anything is touched; everything else:
   // ORCAI_E_UNSUPPORTED, and the caller runs orcai_sepconv_planes_u + orcai_bn_planes_stats
   const int CQ = (Cin + 3) / 4, CQo = (Cout + 3) / 4, WP = orcai_padded_width(W, 3), MTv = (Cout + 15) / 16;
   const int nchunk = (7 * 62 + 64 + 2 * WP + 63) / 64;
-  const size_t lds = (size_t)(2 * nchunk * 256 + CQ * 64 * MTv + 2 * MTv * 16 + 8 * 4 * 8 * MTv) * sizeof(float);
+  const size_t lds = (size_t)(2 * nchunk * 256 + CQ * 64 * MTv + 2 * MTv * 16 + 8 * 4 * 8 * MTv + (ib.mean ? 128 : 0)) * sizeof(float);
   const int nstrip = (W + 61) / 62;
   const bool strip = g_tile_mode == 1 && MTv == 2 && CQ <= 8 && nstrip >= 2 && W * 100 >= nstrip * 62 * 85;
   if (g_tile_mode == 0 || (int64_t)CQo * (H + 2) * WP >= (1ll << 27) || (int64_t)CQ * (H + 2) * WP >= (1ll << 27) || (!strip && (nchunk > 24 || lds > 64 * 1024)))
@@ -1924,7 +1986,22 @@ int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, in
     if (e != hipSuccess) return (int)e;
   }
   SepArgs a{in, dw, pw, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, u_out, shards};
+  a.ib = ib;
   return launch_sepconv<3>(st, a);
+}
+
+int orcai_sepconv_planes_stats(const float* in, int B, int Cin, int H, int W, int relu_in, const float* dw, const float* pw, const float* scale, const float* shift,
+                               int Cout, float* out, float* u_out, double* shards, void* stream) {
+  return sepconv_planes_stats_impl(in, B, Cin, H, W, relu_in, dw, pw, scale, shift, Cout, out, u_out, shards, InBn{}, stream);
+}
+
+int orcai_sepconv_planes_stats_bn(const float* v_in, int B, int Cin, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                                  float in_eps, const float* dw, const float* pw, const float* scale, const float* shift, int Cout, float* out, float* u_out, double* shards,
+                                  void* stream) {
+  if (!in_mean || !in_var || !in_gamma || !in_beta) return ORCAI_E_BADARG;
+  InBn ib;
+  ib.mean = in_mean; ib.var = in_var; ib.gamma = in_gamma; ib.beta = in_beta; ib.eps = in_eps;
+  return sepconv_planes_stats_impl(v_in, B, Cin, H, W, 0, dw, pw, scale, shift, Cout, out, u_out, shards, ib, stream);
 }
 
 int orcai_sepconv_planes_epi(const float* in, int B, int Cin, int H, int W, const float* dw, const float* pw, const float* scale, const float* shift, int Cout, float* out,

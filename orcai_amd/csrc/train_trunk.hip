@@ -741,9 +741,17 @@ __device__ __forceinline__ float lsh(float v) {  // value of lane (l + SH): one 
     return lsh<KS, SH - 1>(__uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true)));
 }
 
-template <int KS>
+// BNIN: x holds the pre-normalisation tensor v of the BatchNorm + ReLU in front of the conv; r = max(fma(v, gamma * inv, beta - mean * gamma * inv), 0)
+// inside the image, 0 in the pads (the arithmetic of bn_planes_apply_kernel: the tensor that pass would have materialised, bit for bit).
+struct InBnW {
+  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;
+  float eps = 0.0f;
+  uint32_t magic_WP = 0;
+};
+
+template <int KS, bool BNIN = false>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int RP, int relu_in,
-                                                        float* __restrict__ dW /*[KS*KS][C], Keras (k,k,C,1)*/, int tasks, int tasks_per_wave) {
+                                                        float* __restrict__ dW /*[KS*KS][C], Keras (k,k,C,1)*/, int tasks, int tasks_per_wave, InBnW ib = InBnW{}) {
   constexpr int R = KS / 2, VAL = 64 - 2 * R, KK = KS * KS;
   const int lane = threadIdx.x & 63;
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -758,6 +766,17 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
   const bool contributes = lane >= R && lane < 64 - R;
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BNIN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cq * 4 + j;
+      if (c < C) {
+        bsc[j] = ib.gamma[c] * rsqrtf(ib.var[c] + ib.eps);
+        bsh[j] = ib.beta[c] - ib.mean[c] * bsc[j];
+      }
+    }
+  }
   // the next window's KS + 1 loads are requested before the current window's products (unconditional, clamped; the gradient of a
   // non-contributing lane is zeroed afterwards): two windows in flight per wave
   const int task0 = wv * tasks_per_wave, task_end = min((wv + 1) * tasks_per_wave, tasks);
@@ -783,12 +802,21 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) ac[dy] = an[dy];
     if (AHEAD && task + 1 < task_end) request(task + 1);
+    int brow = 0;
+    bool bcol = false;
+    if (BNIN) {  // this lane's pixel of the flat padded plane (the rows above / below share its column)
+      const int qq = q < 0 ? 0 : q;
+      brow = (int)__umulhi((uint32_t)qq, ib.magic_WP);
+      bcol = q >= 0 && (qq - brow * WP) < W;
+    }
 #pragma unroll
     for (int dy = 0; dy < KS; ++dy) {
       const float4 a4 = ac[dy];
       float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      const bool inside = BNIN && bcol && (brow + dy - R) >= RP && (brow + dy - R) < RP + H;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (BNIN) a[j] = inside ? fmaxf(fmaf(a[j], bsc[j], bsh[j]), 0.0f) : 0.0f;
         if (relu_in) a[j] = fmaxf(a[j], 0.0f);
         if constexpr (KS == 3) {
           acc[j][dy * 3 + 0] = fmaf(lsh<KS, -1>(a[j]), g[j], acc[j][dy * 3 + 0]);
@@ -1259,7 +1287,7 @@ int orcai_outer_reduce_pixels(int pixels) {
   return prev;
 }
 
-int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {
+static int dw_wgrad_impl(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, const InBnW* bn, void* stream) {
   if (!x || !du || !dW || B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0 || ktap > ksize_planes) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
   const int VAL = 64 - 2 * (ktap / 2);
@@ -1268,13 +1296,32 @@ int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, 
   if (tpw < 8) tpw = 8;
   dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, (C + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
+  if (bn) {
+    if (ktap != 3 || (int64_t)(H + 2 * RP) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
+    InBnW ib = *bn;
+    ib.magic_WP = magic_for(WP);
+    hipLaunchKernelGGL((dw_wgrad_kernel<3, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, 0, dW, tasks, tpw, ib);
+    return (int)hipGetLastError();
+  }
   switch (ktap) {
-    case 3: hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
-    case 5: hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
-    case 7: hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
+    case 3: hipLaunchKernelGGL(dw_wgrad_kernel<3>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw, InBnW{}); break;
+    case 5: hipLaunchKernelGGL(dw_wgrad_kernel<5>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw, InBnW{}); break;
+    case 7: hipLaunchKernelGGL(dw_wgrad_kernel<7>, grid, dim3(256), 0, st, x, du, C, H, W, WP, RP, relu_in, dW, tasks, tpw, InBnW{}); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();
+}
+
+int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream) {
+  return dw_wgrad_impl(x, du, B, C, H, W, ksize_planes, ktap, relu_in, dW, nullptr, stream);
+}
+
+int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                      float in_eps, float* dW, void* stream) {
+  if (!in_mean || !in_var || !in_gamma || !in_beta) return ORCAI_E_BADARG;
+  InBnW ib;
+  ib.mean = in_mean; ib.var = in_var; ib.gamma = in_gamma; ib.beta = in_beta; ib.eps = in_eps;
+  return dw_wgrad_impl(v, du, B, C, H, W, 3, 3, 0, dW, &ib, stream);
 }
 
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream) {

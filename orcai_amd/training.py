@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
         self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
         self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
@@ -463,6 +464,25 @@ class TrunkTrainer:
         N.check(self._fn("bn_planes_apply")(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                             P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), st), "bn_planes_apply")
         self.stats[bn] = (mean, var)
+
+    def _bn_apply(self, v, bn, C, H, W, relu, y):
+        """y = [relu](BN(v)) with the batch statistics _bn_fwd left in self.stats[bn] (the fallback of the apply-on-load path)."""
+        P = self.P
+        mean, var = self.stats[bn]
+        N.check(self._fn("bn_planes_apply")(v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, y.data_ptr(), N.stream_ptr()), "bn_planes_apply")
+
+    def _sep_stats_bn(self, v_in, bn_in, Cin, H, W, dw, pw, shift, Cout, out, u_out) -> bool:
+        """_sep_stats whose input is the PRE-normalisation tensor of BatchNorm `bn_in` (+ ReLU): normalised on load, never materialised."""
+        P = self.P
+        mean, var = self.stats[bn_in]
+        rc = self.lib.orcai_sepconv_planes_stats_bn(v_in.data_ptr(), self.B, Cin, H, W, mean.data_ptr(), var.data_ptr(), P.W(bn_in + "/gamma").data_ptr(),
+                                                    P.W(bn_in + "/beta").data_ptr(), BN_EPS, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
+                                                    out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
+        if rc == N.E_UNSUPPORTED:
+            return False
+        N.check(rc, "orcai_sepconv_planes_stats_bn")
+        return True
 
     def _bn_bwd(self, dy, v, bn, C, H, W, relu, dv):
         lib, P, st = self.lib, self.P, N.stream_ptr()
@@ -567,18 +587,32 @@ class TrunkTrainer:
         res_in = prev
         self.dwl = {}
         self.block_in = {}
+        self.on_load = {}  # block -> bn_a + ReLU applied on load by sep_b (y_a not materialised this step)
         for i, f in enumerate(m.filters, start=1):
             h, w, _ = shapes[i - 1]
             self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
-            for tag, x, cin, relu_in, v, y, relu_out in (("a", prev, c, 1, b[f"va{i}"], b[f"ya{i}"], 1), ("b", b[f"ya{i}"], f, 0, b[f"vb{i}"], None, 0)):
-                name = f"b{i}/sep_{tag}"
-                self.dwl[name] = self._w_dw(name)
-                # BN_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel): y_b is never written
-                fused = self.stats_in_epilogue and k == 3 and self._sep_stats(x, cin, h, w, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"),
-                                                                                                P.W(name + "/bias"), f, v, b[f"u_{tag}{i}"])
+            # sep_a -> bn_a (+ ReLU) -> sep_b -> bn_b.  bn_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel):
+            # y_b is never written.  bn_a + ReLU: applied where sep_b (and, in the backward pass, its depthwise weight gradient) load their
+            # input -- y_a is not materialised either -- when sep_b runs on the LDS-tile kernels with the statistics epilogue (k = 3, f32).
+            na, nb = f"b{i}/sep_a", f"b{i}/sep_b"
+            self.dwl[na], self.dwl[nb] = self._w_dw(na), self._w_dw(nb)
+            va, ya, vb = b[f"va{i}"], b[f"ya{i}"], b[f"vb{i}"]
+            fused = self.stats_in_epilogue and k == 3 and self._sep_stats(prev, c, h, w, 1, self.dwl[na], self._w_pw(na + "/pointwise"), P.W(na + "/bias"), f, va, b[f"u_a{i}"])
+            if not fused:
+                self._sep(prev, c, h, w, k, 1, self.dwl[na], self._w_pw(na + "/pointwise"), P.W(na + "/bias"), f, va, u_out=b[f"u_a{i}"])
+            on_load = self.apply_on_load and self.stats_in_epilogue and k == 3 and not self.half
+            self._bn_fwd(va, f"b{i}/bn_a", f, h, w, 1, None if on_load else ya, sums_in_shards=fused)
+            if on_load:
+                on_load = self._sep_stats_bn(va, f"b{i}/bn_a", f, h, w, self.dwl[nb], self._w_pw(nb + "/pointwise"), P.W(nb + "/bias"), f, vb, b[f"u_b{i}"])
+                if not on_load:  # not a shape of the tile kernels: materialise y_a after all
+                    self._bn_apply(va, f"b{i}/bn_a", f, h, w, 1, ya)
+            self.on_load[i] = on_load
+            fused = on_load
+            if not on_load:
+                fused = self.stats_in_epilogue and k == 3 and self._sep_stats(ya, f, h, w, 0, self.dwl[nb], self._w_pw(nb + "/pointwise"), P.W(nb + "/bias"), f, vb, b[f"u_b{i}"])
                 if not fused:
-                    self._sep(x, cin, h, w, k, relu_in, self.dwl[name], self._w_pw(name + "/pointwise"), P.W(name + "/bias"), f, v, u_out=b[f"u_{tag}{i}"])
-                self._bn_fwd(v, f"b{i}/bn_{tag}", f, h, w, relu_out, y if tag == "a" else None, sums_in_shards=fused)
+                    self._sep(ya, f, h, w, k, 0, self.dwl[nb], self._w_pw(nb + "/pointwise"), P.W(nb + "/bias"), f, vb, u_out=b[f"u_b{i}"])
+            self._bn_fwd(vb, f"b{i}/bn_b", f, h, w, 0, None, sums_in_shards=fused)
             # the residual branch reads the block input BEFORE the previous block's Dropout (architectures.py:88-97)
             bmean, bvar = self.stats[f"b{i}/bn_b"]
             N.check(self._fn("pool_res_add_bn")(b[f"vb{i}"].data_ptr(), res_in.data_ptr(), B, f, c, h, w, k, self._w_pw(f"b{i}/res/kernel").data_ptr(),
@@ -605,7 +639,7 @@ class TrunkTrainer:
             S[bn + "/var"].mul_(BN_MOMENTUM).add_(var, alpha=1 - BN_MOMENTUM)
 
     # ------------------------------------------------------------- backward
-    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr, sums_ready=0, epi=None):
+    def _bn_sep_backward(self, dy, v, bn, relu, name, x, relu_in, Cin, Cout, H, W, u, du, dr, sums_ready=0, epi=None, x_bn=None):
         """BatchNorm backward (in place on dy -> dv) fused with the first step of the separable conv's backward (du = Wpw dv),
         then the rest of _sep_backward.  One pass over (dy, v) replaces BN apply + a pointwise pass that re-reads dv.
         epi: epilogue extra of the input-gradient pass (see _dgrad); returns whether it ran."""
@@ -620,11 +654,11 @@ class TrunkTrainer:
                                                   self.partials.numel(), st)
             if rc != N.E_UNSUPPORTED:
                 N.check(rc, "bn_bwd_pointwise_wgrad")
-                return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, None, u, du, dr, have_du=True, have_pw_wgrad=True, epi=epi)
+                return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, None, u, du, dr, have_du=True, have_pw_wgrad=True, epi=epi, x_bn=x_bn)
         N.check(self._fn("bn_bwd_pointwise")(dy.data_ptr(), v.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                            P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                            P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, dy.data_ptr(), du.data_ptr(), st), "bn_bwd_pointwise")
-        return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True, epi=epi)
+        return self._sep_backward(name, x, relu_in, Cin, Cout, H, W, dy, u, du, dr, have_du=True, epi=epi, x_bn=x_bn)
 
     def _dgrad(self, name, du, Cin, H, W, dr, epi=None) -> bool:
         """dr = depthwise conv of du with the flipped taps (identity pointwise factor): the gradient w.r.t. the separable conv's input.
@@ -650,7 +684,7 @@ class TrunkTrainer:
         self._sep(du, Cin, H, W, k, 0, dw, eye, zeros, Cin, dr)
         return False
 
-    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False, epi=None):
+    def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False, epi=None, x_bn=None):
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
@@ -670,7 +704,12 @@ class TrunkTrainer:
             N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                              self.partials.numel(), st), "outer_reduce")
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
-        N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
+        if x_bn is not None:  # x is the pre-normalisation tensor of BatchNorm x_bn (+ ReLU): normalised on load, as the forward conv did
+            mean, var = self.stats[x_bn]
+            N.check(lib.orcai_dw_wgrad_bn(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, mean.data_ptr(), var.data_ptr(), P.W(x_bn + "/gamma").data_ptr(),
+                                          P.W(x_bn + "/beta").data_ptr(), BN_EPS, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad_bn")
+        else:
+            N.check(self._fn("dw_wgrad")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, relu_in, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
         if not self.dgrad_first:
             epi_ran = self._dgrad(name, du, Cin, H, W, dr, epi)
         return epi_ran
@@ -709,8 +748,9 @@ class TrunkTrainer:
                 residual_wgrad()
             dya = b[f"dya{i}"]
             # the input-gradient pass of sep_b writes dy_a = the gradient of bn_a's output: bn_a's backward sums are reduced in its epilogue
-            sums_a = self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"], dya, sums_ready=1,
-                                           epi=("bsums", b[f"va{i}"], f"b{i}/bn_a", 1))
+            on_load = self.on_load.get(i, False)  # sep_b read bn_a + ReLU of v_a on load: its depthwise weight gradient does the same
+            sums_a = self._bn_sep_backward(dyb, b[f"vb{i}"], f"b{i}/bn_b", 0, f"b{i}/sep_b", b[f"va{i}"] if on_load else b[f"ya{i}"], 0, f, f, h, w, b[f"u_b{i}"], b[f"du_b{i}"],
+                                           dya, sums_ready=1, epi=("bsums", b[f"va{i}"], f"b{i}/bn_a", 1), x_bn=f"b{i}/bn_a" if on_load else None)
             dr = b[f"dr{i}"]
             # through the ReLU in front of sep_a (folded into the input-gradient pass of sep_a where its kernel has the epilogue), then add the
             # residual branch (scatter-add to the even pixels).  For block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward

@@ -166,3 +166,58 @@ def test_input_gradient_pass_with_epilogues(C, H, W, B, relu):
     rc = lib.orcai_sepconv_planes_epi(N.ptr(dud), B, C, H, W, N.ptr(dwd), N.ptr(eye), N.ptr(ones), N.ptr(zeros), C, N.ptr(out3), 3, N.ptr(refd), None, None, None, None, 0.0, 0, None, st)
     N.check(rc, "epi 3")
     assert torch.equal(out3, torch.where(refd > 0, plain, torch.zeros_like(plain)))
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,B", [(30, 30, 37, 171, 2), (40, 40, 23, 86, 3), (50, 50, 12, 43, 2), (60, 60, 9, 22, 3), (10, 10, 16, 12, 4), (20, 20, 8, 6, 2), (30, 30, 9, 171, 1)])
+def test_batchnorm_applied_on_load_equals_the_materialised_tensor(Cin, Cout, H, W, B):
+    """orcai_sepconv_planes_stats_bn / orcai_dw_wgrad_bn (BatchNorm + ReLU of the pre-normalisation tensor formed where the conv loads it,
+    zero outside the image) against orcai_bn_planes_apply followed by orcai_sepconv_planes_stats / orcai_dw_wgrad on the materialised
+    tensor: conv output, depthwise output and batch-statistic sums bit for bit (the same two roundings per value), the depthwise weight
+    gradient to float-atomic reordering."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(Cin + H * 3)
+    k = 3
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    v, du = 2.0 * f(B, Cin, H, W), f(B, Cin, H, W)
+    mean, var = 0.3 * f(Cin), (0.5 + rng.random(Cin)).astype(np.float32)
+    gamma, beta = 1 + 0.3 * f(Cin), 0.4 * f(Cin) + 0.3  # beta - mean * scale != 0: the pads would NOT normalise to zero by themselves
+    CQ = (Cin + 3) // 4
+    dw = f(CQ, 9, 4)
+    dw.transpose(0, 2, 1).reshape(CQ * 4, 9)[Cin:] = 0
+    pw = (f(Cin, Cout) / np.sqrt(Cin)).astype(np.float32)  # (a numpy float64 scalar would silently promote the array)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    vd, dud, dwd, pwd = dev(_quad_planes(v, k)), dev(_quad_planes(du, k)), dev(dw), dev(pw)
+    md, vard, gd, bd = dev(mean), dev(var), dev(gamma), dev(beta)
+    ones, shift = torch.ones(64, device="cuda"), dev(f(64))
+    st = N.stream_ptr()
+    y = torch.zeros_like(vd)
+    N.check(lib.orcai_bn_planes_apply(N.ptr(vd), B, Cin, H, W, k, N.ptr(md), N.ptr(vard), N.ptr(gd), N.ptr(bd), 1e-3, 1, N.ptr(y), st), "apply")
+    CQo = (Cout + 3) // 4
+    res = {}
+    for on_load in (False, True):
+        out = torch.zeros((B, CQo) + tuple(vd.shape[2:]), device="cuda")
+        u = torch.zeros_like(vd)
+        shards = torch.zeros(8 * 16 * 32, dtype=torch.float64, device="cuda")
+        if on_load:
+            rc = lib.orcai_sepconv_planes_stats_bn(N.ptr(vd), B, Cin, H, W, N.ptr(md), N.ptr(vard), N.ptr(gd), N.ptr(bd), 1e-3, N.ptr(dwd), N.ptr(pwd), N.ptr(ones), N.ptr(shift), Cout,
+                                                   N.ptr(out), N.ptr(u), N.ptr(shards), st)
+        else:
+            rc = lib.orcai_sepconv_planes_stats(N.ptr(y), B, Cin, H, W, 0, N.ptr(dwd), N.ptr(pwd), N.ptr(ones), N.ptr(shift), Cout, N.ptr(out), N.ptr(u), N.ptr(shards), st)
+        N.check(rc, "stats")
+        dW = torch.zeros((9, Cin), device="cuda")
+        if on_load:
+            N.check(lib.orcai_dw_wgrad_bn(N.ptr(vd), N.ptr(dud), B, Cin, H, W, N.ptr(md), N.ptr(vard), N.ptr(gd), N.ptr(bd), 1e-3, N.ptr(dW), st), "dw_wgrad_bn")
+        else:
+            N.check(lib.orcai_dw_wgrad(N.ptr(y), N.ptr(dud), B, Cin, H, W, k, k, 0, N.ptr(dW), st), "dw_wgrad")
+        torch.cuda.synchronize()
+        res[on_load] = (out, u, shards, dW.cpu().numpy())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-9 * float(res[False][2].abs().max())  # f64 atomics in another order
+    yr = _from_quad(y.cpu().numpy(), Cin, H, W, k).astype(np.float64)
+    yp = np.zeros((B, Cin, H + 2, W + 2))
+    yp[:, :, 1:-1, 1:-1] = yr
+    want = np.stack([[np.einsum("bchw,bchw->c", yp[:, :, dy : dy + H, dx : dx + W], du.astype(np.float64)) for dx in range(3)] for dy in range(3)]).reshape(9, Cin)
+    for r in (res[True][3], res[False][3]):
+        assert np.abs(r - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
