@@ -343,6 +343,19 @@ int orcai_pack_weights(const float* w, const int* desc, int n_desc, float* out, 
 int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy, const float* v, int B, int H, int W, int ksize, const float* mean,
                        const float* var, const float* gamma, const float* beta, float eps, double* scratch, float* dbeta, float* dgamma, float* dW,
                        void* stream);
+/* The entry conv + bn0 of the training forward WITHOUT the pre-normalisation tensor v0 in HBM (architectures.py:164-168; train.py:201-219):
+ *   orcai_conv0_stats     first pass: v0 = fma(conv, scale, shift) is formed as orcai_conv0_affine forms it, only its batch statistics leave
+ *                         the kernel (shards: 32 * 4 * 8 doubles, the layout orcai_bn_finish_sharded(C = 16) reads);
+ *   orcai_conv0_affine_bn second pass: the conv recomputed from the 1-channel input, then y0 = [relu](fma(v0, gamma * inv, beta - mean * gamma * inv))
+ *                         -- the two roundings of orcai_conv0_affine + orcai_bn_planes_apply, so y0 is bit for bit what those launches wrote;
+ *   orcai_conv0_bn_bwd_x  orcai_conv0_bn_bwd with v0 rebuilt per pixel from the input taps (w0 [k*k][16], bias [16]) instead of read; dW accumulates. */
+int orcai_conv0_stats(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift, double* shards,
+                      void* stream);
+int orcai_conv0_affine_bn(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                          const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int relu, float* out, void* stream);
+int orcai_conv0_bn_bwd_x(const float* in, int64_t snippet_stride, const float* dy, int B, int H, int W, int ksize, const float* w0, const float* bias, const float* mean,
+                         const float* var, const float* gamma, const float* beta, float eps, double* scratch2C /*>= 1024 doubles*/, float* dbeta, float* dgamma, float* dW,
+                         float* workspace /*per-workgroup partial weight gradients*/, int64_t workspace_floats, void* stream);
 /* Training forward / backward of the pooling with the BatchNormalization in front of it applied on the fly (architectures.py:
  * 189-196): `s` / `ybn` hold the PRE-BN tensor v; BN(v) = fma(v, gamma*rsqrt(var+eps), beta - mean*that) is monotone per channel,
  * so the maximum (and its position) is taken on v and transformed once.  BN(v) is never materialised. */

@@ -56,9 +56,19 @@ __device__ __forceinline__ void xcd_remap(int& bx, int& by) {
 template <int KS>
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
                                                      const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][4][HP][WP][4]*/, int relu) {
+                                                     const float* __restrict__ shift, float* __restrict__ out /*[B][4][HP][WP][4]*/, int relu,
+                                                     const float* __restrict__ bn_mean = nullptr, const float* __restrict__ bn_var = nullptr,
+                                                     const float* __restrict__ bn_gamma = nullptr, const float* __restrict__ bn_beta = nullptr, float bn_eps = 0.0f) {
+  // bn_mean != nullptr (training forward, second pass): v = fma(acc, scale, shift) as always, then y = fma(v, gamma * inv, beta - mean * gamma * inv)
+  // -- the two roundings of conv0_affine followed by bn_planes_apply, so y0 is bit for bit what those two launches wrote, without v0 in HBM
   constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
   __shared__ float halo[HH][HP_];
+  __shared__ float bn2_s[2][16];
+  if (bn_mean && threadIdx.x < 16) {
+    const float sc = bn_gamma[threadIdx.x] * rsqrtf(bn_var[threadIdx.x] + bn_eps);
+    bn2_s[0][threadIdx.x] = sc;
+    bn2_s[1][threadIdx.x] = bn_beta[threadIdx.x] - bn_mean[threadIdx.x] * sc;
+  }
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const float* src = in + (int64_t)b * snippet_stride;
   for (int i = threadIdx.x; i < HH * HW; i += 256) {
@@ -91,9 +101,83 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ in
       v.y = fmaf(acc[4 * q + 1], scale[4 * q + 1], shift[4 * q + 1]);
       v.z = fmaf(acc[4 * q + 2], scale[4 * q + 2], shift[4 * q + 2]);
       v.w = fmaf(acc[4 * q + 3], scale[4 * q + 3], shift[4 * q + 3]);
+      if (bn_mean) {
+        v.x = fmaf(v.x, bn2_s[0][4 * q + 0], bn2_s[1][4 * q + 0]);
+        v.y = fmaf(v.y, bn2_s[0][4 * q + 1], bn2_s[1][4 * q + 1]);
+        v.z = fmaf(v.z, bn2_s[0][4 * q + 2], bn2_s[1][4 * q + 2]);
+        v.w = fmaf(v.w, bn2_s[0][4 * q + 3], bn2_s[1][4 * q + 3]);
+      }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       o[(int64_t)q * plane] = v;
     }
+  }
+}
+
+// The training forward's FIRST pass over the entry conv: v = fma(conv, scale, shift) is formed exactly as conv0_kernel forms it and only its
+// batch statistics leave the kernel (per channel sum and sum of squares: f32 per thread -> wave (DPP) -> workgroup (LDS) -> one f64 atomic
+// per value and workgroup into one of 32 accumulator copies, the layout orcai_bn_finish_sharded reads).  The second pass (conv0_kernel with
+// the BatchNorm stage) recomputes the conv from the 1-channel input -- 32 MB per batch of 64 -- and writes y0 = relu(bn0(v0)) directly:
+// v0 (0.52 GB per batch) is never written, re-read for its statistics or re-read by the apply pass.
+template <int KS>
+__global__ __launch_bounds__(256) void conv0_stats_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int B,
+                                                           const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, double* __restrict__ shards /*[32][4][8]*/) {
+  constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
+  __shared__ float halo[HH][HP_];
+  __shared__ float red[4][32];
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+  const int ntiles = tx * ty * B;
+  const int py = threadIdx.x / TW, px = threadIdx.x % TW;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { s1[c] = 0.0f; s2[c] = 0.0f; }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // a workgroup walks many tiles: one reduction per workgroup, not per tile
+    const int b = tile / (tx * ty), rem = tile - b * (tx * ty);
+    const int y0 = (rem / tx) * TH, x0 = (rem - (rem / tx) * tx) * TW;
+    const float* src = in + (int64_t)b * snippet_stride;
+    __syncthreads();  // the previous tile's halo reads are done
+    for (int i = threadIdx.x; i < HH * HW; i += 256) {
+      const int r = i / HW, c = i % HW;
+      const int y = y0 + r - R, x = x0 + c - R;
+      halo[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(int64_t)y * W + x] : 0.0f;
+    }
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) {
+        const float v = halo[py + dy][px + dx];
+        const float* wt = w + (dy * KS + dx) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, wt[c], acc[c]);
+      }
+    const bool live = (y0 + py) < H && (x0 + px) < W;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float v = live ? fmaf(acc[c], scale[c], shift[c]) : 0.0f;
+      s1[c] += v;
+      s2[c] = fmaf(v, v, s2[c]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    float a = s1[c], q = s2[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) { red[wave][c] = a; red[wave][16 + c] = q; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const double tot = ((double)red[0][threadIdx.x] + (double)red[1][threadIdx.x]) + ((double)red[2][threadIdx.x] + (double)red[3][threadIdx.x]);
+    const int isq = threadIdx.x >> 4, c = threadIdx.x & 15;
+    atomicAdd(&shards[((int64_t)(blockIdx.x & 31) * 4 + (c >> 2)) * 8 + isq * 4 + (c & 3)], tot);
   }
 }
 
@@ -1921,6 +2005,39 @@ int orcai_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, in
     case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
     case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
     case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_stats(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift, double* shards,
+                      void* stream) {
+  if (!in || !w || !scale || !shift || !shards || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  const int64_t ntiles = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * B;
+  if (ntiles >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048));  // eight workgroups per compute unit, ~17 tiles each at batch 64
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * 4 * 32, st);
+  if (e != hipSuccess) return (int)e;
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_stats_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, B, w, scale, shift, shards); break;
+    case 5: hipLaunchKernelGGL(conv0_stats_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, B, w, scale, shift, shards); break;
+    case 7: hipLaunchKernelGGL(conv0_stats_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, B, w, scale, shift, shards); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_affine_bn(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                          const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int relu, float* out, void* stream) {
+  if (!in || !w || !scale || !shift || !out || !bn_mean || !bn_var || !bn_gamma || !bn_beta || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  dim3 grid((W + 31) / 32, (H + 7) / 8, B);
+  hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, ksize);
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL(conv0_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps); break;
+    case 5: hipLaunchKernelGGL(conv0_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps); break;
+    case 7: hipLaunchKernelGGL(conv0_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, out, relu, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();

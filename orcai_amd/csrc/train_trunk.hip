@@ -981,6 +981,115 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- bn0 backward with v0 RECOMPUTED from the 1-channel input
+// The training forward no longer stores v0 = conv0(x) + bias (model_fwd.hip: conv0_stats_kernel + conv0_kernel's BatchNorm stage): the two
+// kernels of bn0's backward rebuild it per pixel from the k x k input taps they load anyway -- the fma chain of conv0_kernel in its order,
+// then fma(acc, 1, bias): bit for bit the value the forward pass normalised -- instead of reading 0.52 GB of v0 each.
+// Work distribution of conv0_kernel (8 x 32-pixel tiles, the input halo staged once per tile in LDS, thread = pixel), one channel quad per
+// blockIdx.y, persistent over the tiles: per-thread partial sums live in registers across ~70 tiles and are reduced once per workgroup.
+template <int KS, bool WGRAD>
+__global__ __launch_bounds__(256) void conv0_bn_bwd_x_kernel(const float* __restrict__ in, int64_t snippet_stride, const float* __restrict__ dy, int H, int W, int WP, int B,
+                                                              const float* __restrict__ w0 /*[KS*KS][16]*/, const float* __restrict__ bias,
+                                                              const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, double* __restrict__ shards /*!WGRAD: [32][4][8] sum g | sum g xhat*/,
+                                                              const double* __restrict__ dbeta, const double* __restrict__ dgamma, float inv_count,
+                                                              float* __restrict__ part /*WGRAD: [gridDim.x][KS*KS*16] partial weight gradients*/) {
+  constexpr int TH = 8, TW = 32, R = KS / 2, KK = KS * KS, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1, NACC = WGRAD ? 4 * KK : 8;
+  __shared__ float halo[HH][HP_];
+  __shared__ float red[4][NACC];
+  const int cq = blockIdx.y;
+  const int plane = (H + 2 * R) * WP;
+  float mu[4], inv[4], g[4], bt[4], c1[4], c2[4], wq[KK][4], bs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cq * 4 + k;
+    mu[k] = mean[c]; inv[k] = rsqrtf(var[c] + eps); g[k] = gamma[c]; bt[k] = beta[c]; bs[k] = bias[c];
+    c1[k] = WGRAD ? (float)dbeta[c] * inv_count : 0.0f;
+    c2[k] = WGRAD ? (float)dgamma[c] * inv_count : 0.0f;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) wq[t][k] = w0[t * 16 + c];
+  }
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+  const int ntiles = tx * ty * B;
+  const int py = threadIdx.x / TW, px = threadIdx.x % TW;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tx * ty), rem = tile - b * (tx * ty);
+    const int y0 = (rem / tx) * TH, x0 = (rem - (rem / tx) * tx) * TW;
+    const float* src = in + (int64_t)b * snippet_stride;
+    const int y = y0 + py, x = x0 + px;
+    const bool live = y < H && x < W;
+    // the gradient of this pixel's quad: requested before the halo is staged
+    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) d4 = (reinterpret_cast<const float4*>(dy) + ((int64_t)b * 4 + cq) * plane)[(y + R) * WP + x];
+    __syncthreads();  // the previous tile's halo reads are done
+    for (int i = threadIdx.x; i < HH * HW; i += 256) {
+      const int r = i / HW, c = i % HW;
+      const int yy = y0 + r - R, xx = x0 + c - R;
+      halo[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(int64_t)yy * W + xx] : 0.0f;
+    }
+    __syncthreads();
+    float a[KK];
+#pragma unroll
+    for (int dyy = 0; dyy < KS; ++dyy)
+#pragma unroll
+      for (int dx = 0; dx < KS; ++dx) a[dyy * KS + dx] = halo[py + dyy][px + dx];
+    const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    float gq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float cv = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) cv = fmaf(a[t], wq[t][k], cv);  // conv0_kernel's chain, taps in (dy, dx) order
+      const float v = fmaf(cv, 1.0f, bs[k]);                        // ... and its fma(acc, scale = 1, shift = bias)
+      const float xh = (v - mu[k]) * inv[k];
+      const float de = (live && fmaf(xh, g[k], bt[k]) > 0.0f) ? dd[k] : 0.0f;  // bn0 is followed by a ReLU (architectures.py:167-168)
+      if (WGRAD) {
+        gq[k] = live ? g[k] * inv[k] * (de - c1[k] - xh * c2[k]) : 0.0f;
+      } else {
+        acc[k] += de;
+        acc[4 + k] = fmaf(de, xh, acc[4 + k]);
+      }
+    }
+    if (WGRAD) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k * KK + t] = fmaf(a[t], gq[k], acc[k * KK + t]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const float tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (WGRAD) {
+      const int k = threadIdx.x / KK, t = threadIdx.x - k * KK;
+      part[(int64_t)blockIdx.x * (KK * 16) + t * 16 + cq * 4 + k] = tot;  // Keras layout [tap][filter]; every (workgroup, quad) owns its slots
+    } else {
+      atomicAdd(&shards[((int64_t)(blockIdx.x & 31) * 4 + cq) * 8 + threadIdx.x], (double)tot);  // [sum g (4) | sum g xhat (4)] of this quad
+    }
+  }
+}
+
+// [32][4][8] accumulator copies -> scratch2C = dbeta[16] | dgamma[16] (doubles), in place (all reads before the first write)
+__global__ void conv0_sums_compact_kernel(double* __restrict__ shards) {
+  const int t = threadIdx.x;  // 0..31: dbeta[t] for t < 16, dgamma[t - 16] beyond
+  const int which = t >> 4, c = t & 15;
+  double tot = 0.0;
+  for (int sh = 0; sh < 32; ++sh) tot += shards[((int64_t)sh * 4 + (c >> 2)) * 8 + which * 4 + (c & 3)];
+  __syncthreads();
+  shards[t] = tot;
+}
+
 // ---------------------------------------------------------------- kernel-layout copies of the trunk weights, one launch per step
 // desc[i] = {type, src offset, dst offset, C, aux}: type 0 = Keras depthwise (k,k,C,1) -> [ceil(C/4)][k*k][4] (aux = k*k; zero taps for
 // the padding channels), type 1 = the same with the taps reversed (input-gradient conv), type 2 = pointwise (1,1,Cin,Cout) ->
@@ -1363,6 +1472,43 @@ int orcai_conv0_bn_bwd(const float* in, int64_t snippet_stride, const float* dy,
     case 7: hipLaunchKernelGGL(conv0_bn_wgrad_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, dy, v, H, W, WP, B, mean, var, gamma, beta, eps, db, dg, inv_count, dW); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_bn_bwd_x(const float* in, int64_t snippet_stride, const float* dy, int B, int H, int W, int ksize, const float* w0, const float* bias, const float* mean,
+                         const float* var, const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, float* workspace,
+                         int64_t workspace_floats, void* stream) {
+  if (!in || !dy || !w0 || !bias || !dW || !scratch2C || !dbeta || !dgamma || !workspace || B <= 0) return ORCAI_E_BADARG;
+  if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = 16, R = ksize / 2, WP = orcai_padded_width(W, ksize), KK = ksize * ksize;
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  const int64_t ntiles = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * B;
+  if (plane >= (1ll << 31) || ntiles >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  int gx = (int)(ntiles < 512 ? ntiles : 512);  // x 4 quads: eight workgroups per compute unit
+  if ((int64_t)gx * KK * 16 > workspace_floats) gx = (int)(workspace_floats / (KK * 16));
+  if (gx < 1) return ORCAI_E_BADARG;
+  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 8 * 4 * 32, st);  // 32 accumulator copies
+  if (e != hipSuccess) return (int)e;
+  double* db = scratch2C;
+  double* dg = scratch2C + 16;
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+  dim3 grid(gx, 4);
+#define ORCAI_C0X(KS_)                                                                                                                                     \
+  hipLaunchKernelGGL((conv0_bn_bwd_x_kernel<KS_, false>), grid, dim3(256), 0, st, in, snippet_stride, dy, H, W, WP, B, w0, bias, mean, var, gamma, beta, eps, scratch2C, \
+                     (const double*)nullptr, (const double*)nullptr, inv_count, (float*)nullptr);                                                           \
+  hipLaunchKernelGGL(conv0_sums_compact_kernel, dim3(1), dim3(32), 0, st, scratch2C);                                                                       \
+  hipLaunchKernelGGL((conv0_bn_bwd_x_kernel<KS_, true>), grid, dim3(256), 0, st, in, snippet_stride, dy, H, W, WP, B, w0, bias, mean, var, gamma, beta, eps,  \
+                     (double*)nullptr, db, dg, inv_count, workspace)
+  switch (ksize) {
+    case 3: ORCAI_C0X(3); break;
+    case 5: ORCAI_C0X(5); break;
+    case 7: ORCAI_C0X(7); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_C0X
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for(KK * 16), 8), dim3(256), 0, st, workspace, gx, KK * 16, dW);
   hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }

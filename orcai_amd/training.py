@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
         self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
@@ -580,9 +581,21 @@ class TrunkTrainer:
         H, W = m.input_hw
         k = self.k
         shapes = m.stage_shapes()
-        N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
-                                         0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
-        self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+        self.v0_stored = self.half or not self.conv0_two_pass
+        if self.v0_stored:
+            N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                             0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
+            self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+        else:
+            # two passes over the 1-channel input instead of three over the 16-channel v0: statistics only, then conv + bn0 + ReLU -> y0; v0 itself
+            # is never written (the backward pass rebuilds it from the input taps: orcai_conv0_bn_bwd_x)
+            w0, b0, ones = P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(), self._ones(16).data_ptr()
+            mean0, var0 = P.B("bn0/mean"), P.B("bn0/var")
+            N.check(lib.orcai_conv0_stats(src.data_ptr(), snippet_stride, B, H, W, k, w0, ones, b0, self.scratch.data_ptr(), st), "conv0_stats")
+            N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), B, 16, H, W, mean0.data_ptr(), var0.data_ptr(), st), "bn_finish_sharded")
+            self.stats["bn0"] = (mean0, var0)
+            N.check(lib.orcai_conv0_affine_bn(src.data_ptr(), snippet_stride, B, H, W, k, w0, ones, b0, mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(),
+                                              P.W("bn0/beta").data_ptr(), BN_EPS, 1, b["y0"].data_ptr(), st), "conv0_affine_bn")
         prev, c = b["y0"], 16
         res_in = prev
         self.dwl = {}
@@ -766,9 +779,15 @@ class TrunkTrainer:
             dprev = dr
         H, W = m.input_hw
         mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
-        N.check(self._fn("conv0_bn_bwd")(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
-                                         P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
-                                         P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
+        if self.v0_stored:
+            N.check(self._fn("conv0_bn_bwd")(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
+                                             P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
+                                             P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
+        else:
+            N.check(lib.orcai_conv0_bn_bwd_x(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), B, H, W, k, P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(),
+                                             mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(),
+                                             P.G("bn0/beta").data_ptr(), P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), self.partials.data_ptr(), self.partials.numel(),
+                                             st), "conv0_bn_bwd_x")
         # conv0/bias feeds bn0: zero gradient (see _sep_backward)
 
 

@@ -221,3 +221,56 @@ def test_batchnorm_applied_on_load_equals_the_materialised_tensor(Cin, Cout, H, 
     want = np.stack([[np.einsum("bchw,bchw->c", yp[:, :, dy : dy + H, dx : dx + W], du.astype(np.float64)) for dx in range(3)] for dy in range(3)]).reshape(9, Cin)
     for r in (res[True][3], res[False][3]):
         assert np.abs(r - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("H,W,B,k", [(37, 171, 2, 3), (16, 12, 5, 3), (9, 33, 3, 5), (8, 7, 2, 7)])
+def test_entry_conv_in_two_passes_without_v0(H, W, B, k):
+    """orcai_conv0_stats + orcai_bn_finish_sharded + orcai_conv0_affine_bn against orcai_conv0_affine + orcai_bn_planes_stats +
+    orcai_bn_planes_apply: y0 bit for bit, batch statistics to summation order; orcai_conv0_bn_bwd_x (v0 rebuilt from the input taps)
+    against orcai_conv0_bn_bwd on the stored v0: gradients to float-atomic reordering."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(H * 7 + W)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    x = dev(rng.random((B, H, W), dtype=np.float32))
+    w0, bias, ones = dev(f(k * k, 16) / k), dev(0.1 * f(16)), torch.ones(16, device="cuda")
+    gamma, beta = dev(1 + 0.3 * f(16)), dev(0.2 * f(16))
+    R, WP = k // 2, (W + k // 2 + 3) & ~3
+    shape = (B, 4, H + 2 * R, WP, 4)
+    st = N.stream_ptr()
+    # stored path
+    v0, y_a = torch.zeros(shape, device="cuda"), torch.zeros(shape, device="cuda")
+    mean_a, var_a = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+    scratch = torch.zeros(8 * 16 * 32, dtype=torch.float64, device="cuda")
+    N.check(lib.orcai_conv0_affine(N.ptr(x), H * W, B, H, W, k, N.ptr(w0), N.ptr(ones), N.ptr(bias), 0, N.ptr(v0), st), "conv0_affine")
+    N.check(lib.orcai_bn_planes_stats(N.ptr(v0), B, 16, H, W, k, N.ptr(scratch), N.ptr(mean_a), N.ptr(var_a), st), "bn_planes_stats")
+    N.check(lib.orcai_bn_planes_apply(N.ptr(v0), B, 16, H, W, k, N.ptr(mean_a), N.ptr(var_a), N.ptr(gamma), N.ptr(beta), 1e-3, 1, N.ptr(y_a), st), "apply")
+    # two passes
+    y_b = torch.zeros(shape, device="cuda")
+    mean_b, var_b = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+    N.check(lib.orcai_conv0_stats(N.ptr(x), H * W, B, H, W, k, N.ptr(w0), N.ptr(ones), N.ptr(bias), N.ptr(scratch), st), "conv0_stats")
+    N.check(lib.orcai_bn_finish_sharded(N.ptr(scratch), B, 16, H, W, N.ptr(mean_b), N.ptr(var_b), st), "finish")
+    assert float((mean_a - mean_b).abs().max()) <= 2e-6 * max(1.0, float(mean_a.abs().max())) and float((var_a - var_b).abs().max()) <= 1e-5 * float(var_a.abs().max())
+    # with the SAME statistics the second pass reproduces the materialised tensor bit for bit
+    N.check(lib.orcai_conv0_affine_bn(N.ptr(x), H * W, B, H, W, k, N.ptr(w0), N.ptr(ones), N.ptr(bias), N.ptr(mean_a), N.ptr(var_a), N.ptr(gamma), N.ptr(beta), 1e-3, 1,
+                                      N.ptr(y_b), st), "conv0_affine_bn")
+    assert torch.equal(y_a, y_b)
+    # backward
+    dy = torch.zeros(shape, device="cuda")
+    dy[:, :, R : R + H, :W, :] = dev(f(B, 4, H, W, 4))
+    out = {}
+    for recompute in (False, True):
+        dbeta, dgamma, dW = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda"), torch.zeros((k * k, 16), device="cuda")
+        if recompute:
+            ws = torch.empty(512 * 64 * 64, device="cuda")
+            N.check(lib.orcai_conv0_bn_bwd_x(N.ptr(x), H * W, N.ptr(dy), B, H, W, k, N.ptr(w0), N.ptr(bias), N.ptr(mean_a), N.ptr(var_a), N.ptr(gamma), N.ptr(beta), 1e-3,
+                                             N.ptr(scratch), N.ptr(dbeta), N.ptr(dgamma), N.ptr(dW), N.ptr(ws), ws.numel(), st), "conv0_bn_bwd_x")
+        else:
+            N.check(lib.orcai_conv0_bn_bwd(N.ptr(x), H * W, N.ptr(dy), N.ptr(v0), B, H, W, k, N.ptr(mean_a), N.ptr(var_a), N.ptr(gamma), N.ptr(beta), 1e-3, N.ptr(scratch),
+                                           N.ptr(dbeta), N.ptr(dgamma), N.ptr(dW), st), "conv0_bn_bwd")
+        torch.cuda.synchronize()
+        out[recompute] = [t.cpu().numpy() for t in (dbeta, dgamma, dW)]
+    for a, b_, name in zip(out[True], out[False], ("dbeta", "dgamma", "dW")):
+        assert np.abs(a - b_).max() <= 2e-5 * max(1.0, np.abs(b_).max()), (name, np.abs(a - b_).max())
