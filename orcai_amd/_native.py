@@ -55,6 +55,7 @@ _SIGNATURES = {
     "orcai_masked_bce_w": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_l2_value": (C.c_int, [C.c_void_p, c_i64, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "orcai_lstm_split": (C.c_int, [C.c_int]),
     "orcai_lstm_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_h_lstm_train_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_lstm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

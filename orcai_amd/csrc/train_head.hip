@@ -623,6 +623,109 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_h_kernel(const float* __
   }
 }
 
+// The f32 path's training recurrence with the recurrent product on f16 MFMA at f32 accuracy.  A step of lstm_train_fwd_kernel is bound by ONE
+// compute unit's f32 MFMA rate (64 x v_mfma_f32_16x16x4_f32 of 32 cycles per wave and step, four waves per SIMD: 3.4 of the step's ~7 us), and
+// training at batch 64 keeps 8 compute units busy.  Here every operand is split into two f16 numbers, x = hi + lo / 4096 with hi = f16(x) and
+// lo = f16((x - hi) * 4096) (the scaling keeps lo a NORMAL f16 number for |x| down to 2^-14 / 4096; a product of two f16 numbers is exact in the
+// MFMA's f32 accumulator), and the product h U is the sum of hi*hi (one accumulator, started from the input projection) and hi*lo + lo*hi (a
+// second accumulator, scaled back by 2^-12 at the end); the dropped lo*lo term is 2^-24 of the product -- the rounding of an f32 multiply.
+// 24 MFMAs of 16 cycles per wave and step instead of 64 of 32.  h in [-1, 1] and the recurrent weights are O(0.1): no range issue.  Gate
+// arithmetic, cell state and every stored tensor in f32 as before.
+// x = hi + lo / 4096 with two f16 numbers that are NORMAL (or zero) whatever the matrix unit does with f16 denormals: a value below the smallest
+// normal f16 number travels in lo alone.  Exact to 2^-22 relative for |x| >= 2^-14, to 2^-11 relative (2^-25 of an operand scaled to 1) below.
+__device__ __forceinline__ void split_f16(float x, lh16& hi, lh16& lo) {
+  const lh16 h = fabsf(x) >= 6.103515625e-05f ? (lh16)x : (lh16)0.0f;
+  hi = h;
+  lo = (lh16)((x - (float)h) * 4096.0f);
+}
+
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_train_fwd_split_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
+                                                                      int B, int T, float* __restrict__ out /*[B][T][2U]*/, float* __restrict__ gates, float* __restrict__ cstate) {
+  constexpr int KB = U / 32, HPh = U + 8;  // k blocks of 32; row pitch in halves (16-byte multiple)
+  constexpr float LO_INV = 1.0f / 4096.0f;
+  __shared__ __attribute__((aligned(16))) lh16 hhi[2][16][HPh];
+  __shared__ __attribute__((aligned(16))) lh16 hlo[2][16][HPh];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  lh16x8 uhi[2][KB], ulo[2][KB];  // B[k = 32 kb + 8 lk + e][col = lj] of gate-column tile nt
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        lh16 hi, lo;
+        split_f16(Ud[(int64_t)(kb * 32 + lk * 8 + e) * (4 * U) + wave * 32 + nt * 16 + lj], hi, lo);
+        uhi[nt][kb][e] = hi;
+        ulo[nt][kb][e] = lo;
+      }
+  for (int i = tid; i < 2 * 16 * HPh; i += U * 8) { (&hhi[0][0][0])[i] = (lh16)0.0f; (&hlo[0][0][0])[i] = (lh16)0.0f; }
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int unit = wave * 8 + (lj & 7);
+  f32x4 xz_next[2];
+  auto load_xz = [&](int tt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + lk * 4 + r;
+        xz_next[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + tt) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+      }
+  };
+  load_xz(dir ? T - 1 : 0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2] = {xz_next[0], xz_next[1]};
+    f32x4 acl[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (step + 1 < T) load_xz(dir ? (T - 2 - step) : step + 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const lh16x8 ah = *reinterpret_cast<const lh16x8*>(&hhi[cur][lj][kb * 32 + lk * 8]);  // A[row = batch lj][k = 32 kb + 8 lk + e]
+      const lh16x8 al = *reinterpret_cast<const lh16x8*>(&hlo[cur][lj][kb * 32 + lk * 8]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uhi[nt][kb], acc[nt], 0, 0, 0);
+        acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ulo[nt][kb], acl[nt], 0, 0, 0);
+        acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uhi[nt][kb], acl[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mine0 = fmaf(acl[0][r], LO_INV, acc[0][r]), mine1 = fmaf(acl[1][r], LO_INV, acc[1][r]);
+      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
+      const bool low = lj < 8;
+      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
+      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
+      const float c = gf * cst[r] + gi * gg;
+      const float h = go * tanhf_(c);
+      cst[r] = c;
+      const int row = lk * 4 + r, bb = b0 + row;
+      if (bb < B) {
+        float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
+        gp[0] = low ? gi : gf;
+        gp[16] = low ? gg : go;
+      }
+      if (low) {
+        lh16 hh, hl;
+        split_f16(h, hh, hl);
+        hhi[cur ^ 1][row][unit] = hh;
+        hlo[cur ^ 1][row][unit] = hl;
+        if (bb < B) {
+          out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+          cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // =========================================================================================
 // LSTM backward through time for one direction and 16 snippets.  Per step (walking the forward order backwards):
 //   dh = dH[t] + dz[t_next] U^T
@@ -811,6 +914,136 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_h_kernel(const float* __restri
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dhr[r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+  }
+}
+
+// The backward recurrence of the f32 path on split-f16 MFMA (see lstm_train_fwd_split_kernel).  The gradient dz has no natural scale, so the
+// launch first takes max |dH| over the incoming gradient (lstm_grad_scale_kernel) and every dz is multiplied by the power of two S that brings
+// that maximum into [0.5, 1) before it is split: hi = f16(dz S) (zero below the smallest normal f16), lo = f16((dz S - hi) 4096); the recurrent
+// term is (acc_hi + acc_lo / 4096) / S.  A dz smaller than 2^-26 of the largest incoming gradient is lost -- the resolution an f32 accumulation of
+// the same dot product has.  dxz (the gradient the weight-gradient GEMMs read) is written from the f32 values, untouched by the split.
+__device__ float g_lstm_grad_scale[2];  // S, 1 / S of the launch in flight on this device (one backward recurrence at a time per process)
+
+__global__ __launch_bounds__(256) void lstm_grad_max_kernel(const float* __restrict__ dH, int64_t n, uint32_t* __restrict__ maxbits) {
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = fabsf(dH[i]);
+    m = v > m ? v : m;  // NaN never wins: a non-finite gradient leaves the scale at the finite maximum (the caller's step check sees it anyway)
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.0f && m < INFINITY) atomicMax(maxbits, __float_as_uint(m));
+}
+__global__ void lstm_grad_scale_kernel(uint32_t* maxbits) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t b = *maxbits;
+  // S = 2^(126 - exponent(max)): max * S in [0.5, 1); max = 0 (no gradient at all) -> S = 1
+  const int e = (int)((b >> 23) & 0xff);
+  const float S = (b == 0u || e == 0) ? 1.0f : __uint_as_float((uint32_t)(253 - e < 1 ? 1 : (253 - e > 254 ? 254 : 253 - e)) << 23);
+  g_lstm_grad_scale[0] = S;
+  g_lstm_grad_scale[1] = 1.0f / S;
+  *maxbits = 0u;  // ready for the next launch
+}
+__device__ uint32_t g_lstm_grad_maxbits;
+
+template <int U>
+__global__ __launch_bounds__(U * 4) void lstm_bwd_split_kernel(const float* __restrict__ dH /*[B][T][2U]*/, const float* __restrict__ gates, const float* __restrict__ cstate,
+                                                                const float* __restrict__ Uw /*[2][U][4U] permuted*/, int B, int T,
+                                                                float* __restrict__ dxz /*[B][T][2][4U] permuted*/) {
+  constexpr int ZP = 4 * U + 4, ZH = 4 * U + 8, KB = 4 * U / 32;
+  constexpr float LO_INV = 1.0f / 4096.0f;
+  extern __shared__ __attribute__((aligned(16))) float smem_ls[];
+  float (*dzs)[16][ZP] = reinterpret_cast<float (*)[16][ZP]>(smem_ls);                       // [2][16][ZP] f32: dz rows of the step (for dxz)
+  lh16 (*dzh)[16][ZH] = reinterpret_cast<lh16 (*)[16][ZH]>(smem_ls + 2 * 16 * ZP);           // [2][16][ZH] f16: hi part of dz S, the MFMA's A operand
+  lh16 (*dzl)[16][ZH] = reinterpret_cast<lh16 (*)[16][ZH]>(smem_ls + 2 * 16 * ZP + 16 * ZH);  // [2][16][ZH] f16: lo part (2 x 16 x ZH halves = 16 x ZH floats)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  const int unit = wave * 16 + lj;
+  const float S = g_lstm_grad_scale[0], Sinv = g_lstm_grad_scale[1];
+  lh16x8 uth[KB], utl[KB];  // B[k = 32 kb + 8 lk + e][col = lj] = U[unit][p = k], split
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      lh16 hi, lo;
+      split_f16(Ud[(int64_t)unit * (4 * U) + kb * 32 + lk * 8 + e], hi, lo);
+      uth[kb][e] = hi;
+      utl[kb][e] = lo;
+    }
+  float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhr[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pl = wave * 64 + (lj >> 3) * 32 + (lj & 7);
+  float pg[4][4], pc[4], pcp[4], pdh[4];
+  auto load_step = [&](int step) {
+    const int t = dir ? step : (T - 1 - step);
+    const int tprev = dir ? t + 1 : t - 1;
+    const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int bb = b0 + lk * 4 + r;
+      const bool ok = bb < B && step < T;
+      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + pl : 0;
+      pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
+      pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
+      pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
+      pcp[r] = (ok && has_prev) ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.f;
+      pdh[r] = ok ? dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] : 0.f;
+    }
+  };
+  load_step(0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? step : (T - 1 - step);
+    const int cur = step & 1;
+    float cg[4][4], cc[4], ccp[4], cdh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cc[r] = pc[r]; ccp[r] = pcp[r]; cdh[r] = pdh[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cg[r][q] = pg[r][q];
+    }
+    load_step(step + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = cg[r][0], gf = cg[r][1], gg = cg[r][2], go = cg[r][3];
+      const float c = cc[r], cp = ccp[r];
+      const float dh = cdh[r] + dhr[r];
+      const float tc = tanhf_(c);
+      const float dO = dh * tc;
+      const float dct = dc[r] + dh * go * (1.0f - tc * tc);
+      dc[r] = dct * gf;
+      const float z[4] = {dct * gg * gi * (1.0f - gi), dct * cp * gf * (1.0f - gf), dct * gi * (1.0f - gg * gg), dO * go * (1.0f - go)};
+      float* zr = &dzs[cur][lk * 4 + r][pl];
+      lh16* zh = &dzh[cur][lk * 4 + r][pl];
+      lh16* zl = &dzl[cur][lk * 4 + r][pl];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        zr[8 * q] = z[q];
+        lh16 hi, lo;
+        split_f16(z[q] * S, hi, lo);
+        zh[8 * q] = hi;
+        zl[8 * q] = lo;
+      }
+    }
+    __syncthreads();  // dz[cur] of every wave is visible (f32 rows and the split operand); the buffers cur^1 are free again after the next barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 4 + lk, bb = b0 + row;
+      const float4 v = *reinterpret_cast<const float4*>(&dzs[cur][row][wave * 64 + lj * 4]);
+      if (bb < B) *reinterpret_cast<float4*>(dxz + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 64 + lj * 4) = v;
+    }
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, acl[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const lh16x8 ah = *reinterpret_cast<const lh16x8*>(&dzh[cur][lj][kb * 32 + lk * 8]);
+      const lh16x8 al = *reinterpret_cast<const lh16x8*>(&dzl[cur][lj][kb * 32 + lk * 8]);
+      acc[kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uth[kb], acc[kb & 1], 0, 0, 0);
+      acl[kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, utl[kb], acl[kb & 1], 0, 0, 0);
+      acl[kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uth[kb], acl[kb & 1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dhr[r] = fmaf(acl[0][r] + acl[1][r], LO_INV, acc[0][r] + acc[1][r]) * Sinv;
   }
 }
 
@@ -1083,10 +1316,26 @@ int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, flo
   return (int)hipGetLastError();
 }
 
+static int g_lstm_split = 1;  // 1: the f32 path's recurrences on split-f16 MFMA (f32 accuracy); 0: v_mfma_f32_16x16x4_f32 (orcai_lstm_split: A/B, tests)
+
+int orcai_lstm_split(int on) {
+  const int prev = g_lstm_split;
+  if (on >= 0) g_lstm_split = on ? 1 : 0;
+  return prev;
+}
+
 int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream) {
   if (!xz || !Uw || !out || !gates || !cstate || B <= 0 || T <= 0) return ORCAI_E_BADARG;
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
+  if (g_lstm_split) {
+    switch (units) {
+      case 128: hipLaunchKernelGGL(lstm_train_fwd_split_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+      case 64: hipLaunchKernelGGL(lstm_train_fwd_split_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
+      default: return ORCAI_E_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+  }
   switch (units) {
     case 128: hipLaunchKernelGGL(lstm_train_fwd_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
     case 64: hipLaunchKernelGGL(lstm_train_fwd_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
@@ -1133,6 +1382,36 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
   if (!dH || !gates || !cstate || !Uw || !dxz || B <= 0 || T <= 0) return ORCAI_E_BADARG;
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
+  if (g_lstm_split && (units == 128 || units == 64)) {
+    static uint32_t* maxbits = nullptr;  // looked up once (the first call is never inside a stream capture: warm-up steps come first)
+    hipError_t e = hipSuccess;
+    if (!maxbits) {
+      e = hipGetSymbolAddress((void**)&maxbits, HIP_SYMBOL(g_lstm_grad_maxbits));
+      if (e != hipSuccess) return (int)e;
+    }
+    const int64_t n = (int64_t)B * T * 2 * units;
+    hipLaunchKernelGGL(lstm_grad_max_kernel, dim3((unsigned)((n + 256 * 16 - 1) / (256 * 16))), dim3(256), 0, st, dH, n, maxbits);
+    hipLaunchKernelGGL(lstm_grad_scale_kernel, dim3(1), dim3(64), 0, st, maxbits);
+    const size_t lds = (size_t)2 * 16 * (4 * units + 4) * 4 + (size_t)2 * 2 * 16 * (4 * units + 8) * 2;  // f32 rows + hi + lo operands
+    if (units == 128) {
+      static bool opted = false;  // 132 352 B > 64 KiB: opt in once
+      if (!opted) {
+        e = hipFuncSetAttribute((const void*)lstm_bwd_split_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        opted = true;
+      }
+      hipLaunchKernelGGL(lstm_bwd_split_kernel<128>, grid, dim3(512), lds, st, dH, gates, cstate, Uw, B, T, dxz);
+    } else {
+      static bool opted64 = false;  // 66 816 B
+      if (!opted64) {
+        e = hipFuncSetAttribute((const void*)lstm_bwd_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        opted64 = true;
+      }
+      hipLaunchKernelGGL(lstm_bwd_split_kernel<64>, grid, dim3(256), lds, st, dH, gates, cstate, Uw, B, T, dxz);
+    }
+    return (int)hipGetLastError();
+  }
   switch (units) {
     case 128: hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(512), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;
     case 64: hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), 0, st, dH, gates, cstate, Uw, B, T, dxz); break;

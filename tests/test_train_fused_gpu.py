@@ -274,3 +274,88 @@ def test_entry_conv_in_two_passes_without_v0(H, W, B, k):
         out[recompute] = [t.cpu().numpy() for t in (dbeta, dgamma, dW)]
     for a, b_, name in zip(out[True], out[False], ("dbeta", "dgamma", "dW")):
         assert np.abs(a - b_).max() <= 2e-5 * max(1.0, np.abs(b_).max()), (name, np.abs(a - b_).max())
+
+
+@pytest.mark.parametrize("U,B,T", [(128, 20, 46), (64, 7, 12)])
+def test_lstm_recurrence_on_split_f16_mfma_keeps_f32_accuracy(U, B, T):
+    """orcai_lstm_train_fwd with the recurrent product on f16 MFMA, every operand split as hi + lo / 4096 (the default), against the
+    v_mfma_f32_16x16x4_f32 kernel and against a float64 recurrence in the kernels' column order: the split kernel is as close to float64 as
+    the f32-MFMA kernel is (both limited by f32 accumulation and the fast exp of the gate functions), over all 46 dependent steps."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(U + B)
+    xz = rng.standard_normal((B, T, 2, 4 * U)).astype(np.float32)
+    Uw = (rng.standard_normal((2, U, 4 * U)) * (0.8 / np.sqrt(U))).astype(np.float32)
+    xd, ud = torch.from_numpy(xz).cuda(), torch.from_numpy(Uw).cuda()
+    res = {}
+    prev = lib.orcai_lstm_split(-1)
+    try:
+        for split in (0, 1):
+            lib.orcai_lstm_split(split)
+            h = torch.zeros((B, T, 2 * U), device="cuda")
+            g = torch.zeros((B, T, 2, 4 * U), device="cuda")
+            c = torch.zeros((B, T, 2, U), device="cuda")
+            N.check(lib.orcai_lstm_train_fwd(N.ptr(xd), N.ptr(ud), B, T, U, N.ptr(h), N.ptr(g), N.ptr(c), N.stream_ptr()), "lstm_train_fwd")
+            torch.cuda.synchronize()
+            res[split] = (h.cpu().numpy(), g.cpu().numpy(), c.cpu().numpy())
+    finally:
+        lib.orcai_lstm_split(prev)
+    # float64 recurrence in the permuted column order: wave w owns columns [32 w, 32 w + 32) = (i, f | g, o) of units 8 w .. 8 w + 7
+    sig = lambda a: 1.0 / (1.0 + np.exp(-a))  # noqa: E731
+    href = np.zeros((B, T, 2 * U))
+    for d in range(2):
+        hh, cc = np.zeros((B, U)), np.zeros((B, U))
+        W = Uw[d].astype(np.float64)
+        for step in range(T):
+            t = T - 1 - step if d else step
+            z = xz[:, t, d].astype(np.float64) + hh @ W
+            zz = z.reshape(B, U // 8, 4, 8)  # [wave][i, f, g, o][unit in wave]
+            i_, f_, g_, o_ = sig(zz[:, :, 0]), sig(zz[:, :, 1]), np.tanh(zz[:, :, 2]), sig(zz[:, :, 3])
+            cc = (f_ * cc.reshape(B, U // 8, 8) + i_ * g_).reshape(B, U)
+            hh = (o_ * np.tanh(cc.reshape(B, U // 8, 8))).reshape(B, U)
+            href[:, t, d * U : (d + 1) * U] = hh
+    e32, esp = np.abs(res[0][0] - href).max(), np.abs(res[1][0] - href).max()
+    print(f"LSTM units {U}: max |h - float64| f32-MFMA kernel {e32:.2e}, split-f16 kernel {esp:.2e}; kernels against each other {np.abs(res[0][0] - res[1][0]).max():.2e}")
+    assert esp <= max(2.0 * e32, 2e-6) and esp <= 1e-5
+    for a, b_ in zip(res[0], res[1]):
+        assert np.abs(a - b_).max() <= 1e-5
+
+
+@pytest.mark.parametrize("U,B,T,gscale", [(128, 20, 46, 1e-4), (64, 7, 12, 3.0), (128, 3, 9, 1e-9)])
+def test_lstm_backward_on_split_f16_mfma_keeps_f32_accuracy(U, B, T, gscale):
+    """orcai_lstm_bwd with the recurrent term dz U^T on split-f16 MFMA (every dz scaled by the power of two that brings max |dH| into
+    [0.5, 1), then hi + lo / 4096) against the v_mfma_f32_16x16x4_f32 kernel, for incoming gradients of very different magnitudes: the
+    two agree to f32 accumulation noise relative to the largest gradient, over all dependent steps."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(U + T)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    gates = (1.0 / (1.0 + np.exp(-f(B, T, 2, 4 * U)))).astype(np.float32)  # i, f, o in (0, 1); the g columns are re-drawn in (-1, 1) below
+    gv = gates.reshape(B, T, 2, U // 8, 4, 8)  # [wave][i f g o][unit]... the kernel's permuted order: (i, f | g, o) per 32 columns
+    gv[..., 2, :] = np.tanh(f(B, T, 2, U // 8, 8))
+    cst = f(B, T, 2, U) * 0.7
+    dH = (f(B, T, 2 * U) * gscale).astype(np.float32)
+    dH[0, 0, :5] = 0.0
+    Uw = (f(2, U, 4 * U) * (0.8 / np.sqrt(U))).astype(np.float32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    gd, cd, hd, ud = dev(gates), dev(cst), dev(dH), dev(Uw)
+    res = {}
+    prev = lib.orcai_lstm_split(-1)
+    try:
+        for split in (0, 1, 1):
+            lib.orcai_lstm_split(split)
+            dxz = torch.zeros((B, T, 2, 4 * U), device="cuda")
+            N.check(lib.orcai_lstm_bwd(N.ptr(hd), N.ptr(gd), N.ptr(cd), N.ptr(ud), B, T, U, N.ptr(dxz), N.stream_ptr()), "lstm_bwd")
+            torch.cuda.synchronize()
+            res.setdefault(split, []).append(dxz.cpu().numpy().astype(np.float64))
+    finally:
+        lib.orcai_lstm_split(prev)
+    ref, got = res[0][0], res[1][0]
+    assert np.array_equal(res[1][0], res[1][1])  # the scale of a launch does not leak into the next one
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.isfinite(got).all()
+    err = np.abs(got - ref).max() / scale
+    print(f"LSTM backward units {U}, |dH| ~ {gscale:g}: max |split - f32| / max |dxz| = {err:.2e}")
+    assert err <= 5e-6
