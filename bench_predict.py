@@ -304,7 +304,8 @@ class _TimedLib:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.events.setdefault(name, []).append((e0, e1, args))
+            if rc != -2:  # ORCAI_E_UNSUPPORTED: the launcher refused before touching anything and the caller runs its fallback -- not a launch
+                self.events.setdefault(name, []).append((e0, e1, args))
             return rc
 
         return call
@@ -313,10 +314,12 @@ class _TimedLib:
 # The launcher bracketed inside the timed training steps: the top row of the last fully bracketed table / rocprofv3 summary
 # (profiles/r02_train_rocprofv3_kernel_stats.csv: bn_bwd_pw_kernel<*> 15.6 % of the step summed over its instantiations).  roofline()
 # re-derives the dominant launcher from its own table every run and reports whether the two agree.
-TRAIN_DOMINANT_LAUNCHER = "orcai_bn_bwd_pointwise"
+TRAIN_DOMINANT_LAUNCHER = "orcai_bn_bwd_pointwise_wgrad"
 LAUNCHER_KERNELS = {"orcai_bn_bwd_pointwise": "bn_bwd_pw_kernel<MT>", "orcai_outer_reduce": "outer_reduce_kernel<NP>", "orcai_dw_wgrad": "dw_wgrad_kernel<3>",
                     "orcai_sepconv_planes_stats": "sepconv_tile_kernel / sepconv_ftile_kernel<..., STATS = true>", "orcai_sepconv_planes_u": "sepconv_*_kernel",
-                    "orcai_bn_planes_stats": "planes_sums_kernel", "orcai_bn_planes_apply": "bn_planes_apply_kernel"}
+                    "orcai_bn_planes_stats": "planes_sums_kernel", "orcai_bn_planes_apply": "bn_planes_apply_kernel",
+                    "orcai_bn_bwd_pointwise_wgrad": "bn_bwd_pw_wgrad_kernel<MT, NT, 4>", "orcai_sepconv_planes_epi": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 2 | 3>",
+                    "orcai_sepconv_planes_stats_bn": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 1, BNIN>", "orcai_dw_wgrad_bn": "dw_wgrad_kernel<3, true>"}
 
 
 def traffic_has(workload: str) -> bool:
@@ -335,6 +338,17 @@ def _train_call_bytes(name, a):
     if name == "orcai_sepconv_planes_stats":  # in,B,Cin,H,W,relu_in,dw,pw,scale,shift,Cout,out,u_out,shards,stream (statistics in the epilogue)
         B, Cin, H, W, Cout = a[1], a[2], a[3], a[4], a[10]
         return 4.0 * B * H * W * (2 * Cin + Cout)
+    if name == "orcai_sepconv_planes_stats_bn":  # v_in,B,Cin,H,W,mean,var,gamma,beta,eps,dw,pw,scale,shift,Cout,out,u_out,shards,stream: v in, v out, depthwise output
+        B, Cin, H, W, Cout = a[1], a[2], a[3], a[4], a[14]
+        return 4.0 * B * H * W * (2 * Cin + Cout)
+    if name == "orcai_sepconv_planes_epi":  # in,B,Cin,H,W,dw,pw,scale,shift,Cout,out,epi,ref,...: gradient in, gradient out, the reference tensor
+        B, Cin, H, W, Cout = a[1], a[2], a[3], a[4], a[9]
+        return 4.0 * B * H * W * (Cin + 2 * Cout)
+    if name == "orcai_bn_bwd_pointwise_wgrad":  # dy,v,u,B,C,H,W,ksize,...,wt,Cin,du,...: dy, v (C channels), u and du (Cin channels); dv is never moved
+        B, C, H, W, Cin = a[3], a[4], a[5], a[6], a[19]
+        return 4.0 * B * H * W * (2 * C + 2 * Cin)
+    if name == "orcai_dw_wgrad_bn":  # v,du,B,C,H,W,...
+        return 4.0 * a[2] * a[4] * a[5] * 2 * a[3]
     if name == "orcai_bn_bwd_pointwise":  # dy,v,B,C,H,W,ksize,mean,var,gamma,beta,eps,relu,scratch,sums_ready,dbeta,dgamma,wt,Cin,dv,du,stream
         B, C, H, W, Cin = a[2], a[3], a[4], a[5], a[18]
         return 4.0 * B * H * W * (3 * C + Cin)

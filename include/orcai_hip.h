@@ -243,7 +243,7 @@ int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, flo
 
 /* Training forward of one Bidirectional(LSTM): as orcai_lstm_recurrent, plus the gate activations (i,f,g,o, permuted columns)
  * f32[B][T][2][4*units] and cell states f32[B][T][2][units] the backward pass needs. */
-int orcai_lstm_split(int on); /* 1 (default): the f32 path's training recurrences run their recurrent product on f16 MFMA with every operand split as hi + lo / 4096 (f32 accuracy, 24 MFMAs of 16 cycles per step instead of 64 of 32); 0: v_mfma_f32_16x16x4_f32; < 0 queries; returns the previous value */
+int orcai_lstm_split(int on); /* 1 (default): the f32 path's LSTM recurrences (inference, training forward and backward) run their recurrent product on f16 MFMA with every operand split as hi + lo / 4096 (f32 accuracy, 24 MFMAs of 16 cycles per step instead of 64 of 32); 0: v_mfma_f32_16x16x4_f32; < 0 queries; returns the previous value */
 int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream);
 /* The f16 path's twin (same arguments, f32 tensors): the recurrent product on v_mfma_f32_16x16x32_f16 with h and U rounded to f16,
  * f32 accumulation on the f32 input projection, gates / cell state / outputs in f32; orcai_h_lstm_bwd likewise for the recurrent

@@ -21,6 +21,8 @@
 #include "orcai_hip.h"
 #include "zero_fill.h"
 
+int g_orcai_lstm_split = 1;  // 1: the LSTM recurrences of the f32 path run on split-f16 MFMA at f32 accuracy; 0: on v_mfma_f32_16x16x4_f32 (orcai_lstm_split)
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1716,6 +1718,97 @@ __global__ __launch_bounds__(U * 8) void lstm_kernel(const float* __restrict__ x
   }
 }
 
+// The inference recurrence on split-f16 MFMA at f32 accuracy (train_head.hip, lstm_train_fwd_split_kernel, explains the scheme: every operand
+// as hi + lo / 4096 in two normal f16 numbers, hi*hi in one accumulator, hi*lo + lo*hi in a second one scaled back by 2^-12): a step is bound
+// by one compute unit's matrix rate, and the f32-input MFMA runs at 1/16 of the f16 rate.
+typedef _Float16 mh16;
+typedef mh16 mh16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_f16_m(float x, mh16& hi, mh16& lo) {
+  const mh16 h = fabsf(x) >= 6.103515625e-05f ? (mh16)x : (mh16)0.0f;
+  hi = h;
+  lo = (mh16)((x - (float)h) * 4096.0f);
+}
+
+template <int U>
+__global__ __launch_bounds__(U * 8) void lstm_split_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
+                                                            int B, int T, float* __restrict__ out /*[B][T][2U]*/) {
+  constexpr int KB = U / 32, HPh = U + 8;
+  constexpr float LO_INV = 1.0f / 4096.0f;
+  __shared__ __attribute__((aligned(16))) mh16 hhi[2][16][HPh];
+  __shared__ __attribute__((aligned(16))) mh16 hlo[2][16][HPh];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const float* Ud = Uw + (int64_t)dir * U * 4 * U;
+  mh16x8 uhi[2][KB], ulo[2][KB];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mh16 hi, lo;
+        split_f16_m(Ud[(int64_t)(kb * 32 + lk * 8 + e) * (4 * U) + wave * 32 + nt * 16 + lj], hi, lo);
+        uhi[nt][kb][e] = hi;
+        ulo[nt][kb][e] = lo;
+      }
+  for (int i = tid; i < 2 * 16 * HPh; i += U * 8) { (&hhi[0][0][0])[i] = (mh16)0.0f; (&hlo[0][0][0])[i] = (mh16)0.0f; }
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const int unit = wave * 8 + (lj & 7);
+  f32x4 xz_next[2];
+  auto load_xz = [&](int tt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bb = b0 + lk * 4 + r;
+        xz_next[nt][r] = (bb < B) ? xz[(((int64_t)bb * T + tt) * 2 + dir) * (4 * U) + wave * 32 + nt * 16 + lj] : 0.0f;
+      }
+  };
+  load_xz(dir ? T - 1 : 0);
+  for (int step = 0; step < T; ++step) {
+    const int t = dir ? (T - 1 - step) : step;
+    const int cur = step & 1;
+    f32x4 acc[2] = {xz_next[0], xz_next[1]};
+    f32x4 acl[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    if (step + 1 < T) load_xz(dir ? (T - 2 - step) : step + 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const mh16x8 ah = *reinterpret_cast<const mh16x8*>(&hhi[cur][lj][kb * 32 + lk * 8]);
+      const mh16x8 al = *reinterpret_cast<const mh16x8*>(&hlo[cur][lj][kb * 32 + lk * 8]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, uhi[nt][kb], acc[nt], 0, 0, 0);
+        acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ulo[nt][kb], acl[nt], 0, 0, 0);
+        acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uhi[nt][kb], acl[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mine0 = fmaf(acl[0][r], LO_INV, acc[0][r]), mine1 = fmaf(acl[1][r], LO_INV, acc[1][r]);
+      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
+      const bool low = lj < 8;
+      const float zi = low ? mine0 : oth0, zf = low ? oth0 : mine0;
+      const float zg = low ? mine1 : oth1, zo = low ? oth1 : mine1;
+      const float c = sigmoidf_(zf) * cst[r] + sigmoidf_(zi) * tanhf_(zg);
+      const float h = sigmoidf_(zo) * tanhf_(c);
+      cst[r] = c;
+      if (low) {
+        const int row = lk * 4 + r;
+        mh16 hh, hl;
+        split_f16_m(h, hh, hl);
+        hhi[cur ^ 1][row][unit] = hh;
+        hlo[cur ^ 1][row][unit] = hl;
+        const int bb = b0 + row;
+        if (bb < B) out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // =========================================================================================
 // dense_sigmoid: out[m][n] = sigmoid(x[m][:] . w[:][n] + b[n]),  N <= 8   (architectures.py:239)
 // =========================================================================================
@@ -2218,10 +2311,24 @@ int orcai_gemm_bias_act(const float* A, const float* Bm, const float* bias, cons
   return (int)hipGetLastError();
 }
 
+int orcai_lstm_split(int on) {
+  const int prev = g_orcai_lstm_split;
+  if (on >= 0) g_orcai_lstm_split = on ? 1 : 0;
+  return prev;
+}
+
 int orcai_lstm_recurrent(const float* xz, const float* Uw, int B, int T, int units, float* out, void* stream) {
   if (!xz || !Uw || !out || B <= 0 || T <= 0) return ORCAI_E_BADARG;
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
+  if (g_orcai_lstm_split) {
+    switch (units) {
+      case 128: hipLaunchKernelGGL(lstm_split_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out); break;
+      case 64: hipLaunchKernelGGL(lstm_split_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out); break;
+      default: return ORCAI_E_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+  }
   switch (units) {
     case 128: hipLaunchKernelGGL(lstm_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out); break;
     case 64: hipLaunchKernelGGL(lstm_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out); break;

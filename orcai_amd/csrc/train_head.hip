@@ -11,6 +11,8 @@
 #include "orcai_hip.h"
 #include "zero_fill.h"
 
+extern int g_orcai_lstm_split;  // model_fwd.hip: 1 = LSTM recurrences of the f32 path on split-f16 MFMA (orcai_lstm_split)
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1316,19 +1318,11 @@ int orcai_adam_step(float* w, const float* g, float* m, float* v, int64_t n, flo
   return (int)hipGetLastError();
 }
 
-static int g_lstm_split = 1;  // 1: the f32 path's recurrences on split-f16 MFMA (f32 accuracy); 0: v_mfma_f32_16x16x4_f32 (orcai_lstm_split: A/B, tests)
-
-int orcai_lstm_split(int on) {
-  const int prev = g_lstm_split;
-  if (on >= 0) g_lstm_split = on ? 1 : 0;
-  return prev;
-}
-
 int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream) {
   if (!xz || !Uw || !out || !gates || !cstate || B <= 0 || T <= 0) return ORCAI_E_BADARG;
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
-  if (g_lstm_split) {
+  if (g_orcai_lstm_split) {
     switch (units) {
       case 128: hipLaunchKernelGGL(lstm_train_fwd_split_kernel<128>, grid, dim3(1024), 0, st, xz, Uw, B, T, out, gates, cstate); break;
       case 64: hipLaunchKernelGGL(lstm_train_fwd_split_kernel<64>, grid, dim3(512), 0, st, xz, Uw, B, T, out, gates, cstate); break;
@@ -1382,7 +1376,7 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
   if (!dH || !gates || !cstate || !Uw || !dxz || B <= 0 || T <= 0) return ORCAI_E_BADARG;
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
-  if (g_lstm_split && (units == 128 || units == 64)) {
+  if (g_orcai_lstm_split && (units == 128 || units == 64)) {
     static uint32_t* maxbits = nullptr;  // looked up once (the first call is never inside a stream capture: warm-up steps come first)
     hipError_t e = hipSuccess;
     if (!maxbits) {

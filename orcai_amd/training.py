@@ -962,8 +962,20 @@ class Trainer:
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: the dataset's producer thread keeps pinning and uploading the next batches meanwhile (a global-mode
                 # capture is invalidated by another thread's hipHostMalloc and the process aborts)
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    out = self.train_step(x_in, snippet_stride, B, y_in)
+                # ... and no cyclic garbage collection inside the capture: a collection that happens to run there finalises whatever became unreachable
+                # earlier in the process (a previous trial's trainer with its own captured graph, pinned batches of the dataset thread) with
+                # runtime calls that are illegal while this thread captures -- the process aborted in hpsearch's second trial
+                import gc
+
+                gc.collect()
+                gc_was_enabled = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        out = self.train_step(x_in, snippet_stride, B, y_in)
+                finally:
+                    if gc_was_enabled:
+                        gc.enable()
             torch.cuda.current_stream().wait_stream(side)
             # the two warm-up steps moved weights, Adam moments, moving statistics and the step counter (the capture pass ran nothing):
             # back to the state the caller handed in
