@@ -366,6 +366,11 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
  * reductions of that BatchNorm's backward, so orcai_bn_bwd_pointwise(sums_ready = 1) need not read dy and v for them. */
 int orcai_pool_bwd_bn(const float* dout, const float* v, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
                       const float* bn_var, float bn_eps, double* bn_sums, void* stream);
+/* orcai_pool_bwd_bn that also reduces dbias[c] = sum over snippets and pixels of dout[c] -- the bias gradient of the block's residual 1x1
+ * convolution, whose output gradient dout is (architectures.py:190-196) -- where the pooling backward reads every dout value exactly once;
+ * dout_sums: 4 * ceil(C/4) doubles of workspace.  Replaces an orcai_planes_sum pass over dout. */
+int orcai_pool_bwd_bn_bias(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                           const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream);
 /* orcai_bn_planes_bwd fused with the input gradient through the pointwise weights of the separable conv that produced v:
  * dbeta / dgamma as above, dv (may alias dy) = BN input gradient, du = Wpw dv with wt = pointwise^T [C][Cin] (planes of Cin
  * channels).  One pass over dy and v instead of bn apply + a pointwise conv pass that re-reads dv. */

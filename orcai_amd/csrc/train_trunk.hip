@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
                                                         int C, int H, int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, int pad_left,
                                                         float* __restrict__ dy /*[B][CQ][HP][WP][4]*/, int B, const float* __restrict__ bn_gamma,
                                                         const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float bn_eps,
-                                                        double* __restrict__ bn_sums /*[2][4*CQ]: sum dy, sum dy*xhat*/) {
+                                                        double* __restrict__ bn_sums /*[2][4*CQ]: sum dy, sum dy*xhat*/,
+                                                        double* __restrict__ dout_sums = nullptr /*[4*CQ]: sum of dout per channel (the residual conv's bias gradient)*/) {
   // bn_gamma != NULL: ybn holds the PRE-BatchNorm tensor v; BN(v) = fma(v, gamma*inv, ..) is monotone, increasing for gamma >= 0
   // and decreasing for gamma < 0, so the arg-max of BN(v) is the arg-max of sign(gamma) * v.
   // bn_sums != NULL: the reductions of that BatchNorm's backward (sum of dy and of dy * xhat per channel) are accumulated here,
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   const int chunk = in_range ? idx / Wo : 0;
   const int64_t bq = blockIdx.y;
   float bs[4] = {0.f, 0.f, 0.f, 0.f}, bqs[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, binv[4] = {0.f, 0.f, 0.f, 0.f};
+  float ds[4] = {0.f, 0.f, 0.f, 0.f};  // dout_sums: every pooled pixel belongs to exactly one thread's OWN windows (i0 <= i < i1)
   if (bn_sums) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     if (i + 1 < i1) request(i + 1);
     const float4 m = mx4(mx4(mx4(t0, t1), mx4(m0, m1)), mx4(b0, b1));
     if (i >= i0) {
+      ds[0] += d.x; ds[1] += d.y; ds[2] += d.z; ds[3] += d.w;
       if (r0 >= 0) {
         if (cx0) emit((int64_t)(r0 + R) * WP + x0, add4(c0, sel(t0, m, d)), t0);
         if (cx1) emit((int64_t)(r0 + R) * WP + x1, add4(c1, sel(t1, m, d)), t1);
@@ -583,20 +586,23 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     if (cx0) emit((int64_t)(rl + R) * WP + x0, c0, t0);
     if (cx1) emit((int64_t)(rl + R) * WP + x1, c1, t1);
   }
-  if (bn_sums) {  // block reduction (float64) and 8 atomics per workgroup
-    __shared__ double red[256][8];
+  if (bn_sums) {  // block reduction (float64) and 8 (+ 4) atomics per workgroup
+    __shared__ double red[256][12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = (double)bs[k]; red[threadIdx.x][4 + k] = (double)bqs[k]; }
+    for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = (double)bs[k]; red[threadIdx.x][4 + k] = (double)bqs[k]; red[threadIdx.x][8 + k] = (double)ds[k]; }
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
       if (threadIdx.x < o)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+        for (int k = 0; k < 12; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
       __syncthreads();
     }
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < 12) {
       const int k = threadIdx.x & 3, c = (int)(bq % CQ) * 4 + k;
-      if (c < C) atomicAdd(&bn_sums[(threadIdx.x >> 2) * 4 * CQ + c], red[0][threadIdx.x]);
+      if (c < C) {
+        if (threadIdx.x < 8) atomicAdd(&bn_sums[(threadIdx.x >> 2) * 4 * CQ + c], red[0][threadIdx.x]);
+        else if (dout_sums) atomicAdd(&dout_sums[c], red[0][threadIdx.x]);
+      }
     }
   }
 }
@@ -1325,10 +1331,11 @@ int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u
   return (int)hipGetLastError();
 }
 
-int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
-                      const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
+static int pool_bwd_bn_impl(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                            const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream) {
   if (!dout || !ybn || !dy || B <= 0 || C <= 0 || C > 64 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
   if (bn_sums && (!bn_gamma || !bn_mean || !bn_var)) return ORCAI_E_BADARG;
+  if (dout_sums && (!bn_sums || !dbias)) return ORCAI_E_BADARG;
   if ((int64_t)B * ((C + 3) / 4) > 65535) return ORCAI_E_UNSUPPORTED;  // grid.y = (snippet, quad)
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
@@ -1340,11 +1347,27 @@ int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, 
     hipError_t e = orcai_zero::zero_async(bn_sums, sizeof(double) * 8 * CQ, st);
     if (e != hipSuccess) return (int)e;
   }
+  if (dout_sums) {
+    hipError_t e = orcai_zero::zero_async(dout_sums, sizeof(double) * 4 * CQ, st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
   dim3 grid((per_bq + 255) / 256, (unsigned)(B * CQ));
   hipLaunchKernelGGL(pool_bwd_kernel, grid, dim3(256), 0, st, dout, ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
-                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums);
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, dy, B, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, dout_sums);
+  if (dout_sums) hipLaunchKernelGGL(f64_to_f32_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dout_sums, dbias, C, 0);
   return (int)hipGetLastError();
+}
+
+int orcai_pool_bwd_bn(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                      const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
+  return pool_bwd_bn_impl(dout, ybn, B, C, H, W, ksize, dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, nullptr, nullptr, stream);
+}
+
+int orcai_pool_bwd_bn_bias(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, const float* bn_gamma, const float* bn_mean,
+                           const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream) {
+  if (!dout_sums || !dbias) return ORCAI_E_BADARG;
+  return pool_bwd_bn_impl(dout, ybn, B, C, H, W, ksize, dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, dout_sums, dbias, stream);
 }
 
 int orcai_pool_bwd(const float* dout, const float* ybn, int B, int C, int H, int W, int ksize, float* dy, void* stream) {

@@ -385,6 +385,7 @@ class TrunkTrainer:
         self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
+        self.bias_in_pool = True  # residual bias gradients reduced inside the pooling backward (no planes_sum pass over dout)
         self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
@@ -745,18 +746,25 @@ class TrunkTrainer:
                 N.check(lib.orcai_mask_scale(dprev.data_ptr(), self.block_masks[i - 1].data_ptr(), 1.0 / (1.0 - self.block_rate), dprev.numel(), dprev.data_ptr(), st),
                         "mask_scale")
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
+            bias_in_pool = self.bias_in_pool and not self.half
             def residual_wgrad():  # residual 1x1 stride-2 conv: weight / bias gradients (read-only passes over prev and dout)
                 N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
                                                  self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
-                N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
+                if not bias_in_pool:
+                    N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
 
             if not self.dgrad_first:
                 residual_wgrad()
             # max-pool branch
             dyb = b[f"dyb{i}"]
             bmean, bvar = self.stats[f"b{i}/bn_b"]  # the pooling backward also accumulates bn_b's backward reductions (sum dy, sum dy*xhat)
-            N.check(self._fn("pool_bwd_bn")(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
-                                            bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
+            if bias_in_pool:  # the residual conv's bias gradient (sum of dout) reduced where the pooling backward reads dout anyway
+                N.check(lib.orcai_pool_bwd_bn_bias(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
+                                                   bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), st),
+                        "pool_bwd_bn_bias")
+            else:
+                N.check(self._fn("pool_bwd_bn")(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
+                                                bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), st), "pool_bwd_bn")
             if self.dgrad_first:  # behind the kernel that wrote dyb, not behind the one that wrote dout (see _sep_backward)
                 residual_wgrad()
             dya = b[f"dya{i}"]
