@@ -356,66 +356,80 @@ __global__ __launch_bounds__(64 * NW) void bn_bwd_pw_wgrad_kernel(const float* _
   const float4* ub = reinterpret_cast<const float4*>(u) + (int64_t)b * CQi * plane;
   float4* dub = reinterpret_cast<float4*>(du) + (int64_t)b * CQi * plane;
 
+  // All loads of a window (dy, v of every output quad, u of every input quad: 16 B per lane each) are requested while the PREVIOUS window's
+  // weight-gradient MFMAs run -- with the LDS images two workgroups (8 waves) fit a compute unit, so a wave has to cover its own memory
+  // latency; requests past the last window are clamped to it (unconditional, never used).
+  constexpr int MAXQO = 4 * NT;
+  float4 ru[MAXQ], rd[MAXQO], rv[MAXQO];
+  auto request = [&](int task) {
+    const int tc = task < tasks ? task : tasks - 1;
+    const int q = R * WP + tc * 64 + lane;
+    const int qc = q < plane ? q : plane - 1;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i)
+      if (i < CQi) ru[i] = ub[(int64_t)i * plane + qc];
+#pragma unroll
+    for (int i = 0; i < MAXQO; ++i)
+      if (i < CQ) {
+        rd[i] = dyb[(int64_t)i * plane + qc];
+        rv[i] = vb[(int64_t)i * plane + qc];
+      }
+  };
+  request(blockIdx.x * NW + wave);
   for (int task = blockIdx.x * NW + wave; task < tasks; task += gridDim.x * NW) {
     const int qbase = R * WP + task * 64;  // interior rows only; 1 KiB-aligned windows
     const int q = qbase + lane;
     const int row = (int)__umulhi((uint32_t)q, magic_WP);
     const bool live = (q - row * WP) < W && row < R + H;
-    const int qc = q < plane ? q : plane - 1;
-    float4 ru[MAXQ];  // the depthwise output of this pixel, every input quad: all requested up front
-#pragma unroll
-    for (int i = 0; i < MAXQ; ++i)
-      if (i < CQi) ru[i] = ub[(int64_t)i * plane + qc];
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 nd = dyb[qc], nv = vb[qc];
-    for (int cq = 0; cq < CQ; ++cq) {
-      const float4 d4 = nd, v4 = nv;
-      if (cq + 1 < CQ) {
-        nd = dyb[(int64_t)(cq + 1) * plane + qc];
-        nv = vb[(int64_t)(cq + 1) * plane + qc];
-      }
-      float afrag[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int co = cq * 4 + lk, ci = m * 16 + lj;  // k = conv-output channel, row = conv-input channel
-        const bool ok = co < C && ci < Cin;
-        const float av = wt[ok ? co * Cin + ci : 0];
-        afrag[m] = ok ? av : 0.0f;
-      }
-      const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-      float o[4];
+    for (int cq = 0; cq < MAXQO; ++cq) {
+      if (cq < CQ) {  // wave-uniform
+        const float4 d4 = rd[cq], v4 = rv[cq];
+        float afrag[MT];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = cq * 4 + k;  // wave-uniform: the per-channel constants are scalar loads
-        if (c < C) {
-          const float inv = rsqrtf(var[c] + eps);
-          const float xh = (vv[k] - mean[c]) * inv;
-          float de = dd[k];
-          if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
-          o[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
-        } else {
-          o[k] = 0.0f;
+        for (int m = 0; m < MT; ++m) {
+          const int co = cq * 4 + lk, ci = m * 16 + lj;  // k = conv-output channel, row = conv-input channel
+          const bool ok = co < C && ci < Cin;
+          const float av = wt[ok ? co * Cin + ci : 0];
+          afrag[m] = ok ? av : 0.0f;
         }
-        Bs[(4 * cq + k) * P + lane] = o[k];
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = cq * 4 + k;  // wave-uniform: the per-channel constants are scalar loads
+          if (c < C) {
+            const float inv = rsqrtf(var[c] + eps);
+            const float xh = (vv[k] - mean[c]) * inv;
+            float de = dd[k];
+            if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+            o[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
+          } else {
+            o[k] = 0.0f;
+          }
+          Bs[(4 * cq + k) * P + lane] = o[k];
+        }
+        swap32t(o[0], o[2]);
+        swap32t(o[1], o[3]);
+        swap16t(o[0], o[1]);
+        swap16t(o[2], o[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], o[t], acc[m][t]);
       }
-      swap32t(o[0], o[2]);
-      swap32t(o[1], o[3]);
-      swap16t(o[0], o[1]);
-      swap16t(o[2], o[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m][t] = mfma16(afrag[m], o[t], acc[m][t]);
     }
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i)
       if (i < CQi) {
         As[(4 * i + 0) * P + lane] = ru[i].x; As[(4 * i + 1) * P + lane] = ru[i].y; As[(4 * i + 2) * P + lane] = ru[i].z; As[(4 * i + 3) * P + lane] = ru[i].w;
       }
+    request(task + gridDim.x * NW);  // in flight during the stores and the weight-gradient MFMAs below
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int flat = qbase + 16 * t + lj;
@@ -1021,22 +1035,43 @@ __global__ __launch_bounds__(256) void conv0_bn_bwd_x_kernel(const float* __rest
   const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
   const int ntiles = tx * ty * B;
   const int py = threadIdx.x / TW, px = threadIdx.x % TW;
+  // The NEXT tile's input halo (<= 2 values per thread at k = 3) and gradient quad are requested before the current tile is worked on and
+  // handed over through registers: a tile does not start by waiting for a round trip to memory.
+  constexpr int HN = (HH * HW + 255) / 256;
+  float hreg[HN];
+  float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto request = [&](int tile) {
+    const bool any = tile < ntiles;
+    const int tl = any ? tile : 0;
+    const int b = tl / (tx * ty), rem = tl - b * (tx * ty);
+    const int y0 = (rem / tx) * TH, x0 = (rem - (rem / tx) * tx) * TW;
+    const float* src = in + (int64_t)b * snippet_stride;
+#pragma unroll
+    for (int k = 0; k < HN; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int r = i / HW, c = i % HW;
+      const int yy = y0 + r - R, xx = x0 + c - R;
+      hreg[k] = (any && i < HH * HW && yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(int64_t)yy * W + xx] : 0.0f;
+    }
+    const int y = y0 + py, x = x0 + px;
+    dnext = (any && y < H && x < W) ? (reinterpret_cast<const float4*>(dy) + ((int64_t)b * 4 + cq) * plane)[(y + R) * WP + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  request(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / (tx * ty), rem = tile - b * (tx * ty);
     const int y0 = (rem / tx) * TH, x0 = (rem - (rem / tx) * tx) * TW;
-    const float* src = in + (int64_t)b * snippet_stride;
     const int y = y0 + py, x = x0 + px;
     const bool live = y < H && x < W;
-    // the gradient of this pixel's quad: requested before the halo is staged
-    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) d4 = (reinterpret_cast<const float4*>(dy) + ((int64_t)b * 4 + cq) * plane)[(y + R) * WP + x];
+    (void)b;
     __syncthreads();  // the previous tile's halo reads are done
-    for (int i = threadIdx.x; i < HH * HW; i += 256) {
-      const int r = i / HW, c = i % HW;
-      const int yy = y0 + r - R, xx = x0 + c - R;
-      halo[r][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(int64_t)yy * W + xx] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < HN; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < HH * HW) halo[i / HW][i % HW] = hreg[k];
     }
+    const float4 d4 = dnext;
     __syncthreads();
+    request(tile + gridDim.x);
     float a[KK];
 #pragma unroll
     for (int dyy = 0; dyy < KS; ++dyy)
