@@ -154,16 +154,16 @@ class PredictWorkload:
             val = 60 if op == "sep_b" else 62
             nstrip = -(-widths[blk] // val)
             if mode == 1 and mt == 2 and cqr <= 8 and nstrip >= 2 and widths[blk] * 100 >= nstrip * val * 85:  # launch_sepconv_impl's rule
-                return f"sepconv_tile_kernel<2, {4 if cqr <= 4 else 8}, {xp}, {relu}, 8, false, false>"  # <MT, CQ, XP, RELU, TR, UOUT, STATS>
+                return f"sepconv_tile_kernel<2, {4 if cqr <= 4 else 8}, {xp}, {relu}, 8, false, 0, false>"  # <MT, CQ, XP, RELU, TR, UOUT, EPI, BNIN>
             if mode >= 1:
-                return f"sepconv_ftile_kernel<{mt}, {xp}, {relu}, false, 8, false>"  # <MT, XP, RELU, UOUT, NWV, STATS>
+                return f"sepconv_ftile_kernel<{mt}, {xp}, {relu}, false, 8, 0, false>"  # <MT, XP, RELU, UOUT, NWV, EPI, BNIN>
             return f"sepconv_kernel<3, {mt}>"
         if blk in couts and op == "pool_res":
             return f"pool_res_add_x_kernel<{(couts[blk] + 15) // 16}>"  # inference: the x-pooled fast path
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
-    # (sepconv_tile_kernel<2, 8, true, false, 8, false>) is the top symbol of rocprofv3 --stats for this workload
+    # (sepconv_tile_kernel<2, 8, true, false, 8, false, 0, false>) is the top symbol of rocprofv3 --stats for this workload
     DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
 
     def roofline(self):
@@ -322,6 +322,20 @@ LAUNCHER_KERNELS = {"orcai_bn_bwd_pointwise": "bn_bwd_pw_kernel<MT>", "orcai_out
                     "orcai_sepconv_planes_stats_bn": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 1, BNIN>", "orcai_dw_wgrad_bn": "dw_wgrad_kernel<3, true>"}
 
 
+def measured_traffic_prefix(prefix: str, workload: str):
+    """Mean HBM bytes per launch over every symbol of the table that starts with `prefix` (a launcher's templated kernel family)."""
+    import json
+
+    f = traffic_file()
+    if f is None:
+        return None
+    ks = json.loads(f.read_text()).get(workload, {}).get("kernels", {})
+    hit = [(v["hbm_bytes_per_launch"], v["launches"]) for k, v in ks.items() if k.startswith(prefix)]
+    if not hit:
+        return None
+    return round(sum(b * n for b, n in hit) / sum(n for _, n in hit))
+
+
 def traffic_has(workload: str) -> bool:
     import json
 
@@ -432,7 +446,7 @@ class TrainWorkload:
             t, by, n = priced[top]
             ach = by / (t * 1e-3) / 1e9
             out.update({"bound": "hbm", "kernel": LAUNCHER_KERNELS.get(top, top), "launcher": top, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(LAUNCHER_KERNELS.get(top, top), "train") if traffic_has("train") else None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic_prefix(LAUNCHER_KERNELS.get(top, top).split("<")[0] + "<", "train") if traffic_has("train") else None,
                         "kernel_ms": round(t / n, 4), "launches_per_step": n, "algorithmic_bytes_per_launch": round(by / n),
                         "measured": "fully bracketed steps after the timed region"})
             inside = timed_calls.get(top)

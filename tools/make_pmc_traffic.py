@@ -1,6 +1,6 @@
-"""profiles/rNN_pmc_traffic.json from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/evidence_r02.sh.
+"""profiles/rNN_pmc_traffic.json from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/evidence_r03_b.sh.
 
-usage: python tools/make_pmc_traffic.py gpurun_out/ev2 profiles/r02_pmc_traffic.json
+usage: python tools/make_pmc_traffic.py gpurun_out/ev3 profiles/r03_pmc_traffic.json
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies the
 128-byte requests of wide (16 B per lane) reads at 64 bytes (MI355X_MICROARCH.md, HBM section), so it is doubled.
 """
@@ -21,7 +21,7 @@ def main():
     ev, dst = Path(sys.argv[1]), Path(sys.argv[2])
     result = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 1 --no-cpu-baseline` "
                       "(frontend: --steps 2); hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of the symbol"}
-    for workload, suffix in (("predict", ""), ("frontend", "_fe"), ("hpsearch_f16_set3", "_h")):
+    for workload, suffix in (("predict", ""), ("frontend", "_fe"), ("hpsearch_f16_set3", "_h"), ("train", "_t")):
         if not (ev / f"pmc_fetch{suffix}").exists():
             continue
         d = summarise(ev / f"pmc_fetch{suffix}", ev / f"pmc_write{suffix}")
