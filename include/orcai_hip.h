@@ -401,6 +401,7 @@ int orcai_outer_reduce_pixels(int pixels);
 /* dW[tap][c] += sum r[c][p + off(tap)] * du[c][p], r = relu_in ? relu(x) : x  (depthwise weight gradient, written in the Keras
  * kernel layout (k, k, C, 1), i.e. straight into the flat gradient buffer) */
 int orcai_dw_wgrad(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
+int orcai_dw_wgrad_march(int on); /* experiments: 1 (default) = k = 3 launches on planes >= 100 pixels wide run the row-marching kernel (every byte requested once); 0 = the flat-window kernel everywhere; < 0 queries; returns the previous value */
 /* the same (k = 3) with r = the BatchNorm + ReLU of the pre-normalisation tensor v, formed on load (see orcai_sepconv_planes_stats_bn) */
 int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
                       float in_eps, float* dW, void* stream);

@@ -880,6 +880,111 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- depthwise weight gradient, k = 3, marching down a column strip
+// dw_wgrad_kernel requests every x row three times through L1 (as the row above, the row of, and the row below three different windows) and
+// runs at 3.2-3.7 TB/s on block-1 planes.  Here a wave owns a strip of 64 columns (62 of them outputs) of ONE channel quad and walks down a
+// segment of image rows: the x rows r - 1 and r stay in registers from the previous steps (with their two horizontally shifted copies), row
+// r + 1 and the gradient row r are the only loads of a step -- every byte is requested once -- and they are in flight two steps ahead.  The
+// loop is unrolled by three so that the roles (above, same, below) rotate through register sets without moves.  BNIN: BatchNorm + ReLU of
+// the pre-normalisation tensor applied once per arriving row (dw_wgrad_kernel does it three times per value).
+template <bool BNIN>
+__global__ __launch_bounds__(256) void dw_wgrad_march_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int relu_in,
+                                                              float* __restrict__ dW /*[9][C]*/, int nstrip, int nseg, int rows_per_seg, InBnW ib) {
+  constexpr int KK = 9;
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int cq = blockIdx.y, b = blockIdx.z;
+  const int CQ = (C + 3) >> 2;
+  const int plane = (H + 2) * WP;
+  const float4* xp = reinterpret_cast<const float4*>(x) + ((int64_t)b * CQ + cq) * plane;
+  const float4* dp = reinterpret_cast<const float4*>(du) + ((int64_t)b * CQ + cq) * plane;
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  const bool has_task = task < nstrip * nseg;  // wave-uniform
+  const int strip = has_task ? task % nstrip : 0, seg = has_task ? task / nstrip : 0;
+  const int xcol = strip * 62 - 1 + lane;                   // image column of this lane (lane 0 and 63: halo only)
+  const bool out_lane = has_task && lane >= 1 && lane <= 62 && xcol < W;
+  const bool col_in = xcol >= 0 && xcol < W;
+  const int r_begin = seg * rows_per_seg, r_end = has_task ? min(r_begin + rows_per_seg, H) : r_begin;
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BNIN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cq * 4 + j;
+      if (c < C) {
+        bsc[j] = ib.gamma[c] * rsqrtf(ib.var[c] + ib.eps);
+        bsh[j] = ib.beta[c] - ib.mean[c] * bsc[j];
+      }
+    }
+  }
+  struct Row { float c[4], l[4], r[4]; };  // the row's values at this lane's column, at the column to its left, to its right
+  auto xload = [&](int row) -> float4 {    // image row `row` (-1 .. H): padded-plane row row + 1; clamped, masked on arrival
+    int i = (row + 1) * WP + xcol;
+    i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    return xp[i];
+  };
+  auto dload = [&](int row) -> float4 {
+    int i = (row + 1) * WP + xcol;
+    i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    return dp[i];
+  };
+  auto arrive = [&](const float4& raw, int row, Row& o) {
+    const float v[4] = {raw.x, raw.y, raw.z, raw.w};
+    const bool inside = col_in && row >= 0 && row < H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = v[j];
+      if (BNIN) a = inside ? fmaxf(fmaf(a, bsc[j], bsh[j]), 0.0f) : 0.0f;
+      else if (relu_in) a = fmaxf(a, 0.0f);  // the planes' pads hold zeros already
+      o.c[j] = a;
+      o.l[j] = lsh<3, -1>(a);
+      o.r[j] = lsh<3, 1>(a);
+    }
+  };
+  auto step = [&](const Row& up, const Row& mid, const Row& dn, const float4& g4, int row) {
+    const bool live = out_lane && row < r_end;
+    const float g[4] = {live ? g4.x : 0.f, live ? g4.y : 0.f, live ? g4.z : 0.f, live ? g4.w : 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j][0] = fmaf(up.l[j], g[j], acc[j][0]); acc[j][1] = fmaf(up.c[j], g[j], acc[j][1]); acc[j][2] = fmaf(up.r[j], g[j], acc[j][2]);
+      acc[j][3] = fmaf(mid.l[j], g[j], acc[j][3]); acc[j][4] = fmaf(mid.c[j], g[j], acc[j][4]); acc[j][5] = fmaf(mid.r[j], g[j], acc[j][5]);
+      acc[j][6] = fmaf(dn.l[j], g[j], acc[j][6]); acc[j][7] = fmaf(dn.c[j], g[j], acc[j][7]); acc[j][8] = fmaf(dn.r[j], g[j], acc[j][8]);
+    }
+  };
+  if (r_begin < r_end) {
+    Row A, Bq, Cq;
+    arrive(xload(r_begin - 1), r_begin - 1, A);
+    arrive(xload(r_begin), r_begin, Bq);
+    // in flight: (x row r + 1, gradient row r) of the next THREE steps, one slot per step of the unrolled loop, each refilled right after it is
+    // consumed -- three steps of distance, and no register set with a load in flight is ever moved
+    float4 px0 = xload(r_begin + 1), pg0 = dload(r_begin), px1 = xload(r_begin + 2), pg1 = dload(r_begin + 1), px2 = xload(r_begin + 3), pg2 = dload(r_begin + 2);
+    for (int r = r_begin; r < r_end; r += 3) {  // rows past r_end contribute nothing (live is false); loads stay in the plane (clamped)
+      { const float4 xr = px0, gr = pg0; px0 = xload(r + 4); pg0 = dload(r + 3); arrive(xr, r + 1, Cq); step(A, Bq, Cq, gr, r); }       // up A, mid Bq, down Cq
+      { const float4 xr = px1, gr = pg1; px1 = xload(r + 5); pg1 = dload(r + 4); arrive(xr, r + 2, A); step(Bq, Cq, A, gr, r + 1); }    // up Bq, mid Cq, down A
+      { const float4 xr = px2, gr = pg2; px2 = xload(r + 6); pg2 = dload(r + 5); arrive(xr, r + 3, Bq); step(Cq, A, Bq, gr, r + 2); }   // up Cq, mid A, down Bq
+    }
+  }
+  __shared__ float red[4][4 * KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK;
+    const int t = threadIdx.x - j * KK;  // Keras depthwise kernel layout (k, k, C, 1): element (tap, channel) at tap*C + channel
+    if (cq * 4 + j < C) atomicAdd(&dW[t * C + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 // ---------------------------------------------------------------- conv0 weight gradient
 // dW0[tap][c] += sum_p in[p + off(tap)] * dv0[c][p]; the single-channel input is the UNPADDED snippet image.
 template <int KS>
@@ -1454,6 +1559,14 @@ int orcai_outer_reduce_pixels(int pixels) {
   return prev;
 }
 
+static int g_dw_wgrad_march = 1;  // k = 3, planes at least 100 pixels wide: dw_wgrad_march_kernel (orcai_dw_wgrad_march: A/B)
+
+int orcai_dw_wgrad_march(int on) {
+  const int prev = g_dw_wgrad_march;
+  if (on >= 0) g_dw_wgrad_march = on ? 1 : 0;
+  return prev;
+}
+
 static int dw_wgrad_impl(const float* x, const float* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, const InBnW* bn, void* stream) {
   if (!x || !du || !dW || B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0 || ktap > ksize_planes) return ORCAI_E_BADARG;
   const int WP = orcai_padded_width(W, ksize_planes), RP = ksize_planes / 2;
@@ -1463,6 +1576,23 @@ static int dw_wgrad_impl(const float* x, const float* du, int B, int C, int H, i
   if (tpw < 8) tpw = 8;
   dim3 grid(((tasks + tpw - 1) / tpw + 3) / 4, (C + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
+  if (ktap == 3 && ksize_planes == 3 && g_dw_wgrad_march && W >= 100 && (int64_t)(H + 2) * WP < (1ll << 27)) {
+    // wide planes (block 1 of orcai-V1): the marching kernel requests every byte once.  Strips of 62 columns; segments of rows so that the
+    // grid has >= ~4 waves per SIMD over the chip
+    const int nstrip = (W + 61) / 62;
+    int nseg = (int)((16384 + (int64_t)B * ((C + 3) / 4) * nstrip - 1) / ((int64_t)B * ((C + 3) / 4) * nstrip));
+    if (nseg < 1) nseg = 1;
+    if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;  // at least 24 rows per segment: two halo rows are re-read per segment
+    int rps = (H + nseg - 1) / nseg;
+    rps = (rps + 2) / 3 * 3;  // whole iterations of the loop unrolled by three
+    nseg = (H + rps - 1) / rps;
+    dim3 gridm((nstrip * nseg + 3) / 4, (C + 3) / 4, B);
+    InBnW ib;
+    if (bn) ib = *bn;
+    if (bn) hipLaunchKernelGGL((dw_wgrad_march_kernel<true>), gridm, dim3(256), 0, st, x, du, C, H, W, WP, 0, dW, nstrip, nseg, rps, ib);
+    else hipLaunchKernelGGL((dw_wgrad_march_kernel<false>), gridm, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, dW, nstrip, nseg, rps, ib);
+    return (int)hipGetLastError();
+  }
   if (bn) {
     if (ktap != 3 || (int64_t)(H + 2 * RP) * WP >= (1ll << 29)) return ORCAI_E_UNSUPPORTED;
     InBnW ib = *bn;

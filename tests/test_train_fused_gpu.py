@@ -359,3 +359,33 @@ def test_lstm_backward_on_split_f16_mfma_keeps_f32_accuracy(U, B, T, gscale):
     err = np.abs(got - ref).max() / scale
     print(f"LSTM backward units {U}, |dH| ~ {gscale:g}: max |split - f32| / max |dxz| = {err:.2e}")
     assert err <= 5e-6
+
+
+@pytest.mark.parametrize("C,H,W,B,relu", [(16, 37, 171, 2, 1), (30, 8, 130, 3, 0), (10, 70, 101, 1, 1), (30, 736, 171, 1, 0)])
+def test_marching_depthwise_weight_gradient(C, H, W, B, relu):
+    """dw_wgrad_march_kernel (wide planes: a wave walks down a 64-column strip, every x row and gradient row requested once) against the
+    flat-window kernel and float64: segments, strips, the ReLU on load and planes whose last strip hangs over the row pitch."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C + W)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    x, du = f(B, C, H, W), f(B, C, H, W)
+    xd, dud = torch.from_numpy(_quad_planes(x, 3)).cuda(), torch.from_numpy(_quad_planes(du, 3)).cuda()
+    xr = np.maximum(x, 0) if relu else x
+    xp = np.zeros((B, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = xr
+    want = np.stack([[np.einsum("bchw,bchw->c", xp[:, :, dy : dy + H, dx : dx + W], du.astype(np.float64)) for dx in range(3)] for dy in range(3)]).reshape(9, C)
+    got = {}
+    prev = lib.orcai_dw_wgrad_march(-1)
+    try:
+        for march in (0, 1):
+            lib.orcai_dw_wgrad_march(march)
+            dW = torch.zeros((9, C), device="cuda")
+            N.check(lib.orcai_dw_wgrad(N.ptr(xd), N.ptr(dud), B, C, H, W, 3, 3, relu, N.ptr(dW), N.stream_ptr()), "dw_wgrad")
+            got[march] = dW.cpu().numpy()
+    finally:
+        lib.orcai_dw_wgrad_march(prev)
+    tol = 2e-5 * np.sqrt(B * H * W) * max(1.0, np.abs(want).max() / np.sqrt(B * H * W))
+    for march in (0, 1):
+        assert np.abs(got[march] - want).max() <= max(tol, 1e-4 * np.abs(want).max()), (march, np.abs(got[march] - want).max(), np.abs(want).max())

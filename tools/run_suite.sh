@@ -1,7 +1,4 @@
 mkdir -p gpurun_out
-for i in 1 2; do timeout -k 10 300 python bench.py --workload train --no-cpu-baseline > gpurun_out/bench_train_$i.json 2> gpurun_out/bench_train_$i.err; python - <<PY
-import json
-d = json.load(open("gpurun_out/bench_train_$i.json")); r = d["roofline"]
-print("train", d["value"], d["ms_per_step"], r.get("launcher"), r.get("frac"), r.get("kernel_ms"), r.get("kernel_in_timed_steps"))
-PY
-done
+timeout -k 10 900 python -m pytest tests/test_train_fused_gpu.py tests/test_train_full_gpu.py tests/test_random_configs_gpu.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | cut -c1-600 > gpurun_out/pytest_fe.log
+echo "pytest rc ${PIPESTATUS[0]}"; tail -n 6 gpurun_out/pytest_fe.log
+timeout -k 10 300 python tools/ab_lib.py orcai_dw_wgrad_march 0,1 3 > gpurun_out/ab_flags.log 2>&1; tail -n 6 gpurun_out/ab_flags.log
