@@ -405,6 +405,17 @@ int orcai_dw_wgrad_march(int on); /* experiments: 1 (default) = k = 3 launches o
 /* the same (k = 3) with r = the BatchNorm + ReLU of the pre-normalisation tensor v, formed on load (see orcai_sepconv_planes_stats_bn) */
 int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
                       float in_eps, float* dW, void* stream);
+/* Depthwise backward of a k = 3 separable conv in ONE pass over (du, x) (replaces orcai_sepconv_planes_epi + orcai_dw_wgrad[_bn]; Keras: the
+ * DepthwiseConv2D half of SeparableConv2D's gradient, reference architectures.py:66-86 trained by train.py:201-219):
+ *   dr = du (*) reversed depthwise taps (dw_rev: [ceil(C/4)][9][4], tap t = forward tap 8 - t)    -- the gradient w.r.t. the conv's input
+ *   dW[tap][c] += sum_p r[c][p + off(tap)] * du[c][p]                                              -- as orcai_dw_wgrad (Keras layout (3, 3, C, 1))
+ * with r = relu_in ? relu(x) : x, or, when bn_mean != NULL, r = relu(BatchNorm(x)) formed on load (x = pre-normalisation tensor, as
+ * orcai_dw_wgrad_bn).  epi 0: nothing else.  epi 2 (needs the BatchNorm arguments): dr is the gradient of that BatchNorm's output; its backward
+ * sums sum g | sum g * xhat (g = dr gated by the ReLU when bn_relu) are left in `shards` as dbeta[4 CQ] | dgamma[4 CQ] doubles (>= 8 * CQ * 32
+ * doubles of scratch) for orcai_bn_bwd_pointwise[_wgrad](sums_ready = 1).  epi 3 (relu_in = 1, no BatchNorm): dr is masked by x > 0.  Only the
+ * interior of dr is written.  ORCAI_E_UNSUPPORTED (nothing touched): C > 64, misaligned planes. */
+int orcai_dw_bwd_fused(const float* x, const float* du, int B, int C, int H, int W, int relu_in, const float* dw_rev, float* dr, float* dW, int epi, const float* bn_mean,
+                       const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);
 /* Keras-Reshape layout f32[B][H][W*C] -> padded channel-quad planes (gradient entering the final separable conv) */

@@ -985,6 +985,166 @@ __global__ __launch_bounds__(256) void dw_wgrad_march_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- depthwise backward in ONE marching pass (k = 3)
+// The two passes of a separable conv's backward that read the depthwise-output gradient du -- the input gradient dr = du (*) flipped taps
+// (orcai_sepconv_planes_epi: du and the reference tensor in, dr out) and the depthwise weight gradient (orcai_dw_wgrad[_bn]: x and du in) --
+// use the SAME operands at every pixel: with q = p + tap offset,
+//   dr[p]    = sum_tap wrev[tap] * du[p + off(tap)]            dWrev[tap] = sum_p x[p] * du[p + off(tap)]        (dW[tap] = dWrev[8 - tap])
+// and the epilogue extras of the input-gradient pass (EPI 2: backward sums of the BatchNorm whose pre-normalisation tensor is x; EPI 3: ReLU mask
+// x > 0) read x at p as well.  So one wave marches down a column strip of one channel quad with the three du rows (and their two shifted
+// copies) in registers; a step loads ONE du row and ONE x row (in flight three steps ahead, as in dw_wgrad_march_kernel), and writes one dr row:
+// du, x read once, dr written once -- 3 plane passes where the two launches moved 2 + 3 (EPI 2) or 2 + 2.
+// SW lanes per strip (64, 32 or 16: SW - 2 output columns): a wave carries 64 / SW strips of the same (snippet, quad), so planes narrower than
+// 62 columns do not idle most lanes (W = 86: three 30-column strips = 96 lanes).  Strips beside each other in a wave exchange garbage through the
+// DPP shifts only into their halo lanes, which produce nothing.
+template <int SW, int EPI, bool BNIN>
+__global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int relu_in,
+                                                            const float* __restrict__ wrev /*[CQ][9][4] reversed taps*/, float* __restrict__ dr,
+                                                            float* __restrict__ dW /*[9][C]*/, double* __restrict__ shards /*EPI 2: [32][CQ][8]*/, int nstrip,
+                                                            int nseg, int rps, InBnW ib, int epi_relu) {
+  static_assert(SW == 64 || SW == 32 || SW == 16, "strip lanes");
+  static_assert(EPI == 0 || EPI == 2 || EPI == 3, "epilogue extras");
+  static_assert(EPI != 2 || BNIN, "EPI 2: x is the pre-normalisation tensor of the BatchNorm whose backward sums are taken");
+  constexpr int KK = 9, NSUB = 64 / SW;
+  const int lane = threadIdx.x & 63, sl = lane % SW, sub = lane / SW;
+  const int cq = blockIdx.y, b = blockIdx.z;
+  const int CQ = (C + 3) >> 2;
+  const int plane = (H + 2) * WP;
+  const int64_t pbase = ((int64_t)b * CQ + cq) * plane;
+  const float4* xp = reinterpret_cast<const float4*>(x) + pbase;
+  const float4* dp = reinterpret_cast<const float4*>(du) + pbase;
+  float4* op = reinterpret_cast<float4*>(dr) + pbase;
+  const int task = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NSUB + sub;
+  const bool has_task = task < nstrip * nseg;
+  const int strip = has_task ? task % nstrip : 0, seg = has_task ? task / nstrip : 0;
+  const int xcol = strip * (SW - 2) - 1 + sl;  // image column of this lane (first and last lane of a strip: halo only)
+  const bool out_lane = has_task && sl >= 1 && sl <= SW - 2 && xcol < W;
+  const int r_begin = seg * rps, r_end = min(r_begin + rps, H);  // per strip; every strip of the wave walks rps rows
+  float acc[4][KK];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};  // EPI 2: sum g, sum g * xhat over this lane's pixels
+  float wt[4][KK];  // wave-uniform: scalar loads
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wt[j][t] = wrev[(cq * KK + t) * 4 + j];
+  float bsc[4] = {0.f, 0.f, 0.f, 0.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f}, binv[4] = {0.f, 0.f, 0.f, 0.f}, bgm[4] = {0.f, 0.f, 0.f, 0.f},
+        bbt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BNIN) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cq * 4 + j;
+      if (c < C) {
+        binv[j] = rsqrtf(ib.var[c] + ib.eps);
+        bmu[j] = ib.mean[c]; bgm[j] = ib.gamma[c]; bbt[j] = ib.beta[c];
+        bsc[j] = bgm[j] * binv[j];  // bn_planes_apply_kernel's folded form: the tensor the forward conv saw, bit for bit
+        bsh[j] = bbt[j] - bmu[j] * bsc[j];
+      }
+    }
+  }
+  struct Row { float c[4], l[4], r[4]; };
+  auto pix = [&](int row) -> int {  // image row `row` (-1 .. H): padded-plane row row + 1; clamped (rows past the segment feed dead steps only)
+    const int i = (row + 1) * WP + xcol;
+    return i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+  };
+  auto arrive = [&](const float4& raw, Row& o) {
+    const float v[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o.c[j] = v[j];
+      o.l[j] = lsh<3, -1>(v[j]);
+      o.r[j] = lsh<3, 1>(v[j]);
+    }
+  };
+  auto step = [&](const Row& up, const Row& mid, const Row& dn, const float4& x4, int row) {
+    const bool live = out_lane && row < r_end;
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    float d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float y = xv[j];
+      if (BNIN) y = fmaxf(fmaf(y, bsc[j], bsh[j]), 0.0f);  // a live lane is inside the image
+      else if (relu_in) y = fmaxf(y, 0.0f);
+      y = live ? y : 0.0f;
+      float a = up.l[j] * wt[j][0];
+      a = fmaf(up.c[j], wt[j][1], a); a = fmaf(up.r[j], wt[j][2], a);
+      a = fmaf(mid.l[j], wt[j][3], a); a = fmaf(mid.c[j], wt[j][4], a); a = fmaf(mid.r[j], wt[j][5], a);
+      a = fmaf(dn.l[j], wt[j][6], a); a = fmaf(dn.c[j], wt[j][7], a); a = fmaf(dn.r[j], wt[j][8], a);
+      acc[j][0] = fmaf(up.l[j], y, acc[j][0]); acc[j][1] = fmaf(up.c[j], y, acc[j][1]); acc[j][2] = fmaf(up.r[j], y, acc[j][2]);
+      acc[j][3] = fmaf(mid.l[j], y, acc[j][3]); acc[j][4] = fmaf(mid.c[j], y, acc[j][4]); acc[j][5] = fmaf(mid.r[j], y, acc[j][5]);
+      acc[j][6] = fmaf(dn.l[j], y, acc[j][6]); acc[j][7] = fmaf(dn.c[j], y, acc[j][7]); acc[j][8] = fmaf(dn.r[j], y, acc[j][8]);
+      if (EPI == 2) {  // the arithmetic of bn_planes_bwd_sums_kernel / the EPI 2 epilogue of the tile kernels
+        const float xh = (xv[j] - bmu[j]) * binv[j];
+        const bool gate = !epi_relu || fmaf(xh, bgm[j], bbt[j]) > 0.0f;
+        const float gg = (live && gate) ? a : 0.0f;
+        s1[j] += gg;
+        s2[j] = fmaf(gg, xh, s2[j]);
+      }
+      if (EPI == 3) a = xv[j] > 0.0f ? a : 0.0f;
+      d[j] = a;
+    }
+    if (live) op[(row + 1) * WP + xcol] = make_float4(d[0], d[1], d[2], d[3]);
+  };
+  if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+    Row A, Bq, Cq;
+    arrive(dp[pix(r_begin - 1)], A);
+    arrive(dp[pix(r_begin)], Bq);
+    // in flight: (du row r + 1, x row r) of the next THREE steps, one slot per step of the unrolled loop, refilled right after it is consumed
+    float4 pg0 = dp[pix(r_begin + 1)], px0 = xp[pix(r_begin)], pg1 = dp[pix(r_begin + 2)], px1 = xp[pix(r_begin + 1)], pg2 = dp[pix(r_begin + 3)], px2 = xp[pix(r_begin + 2)];
+    for (int i = 0; i < rps; i += 3) {  // rps is a multiple of three; rows past r_end contribute nothing
+      const int r = r_begin + i;
+      { const float4 gr = pg0, xr = px0; pg0 = dp[pix(r + 4)]; px0 = xp[pix(r + 3)]; arrive(gr, Cq); step(A, Bq, Cq, xr, r); }      // up A, mid Bq, down Cq
+      { const float4 gr = pg1, xr = px1; pg1 = dp[pix(r + 5)]; px1 = xp[pix(r + 4)]; arrive(gr, A); step(Bq, Cq, A, xr, r + 1); }   // up Bq, mid Cq, down A
+      { const float4 gr = pg2, xr = px2; pg2 = dp[pix(r + 6)]; px2 = xp[pix(r + 5)]; arrive(gr, Bq); step(Cq, A, Bq, xr, r + 2); }  // up Cq, mid A, down Bq
+    }
+  }
+  constexpr int NRED = 4 * KK + (EPI == 2 ? 8 : 0);
+  __shared__ float red[4][NRED];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+    }
+  if (EPI == 2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = j < 4 ? s1[j & 3] : s2[j & 3];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][4 * KK + j] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * KK) {
+    const int j = threadIdx.x / KK;
+    const int t = threadIdx.x - j * KK;  // accumulator t belongs to the REVERSED tap: Keras layout (k, k, C, 1), element (tap, channel) at tap * C + channel
+    if (cq * 4 + j < C) atomicAdd(&dW[(KK - 1 - t) * C + cq * 4 + j], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  } else if (EPI == 2 && threadIdx.x < NRED) {
+    const int j = threadIdx.x - 4 * KK;  // 0..3 sum g, 4..7 sum g * xhat: one f64 atomic per value and workgroup into one of 32 accumulator copies
+    const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&shards[((int64_t)((blockIdx.x + 7 * b + 3 * cq) & 31) * CQ + cq) * 8 + j], (double)tot);
+  }
+}
+
+// the 32 accumulator copies [32][CQ][8] -> scratch2C = dbeta[4 CQ] | dgamma[4 CQ] (doubles), in place by one workgroup (all reads before the first write)
+__global__ __launch_bounds__(256) void bwd_sums_compact_kernel(double* __restrict__ shards, int CQ) {
+  const int t = threadIdx.x;
+  double tot = 0.0;
+  if (t < 8 * CQ) {
+    const int which = t >= 4 * CQ, c = which ? t - 4 * CQ : t;
+    for (int sh = 0; sh < 32; ++sh) tot += shards[((int64_t)sh * CQ + (c >> 2)) * 8 + which * 4 + (c & 3)];
+  }
+  __syncthreads();
+  if (t < 8 * CQ) shards[t] = tot;
+}
+
 // ---------------------------------------------------------------- conv0 weight gradient
 // dW0[tap][c] += sum_p in[p + off(tap)] * dv0[c][p]; the single-channel input is the UNPADDED snippet image.
 template <int KS>
@@ -1284,6 +1444,27 @@ __global__ __launch_bounds__(256) void relu_bwd4_kernel(const float4* __restrict
   if (i >= n4) return;
   const float4 d = dy[i], v = y[i];
   dx[i] = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+}
+
+template <int SW>
+static int launch_dw_bwd(hipStream_t st, const float* x, const float* du, int B, int C, int H, int W, int WP, int relu_in, const float* wrev, float* dr, float* dW, int epi,
+                         const InBnW& ib, int epi_relu, double* shards, int nstrip) {
+  constexpr int NSUB = 64 / SW;
+  const int CQ = (C + 3) / 4;
+  const int64_t per_seg = (int64_t)B * CQ * nstrip;
+  int nseg = (int)((16384ll * NSUB + per_seg - 1) / per_seg);  // ~16 waves per SIMD over the chip in total
+  if (nseg < 1) nseg = 1;
+  if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;  // at least 24 rows per segment: two halo rows of du are re-read per segment
+  int rps = (H + nseg - 1) / nseg;
+  rps = (rps + 2) / 3 * 3;  // whole iterations of the loop unrolled by three
+  nseg = (H + rps - 1) / rps;
+  const int waves = (nstrip * nseg + NSUB - 1) / NSUB;
+  dim3 grid((waves + 3) / 4, CQ, B);
+  if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu);
+  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  else hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -1619,6 +1800,35 @@ int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int 
   InBnW ib;
   ib.mean = in_mean; ib.var = in_var; ib.gamma = in_gamma; ib.beta = in_beta; ib.eps = in_eps;
   return dw_wgrad_impl(v, du, B, C, H, W, 3, 3, 0, dW, &ib, stream);
+}
+
+int orcai_dw_bwd_fused(const float* x, const float* du, int B, int C, int H, int W, int relu_in, const float* dw_rev, float* dr, float* dW, int epi, const float* bn_mean,
+                       const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream) {
+  if (!x || !du || !dw_rev || !dr || !dW || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (epi != 0 && epi != 2 && epi != 3)) return ORCAI_E_BADARG;
+  const bool bn = bn_mean != nullptr;
+  if (bn && (!bn_var || !bn_gamma || !bn_beta)) return ORCAI_E_BADARG;
+  if (epi == 2 && (!bn || !shards)) return ORCAI_E_BADARG;
+  if (epi == 3 && (bn || !relu_in)) return ORCAI_E_BADARG;  // the mask x > 0 is the ReLU in front of the conv
+  const int WP = orcai_padded_width(W, 3), CQ = (C + 3) / 4;
+  if (B > 65535 || CQ > 65535 || C > 64 || (int64_t)(H + 2) * WP >= (1ll << 27) || ((uintptr_t)x & 15) || ((uintptr_t)du & 15) || ((uintptr_t)dr & 15)) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  InBnW ib;
+  if (bn) { ib.mean = bn_mean; ib.var = bn_var; ib.gamma = bn_gamma; ib.beta = bn_beta; ib.eps = bn_eps; }
+  if (epi == 2) {
+    hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * CQ * 32, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // strip width: the one that idles the fewest lanes (ties: the widest -- fewer halo columns)
+  int best = 64, best_lanes = ((W + 61) / 62) * 64;
+  if (((W + 29) / 30) * 32 < best_lanes) { best = 32; best_lanes = ((W + 29) / 30) * 32; }
+  if (((W + 13) / 14) * 16 < best_lanes) { best = 16; best_lanes = ((W + 13) / 14) * 16; }
+  int rc;
+  if (best == 64) rc = launch_dw_bwd<64>(st, x, du, B, C, H, W, WP, relu_in, dw_rev, dr, dW, epi, ib, bn_relu, shards, (W + 61) / 62);
+  else if (best == 32) rc = launch_dw_bwd<32>(st, x, du, B, C, H, W, WP, relu_in, dw_rev, dr, dW, epi, ib, bn_relu, shards, (W + 29) / 30);
+  else rc = launch_dw_bwd<16>(st, x, du, B, C, H, W, WP, relu_in, dw_rev, dr, dW, epi, ib, bn_relu, shards, (W + 13) / 14);
+  if (rc != 0) return rc;
+  if (epi == 2) hipLaunchKernelGGL(bwd_sums_compact_kernel, dim3(1), dim3(256), 0, st, shards, CQ);
+  return (int)hipGetLastError();
 }
 
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream) {

@@ -389,6 +389,7 @@ class TrunkTrainer:
         self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
+        self.fused_dw_bwd = True  # input gradient + its epilogue extra + depthwise weight gradient of a k = 3 separable conv in one marching pass (A/B: tools/ab_flags.py)
         self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
         self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
@@ -698,6 +699,34 @@ class TrunkTrainer:
         self._sep(du, Cin, H, W, k, 0, dw, eye, zeros, Cin, dr)
         return False
 
+    def _dw_bwd_fused(self, name, x, relu_in, Cin, H, W, du, dr, epi, x_bn):
+        """orcai_dw_bwd_fused for one separable conv: dr, the depthwise weight gradient and the epilogue extra `epi` of _dgrad in one pass over
+        (du, x).  Returns whether the epilogue extra ran (True / False), or None when the launch is not this kernel's (the caller runs the
+        separate passes): the extras read the conv's own input, so ("bsums", ref, ...) needs ref to be the pre-normalisation tensor x."""
+        P = self.P
+        mode, bn, bn_relu = 0, x_bn, 0
+        if epi is not None and self.dgrad_epilogues:
+            if epi[0] == "bsums":
+                if x_bn is None or epi[2] != x_bn or epi[1].data_ptr() != x.data_ptr():
+                    return None
+                mode, bn_relu = 2, epi[3]
+            elif epi[0] == "relu":
+                if x_bn is not None or not relu_in or epi[1].data_ptr() != x.data_ptr():
+                    return None
+                mode = 3
+        elif epi is not None:
+            return None
+        bnp = [None] * 4
+        if bn is not None:
+            mean, var = self.stats[bn]
+            bnp = [mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(), P.W(bn + "/beta").data_ptr()]
+        rc = self.lib.orcai_dw_bwd_fused(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, relu_in, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
+                                         P.G(name + "/depthwise").data_ptr(), mode, *bnp, BN_EPS, bn_relu, self.scratch.data_ptr(), N.stream_ptr())
+        if rc == N.E_UNSUPPORTED:
+            return None
+        N.check(rc, "orcai_dw_bwd_fused")
+        return mode != 0
+
     def _sep_backward(self, name, x, relu_in, Cin, Cout, H, W, dv, u, du, dr, have_du=False, have_pw_wgrad=False, epi=None, x_bn=None):
         """Backward of one separable conv (+bias): fills dW(depthwise), dW(pointwise), dbias; writes dr = gradient w.r.t. the
         (ReLU'd) input into `dr` (planes of Cin channels)."""
@@ -709,6 +738,14 @@ class TrunkTrainer:
             wt = self._w_pwT(name + "/pointwise", Cin, Cout)
             self._sep(dv, Cout, H, W, 1, 0, self._w_ones_dw(Cout), wt, self._zeros(64), Cin, du)
         epi_ran = False
+        if self.fused_dw_bwd and k == 3 and not self.half:
+            # one marching pass over (du, x): input gradient, its epilogue extra and the depthwise weight gradient (csrc/train_trunk.hip: dw_bwd_march_kernel)
+            fused = self._dw_bwd_fused(name, x, relu_in, Cin, H, W, du, dr, epi, x_bn)
+            if fused is not None:
+                if not have_pw_wgrad:
+                    N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
+                                                     self.partials.numel(), st), "outer_reduce")
+                return fused
         if self.dgrad_first:
             # the input gradient (the only kernel of this layer the next layer waits for) first; the two weight-gradient passes are
             # read-only, and a read-only pass runs faster behind a kernel that wrote ANOTHER tensor (dr) than directly behind the writer

@@ -389,3 +389,80 @@ def test_marching_depthwise_weight_gradient(C, H, W, B, relu):
     tol = 2e-5 * np.sqrt(B * H * W) * max(1.0, np.abs(want).max() / np.sqrt(B * H * W))
     for march in (0, 1):
         assert np.abs(got[march] - want).max() <= max(tol, 1e-4 * np.abs(want).max()), (march, np.abs(got[march] - want).max(), np.abs(want).max())
+
+
+@pytest.mark.parametrize("C,H,W,B,mode", [(30, 37, 171, 2, 2), (16, 40, 171, 2, 0), (30, 23, 86, 3, 3), (40, 25, 86, 2, 2), (50, 31, 43, 2, 2), (40, 12, 43, 3, 3),
+                                          (60, 9, 22, 4, 2), (50, 7, 22, 2, 3), (10, 16, 12, 5, 2), (30, 736, 171, 1, 2), (30, 5, 62, 1, 3), (36, 11, 63, 2, 1),
+                                          (30, 50, 300, 1, 2), (7, 3, 1, 2, 3)])
+def test_depthwise_backward_in_one_marching_pass(C, H, W, B, mode):
+    """orcai_dw_bwd_fused (input gradient + epilogue extra + depthwise weight gradient from one pass over (du, x)) against the launches it
+    replaces -- orcai_sepconv_planes_u with reversed taps and the identity pointwise factor, orcai_dw_wgrad / orcai_dw_wgrad_bn,
+    orcai_bn_bwd_pointwise's own reduction pass -- and float64: mode 0 plain (ReLU on load), 1 plain with BatchNorm + ReLU on load, 2 BatchNorm
+    backward sums of the output (x = the pre-normalisation tensor), 3 ReLU mask by x > 0.  Strip widths 64 / 32 / 16, several segments, planes
+    whose last strip hangs over the row pitch, a single column; pads of the output stay zero; the gradient buffer is accumulated into."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C * 3 + W + mode)
+    k = 3
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    x, du = 2.0 * f(B, C, H, W), f(B, C, H, W)
+    mean, var = 0.3 * f(C), (0.5 + rng.random(C)).astype(np.float32)
+    gamma, beta = 1 + 0.3 * f(C), 0.4 * f(C) + 0.3
+    CQ = (C + 3) // 4
+    taps = f(9, C)  # Keras depthwise kernel (3, 3, C, 1) flattened
+    rev = np.zeros((CQ * 4, 9), dtype=np.float32)
+    rev[:C] = taps[::-1].T  # reversed taps, [channel][tap]
+    rev = np.ascontiguousarray(rev.reshape(CQ, 4, 9).transpose(0, 2, 1))  # [CQ][9][4]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    xd, dud, revd = dev(_quad_planes(x, k)), dev(_quad_planes(du, k)), dev(rev)
+    md, vd, gd, bd = dev(mean), dev(var), dev(gamma), dev(beta)
+    eye, ones, zeros = torch.eye(C, device="cuda").contiguous(), torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    st = N.stream_ptr()
+    bn = mode in (1, 2)
+    relu_in = 0 if bn else 1
+    # the separate launches
+    plain = torch.zeros_like(dud)
+    N.check(lib.orcai_sepconv_planes_u(N.ptr(dud), B, C, H, W, k, k, 0, N.ptr(revd), N.ptr(eye), N.ptr(ones), N.ptr(zeros), C, 0, 0, 0, 0, N.ptr(plain), None, st), "plain")
+    dW_sep = torch.full((9, C), 0.25, device="cuda")
+    if bn:
+        N.check(lib.orcai_dw_wgrad_bn(N.ptr(xd), N.ptr(dud), B, C, H, W, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, N.ptr(dW_sep), st), "dw_wgrad_bn")
+    else:
+        N.check(lib.orcai_dw_wgrad(N.ptr(xd), N.ptr(dud), B, C, H, W, k, k, relu_in, N.ptr(dW_sep), st), "dw_wgrad")
+    # fused
+    out = torch.zeros_like(dud)
+    dW = torch.full((9, C), 0.25, device="cuda")
+    shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device="cuda")
+    epi = {0: 0, 1: 0, 2: 2, 3: 3}[mode]
+    bnp = [N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd)] if bn else [None] * 4
+    N.check(lib.orcai_dw_bwd_fused(N.ptr(xd), N.ptr(dud), B, C, H, W, relu_in, N.ptr(revd), N.ptr(out), N.ptr(dW), epi, *bnp, 1e-3, 1, N.ptr(shards), st), "dw_bwd_fused")
+    torch.cuda.synchronize()
+    want_out = torch.where(xd > 0, plain, torch.zeros_like(plain)) if mode == 3 else plain
+    scale = max(1.0, float(plain.abs().max()))
+    assert float((out - want_out).abs().max()) <= 2e-6 * scale  # the same nine products, one summation order against another
+    pads = out.cpu().numpy().copy()
+    pads[:, :, 1 : 1 + H, :W, :] = 0
+    assert float(np.abs(pads).max()) == 0.0
+    # weight gradient against float64 and the separate kernel
+    inv = 1.0 / np.sqrt(var.astype(np.float64) + 1e-3)
+    if bn:
+        sc = (gamma * (1.0 / np.sqrt(var + np.float32(1e-3))).astype(np.float32)).astype(np.float32)
+        xr = np.maximum(x * sc[None, :, None, None] + (beta - mean * sc)[None, :, None, None], 0).astype(np.float64)
+    else:
+        xr = np.maximum(x, 0).astype(np.float64)
+    xp = np.zeros((B, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = xr
+    want = np.stack([[np.einsum("bchw,bchw->c", xp[:, :, dy : dy + H, dx : dx + W], du.astype(np.float64)) for dx in range(3)] for dy in range(3)]).reshape(9, C)
+    n = B * H * W
+    tol = max(2e-5 * np.sqrt(n) * max(1.0, np.abs(want).max() / np.sqrt(n)), 1e-4 * np.abs(want).max())
+    got, sep = dW.cpu().numpy() - 0.25, dW_sep.cpu().numpy() - 0.25
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+    assert np.abs(sep - want).max() <= tol
+    if mode == 2:  # BatchNorm backward sums of the output, gated by the ReLU
+        dy = _from_quad(plain.cpu().numpy(), C, H, W, k).astype(np.float64)
+        xh = (x.astype(np.float64) - mean[None, :, None, None]) * inv[None, :, None, None]
+        g = np.where(xh * gamma[None, :, None, None] + beta[None, :, None, None] > 0, dy, 0.0)
+        db_ref, dg_ref = g.sum(axis=(0, 2, 3)), (g * xh).sum(axis=(0, 2, 3))
+        s = shards.cpu().numpy()
+        tol_s = 3e-6 * np.sqrt(n) * max(1.0, np.abs(dy).max() * 3)
+        assert np.abs(s[:C] - db_ref).max() <= tol_s and np.abs(s[4 * CQ : 4 * CQ + C] - dg_ref).max() <= tol_s, (np.abs(s[:C] - db_ref).max(), np.abs(s[4 * CQ : 4 * CQ + C] - dg_ref).max(), tol_s)

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_train_fused_gpu.py tests/test_train_full_gpu.py tests/test_random_configs_gpu.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | cut -c1-600 > gpurun_out/pytest_fe.log
 echo "pytest rc ${PIPESTATUS[0]}"; tail -n 6 gpurun_out/pytest_fe.log
-timeout -k 10 300 python tools/ab_lib.py orcai_dw_wgrad_march 0,1 3 > gpurun_out/ab_flags.log 2>&1; tail -n 6 gpurun_out/ab_flags.log
+timeout -k 10 300 python tools/ab_flags.py fused_dw_bwd 3 > gpurun_out/ab_flags.log 2>&1; tail -n 6 gpurun_out/ab_flags.log
