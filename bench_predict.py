@@ -319,7 +319,8 @@ LAUNCHER_KERNELS = {"orcai_bn_bwd_pointwise": "bn_bwd_pw_kernel<MT>", "orcai_out
                     "orcai_sepconv_planes_stats": "sepconv_tile_kernel / sepconv_ftile_kernel<..., STATS = true>", "orcai_sepconv_planes_u": "sepconv_*_kernel",
                     "orcai_bn_planes_stats": "planes_sums_kernel", "orcai_bn_planes_apply": "bn_planes_apply_kernel",
                     "orcai_bn_bwd_pointwise_wgrad": "bn_bwd_pw_wgrad_kernel<MT, NT, 4>", "orcai_sepconv_planes_epi": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 2 | 3>",
-                    "orcai_sepconv_planes_stats_bn": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 1, BNIN>", "orcai_dw_wgrad_bn": "dw_wgrad_kernel<3, true>"}
+                    "orcai_sepconv_planes_stats_bn": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 1, BNIN>", "orcai_dw_wgrad_bn": "dw_wgrad_kernel<3, true>",
+                    "orcai_dw_bwd_fused": "dw_bwd_march_kernel<SW, EPI, BNIN>"}
 
 
 def measured_traffic_prefix(prefix: str, workload: str):
@@ -361,6 +362,8 @@ def _train_call_bytes(name, a):
     if name == "orcai_bn_bwd_pointwise_wgrad":  # dy,v,u,B,C,H,W,ksize,...,wt,Cin,du,...: dy, v (C channels), u and du (Cin channels); dv is never moved
         B, C, H, W, Cin = a[3], a[4], a[5], a[6], a[19]
         return 4.0 * B * H * W * (2 * C + 2 * Cin)
+    if name == "orcai_dw_bwd_fused":  # x,du,B,C,H,W,...: du and x read once, dr written once
+        return 4.0 * a[2] * a[4] * a[5] * 3 * a[3]
     if name == "orcai_dw_wgrad_bn":  # v,du,B,C,H,W,...
         return 4.0 * a[2] * a[4] * a[5] * 2 * a[3]
     if name == "orcai_bn_bwd_pointwise":  # dy,v,B,C,H,W,ksize,mean,var,gamma,beta,eps,relu,scratch,sums_ready,dbeta,dgamma,wt,Cin,dv,du,stream
