@@ -510,6 +510,11 @@ int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, 
 int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, float* workspace,
                          int64_t workspace_floats, void* stream);
 int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);
+/* orcai_dw_bwd_fused on f16 octet planes (dw_rev: f16 [ceil(C/8)][9][8] reversed taps; dr f16; dW and the sums f32 / f64): with the BatchNorm
+ * arguments x is the pre-normalisation tensor and y = f16(relu(BN(x))) is formed on load -- the value orcai_h_bn_planes_apply stored.  shards: >= 16 *
+ * ceil(C/8) * 32 doubles; epi 2 leaves dbeta[8 CO] | dgamma[8 CO] there for orcai_h_bn_bwd_pointwise(sums_ready = 1). */
+int orcai_h_dw_bwd_fused(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
+                         const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream);
 int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
                          const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream);
 int orcai_h_pack_weights(const float* w, const int* desc, int n_desc, void* out, void* stream);

@@ -633,6 +633,192 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- depthwise backward in ONE marching pass (k = 3), f16 octet planes
+// The f16 twin of train_trunk.hip's dw_bwd_march_kernel: the input gradient dr = du (*) reversed taps (what orcai_h_sepconv computes with the
+// identity pointwise factor: packed-f16 products, f16 output), its epilogue extra (EPI 2: backward sums of the BatchNorm whose pre-normalisation
+// tensor is x, f32 terms; EPI 3: ReLU mask x > 0 -- the separate orcai_h_planes_relu_bwd pass) and the depthwise weight gradient (f32 accumulators,
+// the products of orcai_h_dw_wgrad) from ONE pass over (du, x): a wave marches down a column strip of one channel OCTET with the three du rows and
+// their two shifted copies in registers (packed f16), a step loads one du row and one x row, three steps ahead, and stores one dr row.
+// BNIN: x is the pre-normalisation tensor v; y = f16(relu(fma(v, s, t))) is formed on load -- the value bn_planes_apply_h_kernel stored -- so the
+// materialised y_a is not read by the backward pass at all.
+struct InBnH {
+  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;
+  float eps = 0.0f;
+};
+
+// acc = fma(f32(half HI ? upper : lower of d), y, acc)
+__device__ __forceinline__ void mixacc(int hi, float& acc, uint32_t d, float y) {  // hi: a constant after unrolling
+  if (hi) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(d), "v"(y));
+  else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(d), "v"(y));
+}
+
+template <int SW, int EPI, bool BNIN>
+__global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restrict__ x, const h16* __restrict__ du, int C, int H, int W, int WP, int relu_in,
+                                                              const h16* __restrict__ wrev /*[CO][9][8] reversed taps*/, h16* __restrict__ dr,
+                                                              float* __restrict__ dW /*[9][C]*/, double* __restrict__ shards /*EPI 2: [32][CO][16]*/, int nstrip,
+                                                              int nseg, int rps, InBnH ib, int epi_relu) {
+  static_assert(SW == 64 || SW == 32 || SW == 16, "strip lanes");
+  static_assert(EPI == 0 || EPI == 2 || EPI == 3, "epilogue extras");
+  static_assert(EPI != 2 || BNIN, "EPI 2: x is the pre-normalisation tensor of the BatchNorm whose backward sums are taken");
+  constexpr int KK = 9, NSUB = 64 / SW;
+  const int lane = threadIdx.x & 63, sl = lane % SW, sub = lane / SW;
+  const int co = blockIdx.y, b = blockIdx.z;
+  const int CO = (C + 7) >> 3;
+  const int plane = (H + 2) * WP;
+  const int64_t pbase = ((int64_t)b * CO + co) * plane;
+  const h16x8* xp = reinterpret_cast<const h16x8*>(x) + pbase;
+  const h16x8* dp = reinterpret_cast<const h16x8*>(du) + pbase;
+  h16x8* op = reinterpret_cast<h16x8*>(dr) + pbase;
+  const int task = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NSUB + sub;
+  const bool has_task = task < nstrip * nseg;
+  const int strip = has_task ? task % nstrip : 0, seg = has_task ? task / nstrip : 0;
+  const int xcol = strip * (SW - 2) - 1 + sl;
+  const bool out_lane = has_task && sl >= 1 && sl <= SW - 2 && xcol < W;
+  const int r_begin = seg * rps, r_end = min(r_begin + rps, H);
+  float acc[8][KK];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[j][t] = 0.0f;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.0f;
+  h16x8 wt[KK];  // wave-uniform
+#pragma unroll
+  for (int t = 0; t < KK; ++t) wt[t] = *reinterpret_cast<const h16x8*>(wrev + ((int64_t)co * KK + t) * 8);
+  float bsc[8], bsh[8], bmu[8], binv[8], bgm[8], bbt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsc[j] = bsh[j] = bmu[j] = binv[j] = bgm[j] = bbt[j] = 0.0f;
+  if (BNIN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = co * 8 + j;
+      if (c < C) {
+        binv[j] = rsqrtf(ib.var[c] + ib.eps);
+        bmu[j] = ib.mean[c]; bgm[j] = ib.gamma[c]; bbt[j] = ib.beta[c];
+        bsc[j] = bgm[j] * binv[j];  // bn_planes_apply_h_kernel's arithmetic
+        bsh[j] = bbt[j] - bmu[j] * bsc[j];
+      }
+    }
+  }
+  struct Row { h16x8 c, l, r; };
+  auto pix = [&](int row) -> int {
+    const int i = (row + 1) * WP + xcol;
+    return i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+  };
+  auto arrive = [&](const h16x8& raw, Row& o) {
+    o.c = raw;
+    o.l = lane_shift_h<-1>(raw);
+    o.r = lane_shift_h<1>(raw);
+  };
+  auto step = [&](const Row& up, const Row& mid, const Row& dn, const h16x8& x8, int row) {
+    const bool live = out_lane && row < r_end;
+    // input gradient: nine packed products per dword, f16 (the arithmetic class of dw_octet)
+    h16x8 a = up.l * wt[0];
+    a = up.c * wt[1] + a; a = up.r * wt[2] + a;
+    a = mid.l * wt[3] + a; a = mid.c * wt[4] + a; a = mid.r * wt[5] + a;
+    a = dn.l * wt[6] + a; a = dn.c * wt[7] + a; a = dn.r * wt[8] + a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv = (float)x8[j];
+      float y;
+      if (BNIN) y = (float)(h16)fmaxf(fmaf(xv, bsc[j], bsh[j]), 0.0f);  // the f16 value the forward pass stored as y
+      else y = relu_in ? fmaxf(xv, 0.0f) : xv;
+      y = live ? y : 0.0f;
+      // acc += f32(du half) * y as ONE v_fma_mix_f32 reading the half out of the packed row register (written as asm: the compiler otherwise
+      // keeps f32 copies of all nine shifted rows alive across the three steps that use a row -- 72 more registers)
+      const int dwj = j >> 1;
+      mixacc(j & 1, acc[j][0], as_u(up.l)[dwj], y); mixacc(j & 1, acc[j][1], as_u(up.c)[dwj], y); mixacc(j & 1, acc[j][2], as_u(up.r)[dwj], y);
+      mixacc(j & 1, acc[j][3], as_u(mid.l)[dwj], y); mixacc(j & 1, acc[j][4], as_u(mid.c)[dwj], y); mixacc(j & 1, acc[j][5], as_u(mid.r)[dwj], y);
+      mixacc(j & 1, acc[j][6], as_u(dn.l)[dwj], y); mixacc(j & 1, acc[j][7], as_u(dn.c)[dwj], y); mixacc(j & 1, acc[j][8], as_u(dn.r)[dwj], y);
+      if (EPI == 2) {  // bn_planes_bwd_sums_h_kernel's terms on the f16 gradient just formed
+        const float xh = (xv - bmu[j]) * binv[j];
+        const bool gate = !epi_relu || fmaf(xh, bgm[j], bbt[j]) > 0.0f;
+        const float gg = (live && gate) ? (float)a[j] : 0.0f;
+        s1[j] += gg;
+        s2[j] = fmaf(gg, xh, s2[j]);
+      }
+      if (EPI == 3) a[j] = xv > 0.0f ? a[j] : (h16)0.0f;
+    }
+    if (live) op[(row + 1) * WP + xcol] = a;
+  };
+  if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+    Row A, Bq, Cq;
+    arrive(dp[pix(r_begin - 1)], A);
+    arrive(dp[pix(r_begin)], Bq);
+    h16x8 pg0 = dp[pix(r_begin + 1)], px0 = xp[pix(r_begin)], pg1 = dp[pix(r_begin + 2)], px1 = xp[pix(r_begin + 1)], pg2 = dp[pix(r_begin + 3)], px2 = xp[pix(r_begin + 2)];
+    for (int i = 0; i < rps; i += 3) {
+      const int r = r_begin + i;
+      { const h16x8 gr = pg0, xr = px0; pg0 = dp[pix(r + 4)]; px0 = xp[pix(r + 3)]; arrive(gr, Cq); step(A, Bq, Cq, xr, r); }
+      { const h16x8 gr = pg1, xr = px1; pg1 = dp[pix(r + 5)]; px1 = xp[pix(r + 4)]; arrive(gr, A); step(Bq, Cq, A, xr, r + 1); }
+      { const h16x8 gr = pg2, xr = px2; pg2 = dp[pix(r + 6)]; px2 = xp[pix(r + 5)]; arrive(gr, Bq); step(Cq, A, Bq, xr, r + 2); }
+    }
+  }
+  constexpr int NRED = 8 * KK + (EPI == 2 ? 16 : 0);
+  __shared__ float red[4][NRED];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float v = acc[j][t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+    }
+  if (EPI == 2) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float v = j < 8 ? s1[j & 7] : s2[j & 7];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[threadIdx.x >> 6][8 * KK + j] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * KK) {
+    const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;  // accumulator t is the REVERSED tap
+    const int c = co * 8 + j;
+    if (c < C) atomicAdd(&dW[(KK - 1 - t) * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  } else if (EPI == 2 && threadIdx.x < NRED) {
+    const int j = threadIdx.x - 8 * KK;  // 0..7 sum g, 8..15 sum g * xhat
+    const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&shards[((int64_t)((blockIdx.x + 7 * b + 3 * co) & 31) * CO + co) * 16 + j], (double)tot);
+  }
+}
+
+// the 32 accumulator copies [32][CO][16] -> scratch2C = dbeta[8 CO] | dgamma[8 CO] (doubles), in place by one workgroup
+__global__ __launch_bounds__(256) void bwd_sums_compact_h_kernel(double* __restrict__ shards, int CO) {
+  const int t = threadIdx.x;
+  double tot = 0.0;
+  if (t < 16 * CO) {
+    const int which = t >= 8 * CO, c = which ? t - 8 * CO : t;
+    for (int sh = 0; sh < 32; ++sh) tot += shards[((int64_t)sh * CO + (c >> 3)) * 16 + which * 8 + (c & 7)];
+  }
+  __syncthreads();
+  if (t < 16 * CO) shards[t] = tot;
+}
+
+template <int SW>
+int launch_dw_bwd_h(hipStream_t st, const h16* x, const h16* du, int B, int C, int H, int W, int WP, int relu_in, const h16* wrev, h16* dr, float* dW, int epi,
+                    const InBnH& ib, int epi_relu, double* shards, int nstrip) {
+  constexpr int NSUB = 64 / SW;
+  const int CO = (C + 7) / 8;
+  const int64_t per_seg = (int64_t)B * CO * nstrip;
+  int nseg = (int)((16384ll * NSUB + per_seg - 1) / per_seg);
+  if (nseg < 1) nseg = 1;
+  if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;
+  int rps = (H + nseg - 1) / nseg;
+  rps = (rps + 2) / 3 * 3;
+  nseg = (H + rps - 1) / rps;
+  const int waves = (nstrip * nseg + NSUB - 1) / NSUB;
+  dim3 grid((waves + 3) / 4, CO, B);
+  if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu);
+  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  else hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- entry conv weight gradient with bn0 (+ReLU) backward on the fly
 // dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) is formed per pixel from (dy, v, sums) and consumed at once (never written).
 // Block (bx, co): octet co of the 16 entry channels (8 x k x k accumulators per lane for k = 3; two blocks per octet for k = 5, 7).
@@ -920,6 +1106,35 @@ int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, 
     case 7: hipLaunchKernelGGL((dw_wgrad_h_kernel<7, 4>), grid, dim3(256), 0, st, (const h16*)x, (const h16*)du, C, H, W, WP, RP, relu_in, dW, tasks, tpw); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
+  return (int)hipGetLastError();
+}
+
+int orcai_h_dw_bwd_fused(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
+                         const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream) {
+  if (!x || !du || !dw_rev || !dr || !dW || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (epi != 0 && epi != 2 && epi != 3)) return ORCAI_E_BADARG;
+  const bool bn = bn_mean != nullptr;
+  if (bn && (!bn_var || !bn_gamma || !bn_beta)) return ORCAI_E_BADARG;
+  if (epi == 2 && (!bn || !shards)) return ORCAI_E_BADARG;
+  if (epi == 3 && (bn || !relu_in)) return ORCAI_E_BADARG;
+  const int WP = orcai_padded_width(W, 3), CO = (C + 7) / 8;
+  if (B > 65535 || C > 64 || (int64_t)(H + 2) * WP >= (1ll << 27) || ((uintptr_t)x & 15) || ((uintptr_t)du & 15) || ((uintptr_t)dr & 15)) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  InBnH ib;
+  if (bn) { ib.mean = bn_mean; ib.var = bn_var; ib.gamma = bn_gamma; ib.beta = bn_beta; ib.eps = bn_eps; }
+  if (epi == 2) {
+    hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 16 * CO * 32, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int best = 64, best_lanes = ((W + 61) / 62) * 64;
+  if (((W + 29) / 30) * 32 < best_lanes) { best = 32; best_lanes = ((W + 29) / 30) * 32; }
+  if (((W + 13) / 14) * 16 < best_lanes) { best = 16; best_lanes = ((W + 13) / 14) * 16; }
+  const h16 *xh = (const h16*)x, *dh = (const h16*)du, *wh = (const h16*)dw_rev;
+  int rc;
+  if (best == 64) rc = launch_dw_bwd_h<64>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 61) / 62);
+  else if (best == 32) rc = launch_dw_bwd_h<32>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 29) / 30);
+  else rc = launch_dw_bwd_h<16>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 13) / 14);
+  if (rc != 0) return rc;
+  if (epi == 2) hipLaunchKernelGGL(bwd_sums_compact_h_kernel, dim3(1), dim3(256), 0, st, shards, CO);
   return (int)hipGetLastError();
 }
 

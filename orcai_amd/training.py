@@ -707,6 +707,11 @@ class TrunkTrainer:
         mode, bn, bn_relu = 0, x_bn, 0
         if epi is not None and self.dgrad_epilogues:
             if epi[0] == "bsums":
+                if self.half and x_bn is None and relu_in == 0 and epi[3] == 1:
+                    # f16 path: the forward materialised x = y_a = f16(relu(BN(v_a))); the kernel forms exactly that value from v_a on load,
+                    # so the pass reads the pre-normalisation tensor (which the sums need anyway) instead of y_a
+                    x, x_bn = epi[1], epi[2]
+                    bn = x_bn
                 if x_bn is None or epi[2] != x_bn or epi[1].data_ptr() != x.data_ptr():
                     return None
                 mode, bn_relu = 2, epi[3]
@@ -720,7 +725,7 @@ class TrunkTrainer:
         if bn is not None:
             mean, var = self.stats[bn]
             bnp = [mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(), P.W(bn + "/beta").data_ptr()]
-        rc = self.lib.orcai_dw_bwd_fused(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, relu_in, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
+        rc = self._fn("dw_bwd_fused")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, relu_in, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
                                          P.G(name + "/depthwise").data_ptr(), mode, *bnp, BN_EPS, bn_relu, self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
             return None
@@ -738,7 +743,7 @@ class TrunkTrainer:
             wt = self._w_pwT(name + "/pointwise", Cin, Cout)
             self._sep(dv, Cout, H, W, 1, 0, self._w_ones_dw(Cout), wt, self._zeros(64), Cin, du)
         epi_ran = False
-        if self.fused_dw_bwd and k == 3 and not self.half:
+        if self.fused_dw_bwd and k == 3:
             # one marching pass over (du, x): input gradient, its epilogue extra and the depthwise weight gradient (csrc/train_trunk.hip: dw_bwd_march_kernel)
             fused = self._dw_bwd_fused(name, x, relu_in, Cin, H, W, du, dr, epi, x_bn)
             if fused is not None:

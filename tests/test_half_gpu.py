@@ -543,3 +543,71 @@ def test_overflowing_step_is_voided_on_the_device():
     assert int(tr.skipped.item()) == 2 and int(tr.counter.item()) == 2 and int(tr.ok_dev.item()) == 1
     assert not torch.equal(tr.P.w, before["w"]) and bool(torch.isfinite(tr.P.w).all())
     assert tr.state_dict()["step"] == 2  # the host mirror follows the device counter
+
+
+@pytest.mark.parametrize("C,H,W,B,mode", [(30, 37, 171, 2, 2), (16, 40, 171, 2, 0), (30, 23, 86, 3, 3), (40, 25, 86, 2, 2), (50, 31, 43, 2, 2), (40, 12, 43, 3, 3),
+                                          (60, 9, 22, 4, 2), (50, 7, 22, 2, 3), (10, 16, 12, 5, 1), (30, 100, 171, 1, 2), (64, 5, 62, 1, 3), (7, 3, 1, 2, 0)])
+def test_depthwise_backward_h_in_one_marching_pass(C, H, W, B, mode):
+    """orcai_h_dw_bwd_fused (the f16 twin of orcai_dw_bwd_fused) against float64 on f16-representable inputs: the input gradient (nine packed-f16
+    products per value: a few f16 roundings), its ReLU mask (mode 3), the depthwise weight gradient (f32 accumulation of exact f16 products; with
+    BatchNorm on load -- modes 1, 2 -- of the f16 value orcai_h_bn_planes_apply would have stored) and the BatchNorm backward sums of the output
+    (mode 2, taken on the f16 gradient the kernel stored); pads of the output stay zero."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C * 5 + W + mode)
+    k = 3
+    x, du = _rand_planes(rng, B, C, H, W, k, 2.0), _rand_planes(rng, B, C, H, W, k)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    mean, var = 0.3 * f(C), (0.5 + rng.random(C)).astype(np.float32)
+    gamma, beta = 1 + 0.3 * f(C), 0.4 * f(C) + 0.3
+    CO = (C + 7) // 8
+    taps = f(9, C).astype(np.float16)  # Keras depthwise kernel (3, 3, C, 1) flattened, f16-representable
+    rev = np.zeros((CO * 8, 9), dtype=np.float16)
+    rev[:C] = taps[::-1].T
+    rev = np.ascontiguousarray(rev.reshape(CO, 8, 9).transpose(0, 2, 1))  # [CO][9][8]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    xd, dud, revd = dev(to_octet_planes(x, k)), dev(to_octet_planes(du, k)), dev(rev)
+    md, vd, gd, bd = dev(mean), dev(var), dev(gamma), dev(beta)
+    bn = mode in (1, 2)
+    relu_in = 0 if bn else 1
+    out = torch.zeros_like(dud)
+    dW = torch.full((9, C), 0.25, device="cuda")
+    shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device="cuda")
+    epi = {0: 0, 1: 0, 2: 2, 3: 3}[mode]
+    bnp = [N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd)] if bn else [None] * 4
+    N.check(lib.orcai_h_dw_bwd_fused(N.ptr(xd), N.ptr(dud), B, C, H, W, relu_in, N.ptr(revd), N.ptr(out), N.ptr(dW), epi, *bnp, 1e-3, 1, N.ptr(shards), N.stream_ptr()), "h_dw_bwd_fused")
+    torch.cuda.synchronize()
+    got_dr, pads = from_octet_planes(out.cpu().numpy(), C, H, W, k)
+    assert float(np.abs(pads.astype(np.float32)).max()) == 0.0
+    # input gradient: dr[r][c] = sum_tap w[tap] du[r - (ky - 1)][c - (kx - 1)]
+    dup = np.zeros((B, C, H + 2, W + 2))
+    dup[:, :, 1:-1, 1:-1] = du.astype(np.float64)
+    want_dr = np.zeros((B, C, H, W))
+    for ky in range(3):
+        for kx in range(3):
+            want_dr += taps[ky * 3 + kx].astype(np.float64)[None, :, None, None] * dup[:, :, 2 - ky : 2 - ky + H, 2 - kx : 2 - kx + W]
+    if mode == 3:
+        want_dr = np.where(x.astype(np.float64) > 0, want_dr, 0.0)
+    assert np.abs(got_dr.astype(np.float64) - want_dr).max() <= 2e-2 * max(1.0, np.abs(want_dr).max()), np.abs(got_dr.astype(np.float64) - want_dr).max()
+    # weight gradient
+    if bn:
+        sc = (gamma * (1.0 / np.sqrt(var + np.float32(1e-3))).astype(np.float32)).astype(np.float32)
+        xr = np.maximum(x.astype(np.float32) * sc[None, :, None, None] + (beta - mean * sc)[None, :, None, None], 0).astype(np.float16).astype(np.float64)
+    else:
+        xr = np.maximum(x, 0).astype(np.float64)
+    xp = np.zeros((B, C, H + 2, W + 2))
+    xp[:, :, 1:-1, 1:-1] = xr
+    want = np.stack([[np.einsum("bchw,bchw->c", xp[:, :, dy : dy + H, dx : dx + W], du.astype(np.float64)) for dx in range(3)] for dy in range(3)]).reshape(9, C)
+    n = B * H * W
+    tol = max(2e-5 * np.sqrt(n) * max(1.0, np.abs(want).max() / np.sqrt(n)), 2e-4 * np.abs(want).max())
+    got = dW.cpu().numpy() - 0.25
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+    if mode == 2:
+        inv = 1.0 / np.sqrt(var.astype(np.float64) + 1e-3)
+        xh = (x.astype(np.float64) - mean[None, :, None, None]) * inv[None, :, None, None]
+        g = np.where(xh * gamma[None, :, None, None] + beta[None, :, None, None] > 0, got_dr.astype(np.float64), 0.0)
+        db_ref, dg_ref = g.sum(axis=(0, 2, 3)), (g * xh).sum(axis=(0, 2, 3))
+        s = shards.cpu().numpy()
+        tol_s = 3e-6 * np.sqrt(n) * max(1.0, np.abs(got_dr).max() * 3) + 1e-3 * np.sqrt(n) * 2e-3  # + a few gate decisions within f32 rounding of zero
+        assert np.abs(s[:C] - db_ref).max() <= tol_s and np.abs(s[8 * CO : 8 * CO + C] - dg_ref).max() <= tol_s, (np.abs(s[:C] - db_ref).max(), np.abs(s[8 * CO : 8 * CO + C] - dg_ref).max(), tol_s)
