@@ -53,11 +53,32 @@ def _sepconv(x, p, name):
     return _conv_same(x, p[name + "/pointwise"], p[name + "/bias"], 1)
 
 
-def _maxpool_same(x, k=(3, 2), s=2):
+def _maxpool_same(x, k=(3, 2), s=2, forced=None, key=None):
     _, pt, pb = same_pad(x.shape[2], k[0], s)
     _, pl, pr = same_pad(x.shape[3], k[1], s)
     x = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
-    return F.max_pool2d(x, kernel_size=k, stride=s)
+    if forced is None or (key not in forced and "record" not in forced):
+        return F.max_pool2d(x, kernel_size=k, stride=s)
+    win = x.unfold(2, k[0], s).unfold(3, k[1], s)  # [B, C, Ho, Wo, kh, kw]
+    B, C, Ho, Wo = win.shape[:4]
+    win = win.reshape(B, C, Ho, Wo, k[0] * k[1])
+    if "record" in forced:  # the branch THIS forward takes: first maximal element in window scan order (what max_pool2d's backward routes to)
+        forced["record"][key] = torch.argmax(win.detach(), dim=4)
+        return F.max_pool2d(x, kernel_size=k, stride=s)
+    # forced branch: element forced[key][b, c, i, j] (0 .. kh*kw-1, window scan order) of every window is taken as its maximum
+    return torch.gather(win, 4, forced[key].unsqueeze(-1)).squeeze(-1)
+
+
+def _relu(x, forced=None, key=None):
+    """ReLU, or -- forced[key] given -- the branch another implementation took: x * mask (0/1 tensor of x's shape).  Used to compare a reduced-
+    precision path's gradient with the float64 gradient of the SAME piecewise-linear branch (tests/test_half_gpu.py): a pre-activation within
+    f16 rounding of zero gets one mask in f64 and the other in f16, and every such flip moves that element's gradient by O(1)."""
+    if forced is not None and "record" in forced:
+        forced["record"][key] = (x.detach() > 0).to(x.dtype)
+        return torch.relu(x)
+    if forced is None or key not in forced:
+        return torch.relu(x)
+    return x * forced[key]
 
 
 def _lstm_dir(x, W, U, b, reverse):
@@ -82,22 +103,24 @@ def _bilstm(x, p, name):
     return torch.cat([fwd, bwd], dim=2)
 
 
-def forward_train(p: dict, x_nhwc: torch.Tensor, masks: dict | None, rate: float, n_blocks: int):
+def forward_train(p: dict, x_nhwc: torch.Tensor, masks: dict | None, rate: float, n_blocks: int, forced: dict | None = None):
     """Training-mode forward.  p: dict of torch tensors (Keras layouts).  masks: {'drop1','drop2','drop3'} of 0/1
-    tensors shaped like the tensors they multiply, or None for no dropout.  Returns (probabilities, new BN stats)."""
+    tensors shaped like the tensors they multiply, or None for no dropout.  Returns (probabilities, new BN stats).
+    forced: optional branches taken by another implementation -- 'relu/bn0', 'relu/b{i}/in', 'relu/b{i}/bn_a', 'relu/bn_f' (NCHW 0/1 masks),
+    'relu/dense1' ([B][T][128]) and 'pool/b{i}' (int64 window element per pooled value); see _relu / _maxpool_same."""
     new_stats = {}
     keep = 1.0 - rate
     x = x_nhwc.permute(0, 3, 1, 2)
-    x = torch.relu(_bn_train(_conv_same(x, p["conv0/kernel"], p["conv0/bias"], 1), p, "bn0", new_stats))
+    x = _relu(_bn_train(_conv_same(x, p["conv0/kernel"], p["conv0/bias"], 1), p, "bn0", new_stats), forced, "relu/bn0")
     prev = x
     for b in range(1, n_blocks + 1):
-        x = torch.relu(x)
-        x = torch.relu(_bn_train(_sepconv(x, p, f"b{b}/sep_a"), p, f"b{b}/bn_a", new_stats))
+        x = _relu(x, forced, f"relu/b{b}/in")
+        x = _relu(_bn_train(_sepconv(x, p, f"b{b}/sep_a"), p, f"b{b}/bn_a", new_stats), forced, f"relu/b{b}/bn_a")
         x = _bn_train(_sepconv(x, p, f"b{b}/sep_b"), p, f"b{b}/bn_b", new_stats)
-        x = _maxpool_same(x)
+        x = _maxpool_same(x, forced=forced, key=f"pool/b{b}")
         x = x + _conv_same(prev, p[f"b{b}/res/kernel"], p[f"b{b}/res/bias"], 2)
         prev = x
-    x = torch.relu(_bn_train(_sepconv(x, p, "sep_f"), p, "bn_f", new_stats))
+    x = _relu(_bn_train(_sepconv(x, p, "sep_f"), p, "bn_f", new_stats), forced, "relu/bn_f")
     B, C, H, W = x.shape
     x = x.permute(0, 2, 3, 1).reshape(B, H, W * C)
     x = _bilstm(x, p, "lstm1")
@@ -106,7 +129,7 @@ def forward_train(p: dict, x_nhwc: torch.Tensor, masks: dict | None, rate: float
     x = _bilstm(x, p, "lstm2")
     if masks is not None:
         x = x * masks["drop2"] / keep
-    x = torch.relu(x @ p["dense1/kernel"] + p["dense1/bias"])
+    x = _relu(x @ p["dense1/kernel"] + p["dense1/bias"], forced, "relu/dense1")
     x = _bn_train(x, p, "bn_d", new_stats, axis=2)
     if masks is not None:
         x = x * masks["drop3"] / keep
@@ -166,12 +189,14 @@ def l2_penalty(p: dict) -> torch.Tensor:
     return sum(L2 * torch.sum(p[k] ** 2) for k in L2_KERNELS)
 
 
-def loss_and_grads(params_np: dict, x: np.ndarray, y: np.ndarray, masks_np: dict | None, rate: float, dtype=torch.float64):
-    """One forward + backward.  Returns dict(loss, bce, grads {name: ndarray}, probs, new_stats)."""
+def loss_and_grads(params_np: dict, x: np.ndarray, y: np.ndarray, masks_np: dict | None, rate: float, dtype=torch.float64, forced_np: dict | None = None):
+    """One forward + backward.  Returns dict(loss, bce, grads {name: ndarray}, probs, new_stats).  forced_np: see forward_train."""
     p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=is_trainable(k)) for k, v in params_np.items()}
     n_blocks = sum(1 for k in p if k.endswith("/res/kernel"))
     masks = None if masks_np is None else {k: torch.tensor(v, dtype=dtype) for k, v in masks_np.items()}
-    probs, new_stats = forward_train(p, torch.tensor(x, dtype=dtype), masks, rate, n_blocks)
+    forced = None if forced_np is None else {k: (v if k == "record" else torch.tensor(np.asarray(v), dtype=torch.int64) if k.startswith("pool/") else torch.tensor(np.asarray(v), dtype=dtype))
+                                             for k, v in forced_np.items()}  # {"record": {}} collects the branches this forward takes (torch tensors)
+    probs, new_stats = forward_train(p, torch.tensor(x, dtype=dtype), masks, rate, n_blocks, forced)
     bce = masked_bce(torch.tensor(y, dtype=dtype), probs)
     loss = bce + l2_penalty(p)
     loss.backward()

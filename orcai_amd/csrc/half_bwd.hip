@@ -331,10 +331,6 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.v[k] = fmaxf(a.v[k], b.v[k]);
     return o; };
-  auto sel = [](const O8& v, const O8& m, const O8& d) { O8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o.v[k] = v.v[k] == m.v[k] ? d.v[k] : 0.f;
-    return o; };
   auto add8 = [](const O8& a, const O8& b) { O8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o.v[k] = a.v[k] + b.v[k];
@@ -388,18 +384,33 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
     unpack8(dn, d.v);
     if (i + 1 < i1) request(i + 1);
     const O8 m = mx8(mx8(mx8(t0, t1), mx8(m0, m1)), mx8(b0, b1));
-    if (i >= i0) {
-      if (r0 >= 0) {
-        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add8(c0, sel(t0, m, d)), t0);
-        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add8(c1, sel(t1, m, d)), t1);
-      }
-      if (r0 + 1 < H) {
-        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, sel(m0, m, d), m0);
-        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, sel(m1, m, d), m1);
+    // first maximal position in scan order takes the window's gradient (pool_bwd_kernel of train_trunk.hip): f16 values tie often
+    O8 g6[6];
+    {
+      const O8* v[6] = {&t0, &t1, &m0, &m1, &b0, &b1};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bool taken = false;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const bool hit = v[p]->v[k] == m.v[k];
+          g6[p].v[k] = (hit && !taken) ? d.v[k] : 0.f;
+          taken = taken || hit;
+        }
       }
     }
-    c0 = sel(b0, m, d);
-    c1 = sel(b1, m, d);
+    if (i >= i0) {
+      if (r0 >= 0) {
+        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add8(c0, g6[0]), t0);
+        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add8(c1, g6[1]), t1);
+      }
+      if (r0 + 1 < H) {
+        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, g6[2], m0);
+        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, g6[3], m1);
+      }
+    }
+    c0 = g6[4];
+    c1 = g6[5];
     t0 = b0;
     t1 = b1;
   }

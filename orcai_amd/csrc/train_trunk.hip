@@ -536,7 +536,24 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     return make_float4(t.x * sgn.x, t.y * sgn.y, t.z * sgn.z, t.w * sgn.w);
   };
   auto mx4 = [](float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); };
-  auto sel = [](float4 v, float4 m, float4 d) { return make_float4(v.x == m.x ? d.x : 0.f, v.y == m.y ? d.y : 0.f, v.z == m.z ? d.z : 0.f, v.w == m.w ? d.w : 0.f); };
+  auto route_first = [](float4 v0, float4 v1, float4 v2, float4 v3, float4 v4, float4 v5, float4 m, float4 d, float4 (&g)[6]) {
+    const float4 v[6] = {v0, v1, v2, v3, v4, v5};
+    const float mm[4] = {m.x, m.y, m.z, m.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    float o[6][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bool taken = false;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const float vv = k == 0 ? v[p].x : (k == 1 ? v[p].y : (k == 2 ? v[p].z : v[p].w));
+        const bool hit = vv == mm[k];
+        o[p][k] = (hit && !taken) ? dd[k] : 0.f;
+        taken = taken || hit;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) g[p] = make_float4(o[p][0], o[p][1], o[p][2], o[p][3]);
+  };
   auto add4 = [](float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
   auto emit = [&](int64_t pos, float4 g, float4 tv) {  // store one gradient pixel-quad; tv = sign(gamma) * v at that position
     gp[pos] = g;
@@ -579,19 +596,24 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const float4 d = dn;
     if (i + 1 < i1) request(i + 1);
     const float4 m = mx4(mx4(mx4(t0, t1), mx4(m0, m1)), mx4(b0, b1));
+    // the gradient of a window goes to its FIRST maximal position in scan order (rows, then columns) -- what TensorFlow's MaxPoolGrad (argmax)
+    // and torch's max_pool2d backward do; with ties (frequent once activations are stored in f16) "every maximal position" would count the
+    // window's gradient more than once
+    float4 g6[6];
+    route_first(t0, t1, m0, m1, b0, b1, m, d, g6);
     if (i >= i0) {
       ds[0] += d.x; ds[1] += d.y; ds[2] += d.z; ds[3] += d.w;
       if (r0 >= 0) {
-        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add4(c0, sel(t0, m, d)), t0);
-        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add4(c1, sel(t1, m, d)), t1);
+        if (cx0) emit((int64_t)(r0 + R) * WP + x0, add4(c0, g6[0]), t0);
+        if (cx1) emit((int64_t)(r0 + R) * WP + x1, add4(c1, g6[1]), t1);
       }
       if (r0 + 1 < H) {  // r0 + 1 >= 0 always
-        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, sel(m0, m, d), m0);
-        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, sel(m1, m, d), m1);
+        if (cx0) emit((int64_t)(r0 + 1 + R) * WP + x0, g6[2], m0);
+        if (cx1) emit((int64_t)(r0 + 1 + R) * WP + x1, g6[3], m1);
       }
     }
-    c0 = sel(b0, m, d);
-    c1 = sel(b1, m, d);
+    c0 = g6[4];
+    c1 = g6[5];
     t0 = b0;
     t1 = b1;
   }

@@ -303,6 +303,7 @@ def _train_setup(cfg, B, seed, rate, precision):
     tr = Trainer(model, learning_rate=1e-3)
     xd = torch.from_numpy(np.ascontiguousarray(x[..., 0])).cuda().view(-1)
     out = tr.forward_backward(xd, H * W, B, torch.from_numpy(y).cuda(), masks={k: torch.from_numpy(v).cuda() for k, v in masks.items()})
+    tr._test_inputs = (p, x, y, masks)
     return ref, tr, out
 
 
@@ -317,33 +318,75 @@ def _train_setup(cfg, B, seed, rate, precision):
 )
 def test_half_training_step_gradients_vs_autograd(cfg, B):
     """Forward in training mode + masked BCE + L2 + full backward on the f16 path against torch autograd (float64) on the CPU oracle.
-    What f16 storage does to this comparison: every activation is rounded to 2^-11 relative, so the ~1 % of pre-activations that lie
-    within that rounding of zero get the OTHER ReLU mask than in the f32 oracle; each flipped element changes its gradient by O(1).
-    The f16 path's gradient is the gradient of ITS forward function (masks are recomputed from the same stored f16 tensors), and
-    the backward kernels are pinned one by one against their f32 twins on identical inputs (the *_twin tests below); here the whole
-    step is held to: probabilities 5e-3, loss 5e-3 relative, and per gradient tensor cosine similarity >= 0.97 with relative L2
-    error <= 0.25 against the f64 oracle (on these few-thousand-pixel test shapes; the sums average flips out as planes grow)."""
+    Every activation is rounded to 2^-11 relative in f16, so the ~1 % of pre-activations within that rounding of zero get the OTHER ReLU mask
+    than in a float64 forward (and pooling windows another maximal element), and each such flip moves its gradient element by O(1): against
+    the free-running float64 oracle a gradient tensor agrees to a cosine of 0.9 and nothing tighter can be asked.  The f16 path's gradient is
+    the gradient of ITS forward function, so the comparison that pins it is with the float64 gradient of the SAME piecewise-linear branch:
+    the ReLU masks and pooling selections are read back from the tensors the f16 forward stored (y0, y_a, the block outputs, v_b, the head's
+    rectified tensors) and forced on the oracle (oracle.train_ref `forced`, self-checked on the CPU in tests/test_oracle_golden.py).  Held to:
+    probabilities 5e-3, loss 5e-3 relative, every gradient tensor to relative L2 <= 2e-2 of the branch-matched float64 gradient."""
     ref, tr, out = _train_setup(cfg, B, seed=5, rate=0.5, precision="f16")
     assert tr.half and tr.trunk.buf["v0"].dtype == torch.float16
     acc = out["acc"].cpu().numpy()
     assert np.abs(out["probs"].cpu().numpy() - ref["probs"]).max() <= 5e-3
     assert abs(acc[0] / acc[1] + acc[3] - ref["loss"]) <= 5e-3 * max(1.0, abs(ref["loss"]))
-    rel, cos, bad = {}, {}, {}
+    matched = _branch_matched_reference(cfg, B, tr, seed=5, rate=0.5)
+    rel, relm, cos, bad = {}, {}, {}, {}
     for name, g in ref["grads"].items():
         got = tr.P.G(name).cpu().numpy().astype(np.float64) / tr.grad_scale
         assert np.isfinite(got).all(), name
         if name.endswith("/bias") and not name.startswith(("dense2", "lstm", "dense1")) and "res" not in name:
             assert np.abs(got).max() <= 1e-3  # a bias in front of a BatchNorm has zero gradient
             continue
-        gn = float(np.linalg.norm(g))
+        gm = matched["grads"][name]
+        gn, gmn = float(np.linalg.norm(g)), float(np.linalg.norm(gm))
         rel[name] = float(np.linalg.norm(got - g)) / max(gn, 1e-12)
+        relm[name] = float(np.linalg.norm(got - gm)) / max(gmn, 1e-12)
         cos[name] = float((got * g).sum() / max(np.linalg.norm(got) * gn, 1e-30))
-        if rel[name] > 0.25 or cos[name] < 0.97:
-            bad[name] = (rel[name], cos[name])
-    top = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
-    print(f"f16 training step {cfg['filters']} k={cfg['kernel_size']}: relative L2 gradient error median {np.median(list(rel.values())):.1e}, "
-          f"worst {[(k, f'{v:.1e}') for k, v in top]}, min cosine {min(cos.values()):.4f}")
+        if relm[name] > 2e-2 or cos[name] < 0.9:
+            bad[name] = (relm[name], cos[name])
+    top = sorted(relm.items(), key=lambda kv: -kv[1])[:3]
+    print(f"f16 training step {cfg['filters']} k={cfg['kernel_size']}: relative L2 gradient error vs the branch-matched oracle median {np.median(list(relm.values())):.1e}, "
+          f"worst {[(k, f'{v:.1e}') for k, v in top]}; vs the free-running oracle median {np.median(list(rel.values())):.1e}, worst {max(rel.values()):.1e}, min cosine {min(cos.values()):.4f}")
     assert not bad, bad
+
+
+def _branch_matched_reference(cfg, B, tr, seed, rate):
+    """The float64 oracle's loss and gradients on the branches the f16 forward took (see the test above)."""
+    from oracle import train_ref as T
+    from oracle.model_ref import same_pad
+
+    k = cfg["kernel_size"]
+    H, W, _ = cfg["input_shape"]
+    buf, shapes = tr.trunk.buf, tr.model.stage_shapes()
+
+    def planes(name, C, h, w):
+        return from_octet_planes(buf[name].float().cpu().numpy(), C, h, w, k)[0].astype(np.float64)
+
+    forced = {}
+    y0 = planes("y0", 16, H, W)
+    forced["relu/bn0"] = forced["relu/b1/in"] = (y0 > 0).astype(np.float64)  # the second ReLU is the identity on the rectified tensor
+    cprev = 16
+    for i, c in enumerate(cfg["filters"], start=1):
+        h, w, _ = shapes[i - 1]
+        if i > 1:
+            forced[f"relu/b{i}/in"] = (planes(f"prev{i - 1}", cprev, h, w) > 0).astype(np.float64)
+        forced[f"relu/b{i}/bn_a"] = (planes(f"ya{i}", c, h, w) > 0).astype(np.float64)
+        sgn = np.where(tr.P.W(f"b{i}/bn_b/gamma").cpu().numpy() < 0, -1.0, 1.0)
+        sv = planes(f"vb{i}", c, h, w) * sgn[None, :, None, None]  # the pooling kernels take the arg-max of sign(gamma) * v (BatchNorm is monotone)
+        _, pt, pb = same_pad(h, 3, 2)
+        _, pl, pr = same_pad(w, 2, 2)
+        svp = np.pad(sv, ((0, 0), (0, 0), (pt, pb), (pl, pr)), constant_values=-np.inf)
+        ho, wo = shapes[i][0], shapes[i][1]
+        win = np.stack([svp[:, :, dy : dy + 2 * ho : 2, dx : dx + 2 * wo : 2] for dy in range(3) for dx in range(2)], axis=-1)
+        forced[f"pool/b{i}"] = np.argmax(win, axis=-1)  # first maximal element in window scan order
+        cprev = c
+    hc = tr.head.cache
+    hl, wl, _ = shapes[-1]
+    forced["relu/bn_f"] = (hc["x1"].cpu().numpy().reshape(B, hl, wl, -1).transpose(0, 3, 1, 2) > 0).astype(np.float64)
+    forced["relu/dense1"] = (hc["pre1"].cpu().numpy() > 0).astype(np.float64)
+    p, x, y, masks = tr._test_inputs
+    return T.loss_and_grads(p, x, y, masks, rate, forced_np=forced)
 
 
 def test_half_training_tracks_f32_training():
@@ -512,6 +555,45 @@ def test_pool_bwd_h_vs_f32_twin(C, H, W):
     for i, name in enumerate(("dy", "sum dy", "sum dy*xhat")):
         a, b = out[True][i], out[False][i]
         assert np.abs(a - b).max() <= 3e-3 * max(1.0, np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("C,H,W", [(12, 12, 21), (30, 9, 14), (8, 16, 6)])
+def test_pool_bwd_ties_go_to_the_first_maximum(C, H, W):
+    """Max-pool backward on inputs FULL of ties (small integers): the window's gradient goes to its first maximal position in scan order, as
+    torch's max_pool2d backward and TensorFlow's MaxPoolGrad route it -- both kernels (f32 quads, f16 octets) against torch autograd on the CPU.
+    gamma of both signs: the arg-max is taken on sign(gamma) * v."""
+    import torch.nn.functional as F
+
+    from oracle.model_ref import same_pad
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(C + W)
+    B, k = 2, 3
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    v = rng.integers(-2, 3, size=(B, C, H, W)).astype(np.float16)
+    dout = rng.integers(-4, 5, size=(B, C, Ho, Wo)).astype(np.float16)
+    gamma = rng.standard_normal(C).astype(np.float32)
+    mean, var = np.zeros(C, dtype=np.float32), np.ones(C, dtype=np.float32)
+    sgn = np.where(gamma < 0, -1.0, 1.0)
+    x = torch.tensor(v.astype(np.float64) * sgn[None, :, None, None], requires_grad=True)
+    _, pt, pb = same_pad(H, 3, 2)
+    _, pl, pr = same_pad(W, 2, 2)
+    y = F.max_pool2d(F.pad(x, (pl, pr, pt, pb), value=float("-inf")), kernel_size=(3, 2), stride=2)
+    y.backward(torch.tensor(dout.astype(np.float64)))
+    want = x.grad.numpy()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    md, vd, gd = dev(mean), dev(var), dev(gamma)
+    for half in (False, True):
+        planes = (lambda a: dev(to_octet_planes(a, k))) if half else (lambda a: dev(_quad_planes(a.astype(np.float32), k)))
+        fn = lib.orcai_h_pool_bwd_bn if half else lib.orcai_pool_bwd_bn
+        dd, vv = planes(dout), planes(v)
+        dy = torch.zeros_like(vv)
+        sums = torch.zeros(128, dtype=torch.float64, device="cuda")
+        N.check(fn(N.ptr(dd), N.ptr(vv), B, C, H, W, k, N.ptr(dy), N.ptr(gd), N.ptr(md), N.ptr(vd), 1e-3, N.ptr(sums), N.stream_ptr()), "pool_bwd_bn")
+        got = from_octet_planes(dy.float().cpu().numpy(), C, H, W, k)[0] if half else _from_quad(dy.cpu().numpy(), C, H, W, k)
+        assert np.array_equal(got.astype(np.float64), want), (half, np.abs(got - want).max())
+        assert abs(float(sums.cpu().numpy()[:C].sum()) - float(dout.astype(np.float64).sum())) < 1e-6  # every window's gradient lands exactly once
 
 
 def test_overflowing_step_is_voided_on_the_device():

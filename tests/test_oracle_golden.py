@@ -263,3 +263,30 @@ def test_reference_snippet_tables_are_valid_product_inputs(golden_dir):
     assert len(lengths["train.csv.gz"]) == param["model"]["batch_size"] * param["model"]["n_batch_train"]
     assert hasattr(G, "snippet_fixture_inputs")  # the generator of the recordings these tables index (used by the GPU test)
 
+
+
+def test_training_oracle_forced_branches_reproduce_its_own_gradient():
+    """oracle.train_ref with `forced` branches (ReLU masks, max-pool window elements): forcing the branches an unforced forward records gives
+    that forward's loss and gradients again (the mechanism tests/test_half_gpu.py uses to compare the f16 path with the float64 gradient of
+    the SAME piecewise-linear branch), and forcing OTHER branches changes them."""
+    from oracle import model_ref as M
+    from oracle import train_ref as T
+
+    cfg = dict(input_shape=(32, 12, 1), filters=(10, 20), kernel_size=3, lstm_units=8, num_labels=3)
+    p = M.calibrated_params(seed=3, **cfg)
+    rng = np.random.default_rng(3)
+    B, steps = 2, 32 // 4
+    x = rng.random((B, 32, 12, 1), dtype=np.float32)
+    y = (rng.random((B, steps, 3)) > 0.5).astype(np.float32)
+    masks = {k: (rng.random((B, steps, d)) > 0.5).astype(np.float32) for k, d in (("drop1", 16), ("drop2", 16), ("drop3", 128))}
+    rec = {}
+    base = T.loss_and_grads(p, x, y, masks, 0.5, forced_np={"record": rec})
+    assert {"relu/bn0", "relu/b1/in", "relu/b2/bn_a", "relu/bn_f", "relu/dense1", "pool/b1", "pool/b2"} <= set(rec)
+    forced = {k: v.numpy() for k, v in rec.items()}
+    again = T.loss_and_grads(p, x, y, masks, 0.5, forced_np=forced)
+    assert abs(again["loss"] - base["loss"]) <= 1e-12
+    for k, g in base["grads"].items():
+        assert np.abs(again["grads"][k] - g).max() <= 1e-10 * max(1.0, np.abs(g).max()), k
+    forced["relu/b1/bn_a"] = 1.0 - forced["relu/b1/bn_a"]
+    other = T.loss_and_grads(p, x, y, masks, 0.5, forced_np=forced)
+    assert np.abs(other["grads"]["b1/sep_a/pointwise"] - base["grads"]["b1/sep_a/pointwise"]).max() > 1e-6
