@@ -1059,11 +1059,12 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = cq * 4 + j;
-      if (c < C) {
-        binv[j] = rsqrtf(ib.var[c] + ib.eps);
+      if (c < C) {  // wave-uniform values computed on the vector unit: back to scalar registers (24 VGPRs otherwise)
+        auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+        binv[j] = uni(rsqrtf(ib.var[c] + ib.eps));
         bmu[j] = ib.mean[c]; bgm[j] = ib.gamma[c]; bbt[j] = ib.beta[c];
-        bsc[j] = bgm[j] * binv[j];  // bn_planes_apply_kernel's folded form: the tensor the forward conv saw, bit for bit
-        bsh[j] = bbt[j] - bmu[j] * bsc[j];
+        bsc[j] = uni(bgm[j] * binv[j]);  // bn_planes_apply_kernel's folded form: the tensor the forward conv saw, bit for bit
+        bsh[j] = uni(bbt[j] - bmu[j] * bsc[j]);
       }
     }
   }

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_half_gpu.py tests/test_train_full_gpu.py tests/test_train_fused_gpu.py -q -m gpu -s 2>&1 | grep -v amdgpu.ids | cut -c1-1500 > gpurun_out/pytest_fe.log
-echo "pytest rc ${PIPESTATUS[0]}"; grep -E "f16 training step|passed|failed|Error|assert" gpurun_out/pytest_fe.log | tail -n 14
+timeout -k 10 300 python tools/launcher_calls.py 100 > gpurun_out/launcher_calls.log 2>&1; grep -E "dw_bwd|sum of" gpurun_out/launcher_calls.log
+timeout -k 10 600 python -m pytest tests/test_train_fused_gpu.py tests/test_half_gpu.py -q -m gpu -k "marching or one_marching" 2>&1 | tail -n 3
