@@ -1,3 +1,14 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python tools/launcher_calls.py 100 > gpurun_out/launcher_calls.log 2>&1; grep -E "dw_bwd|sum of" gpurun_out/launcher_calls.log
-timeout -k 10 600 python -m pytest tests/test_train_fused_gpu.py tests/test_half_gpu.py -q -m gpu -k "marching or one_marching" 2>&1 | tail -n 3
+python bench.py --no-cpu-baseline --no-secondary > gpurun_out/exp_base.json 2> gpurun_out/exp_base.err && \
+cp orcai_amd/liborcai_hip.so /tmp/keep.so && cp orcai_amd/liborcai_hip_exp.so orcai_amd/liborcai_hip.so && touch orcai_amd/liborcai_hip.so && \
+python bench.py --no-cpu-baseline --no-secondary > gpurun_out/exp_split.json 2> gpurun_out/exp_split.err ; cp /tmp/keep.so orcai_amd/liborcai_hip.so
+python - <<'PY'
+import json
+for n in ("exp_base", "exp_split"):
+    try:
+        d = json.loads(open(f"gpurun_out/{n}.json").read().strip().splitlines()[-1])
+        r = d["roofline"]
+        print(n, d["value"], d["ms_per_step"], r["kernel_ms"], r["per_layer_ms_per_step"])
+    except Exception as e:
+        print(n, "failed", e)
+PY
