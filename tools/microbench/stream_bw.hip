@@ -26,6 +26,58 @@ __global__ __launch_bounds__(256) void stream_kernel(const float4* __restrict__ 
   }
 }
 
+// The marching depthwise backward's access pattern with no arithmetic and few registers: a wave walks down a 64-lane column strip of one
+// channel-quad plane (row pitch WP pixels of 16 bytes), loads one row of two tensors per step and stores one (block 1 of orcai-V1 at batch 64:
+// planes 738 x 172, 3 strips of 62 columns, segments of 69 rows).  DEPTH rows requested ahead.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void march_copy_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ d, int H, int W, int WP, int nstrip,
+                                                          int nseg, int rps, int CQ, int sstep, int halo) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= nstrip * nseg) return;
+  const int strip = task % nstrip, seg = task / nstrip;
+  const int xcol = strip * sstep - halo + lane;
+  const int plane = (H + 2) * WP;
+  const size_t pbase = ((size_t)blockIdx.z * CQ + blockIdx.y) * plane;
+  const bool out = lane >= halo && lane < halo + sstep && xcol < W;
+  const int r0 = seg * rps, r1 = min(r0 + rps, H);
+  auto pix = [&](int row) { int i = (row + 1) * WP + xcol; return i < 0 ? 0 : (i >= plane ? plane - 1 : i); };
+  float4 pa[DEPTH], pb[DEPTH];
+#pragma unroll
+  for (int k = 0; k < DEPTH; ++k) { pa[k] = a[pbase + pix(r0 + k)]; pb[k] = b[pbase + pix(r0 + k)]; }
+  for (int r = r0; r < r1; r += DEPTH) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) {
+      const float4 x = pa[k], y = pb[k];
+      pa[k] = a[pbase + pix(r + k + DEPTH)];
+      pb[k] = b[pbase + pix(r + k + DEPTH)];
+      if (out && r + k < r1) d[pbase + (size_t)(r + k + 1) * WP + xcol] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+  }
+}
+
+template <int DEPTH>
+void run_march(float4* buf[5], int WP = 172, int sstep = 62, int halo = 1) {
+  const int B = 64, CQ = 8, H = 736, W = 171, nseg = 11, rps = 69;
+  const int nstrip = (W + sstep - 1) / sstep;
+  dim3 grid((nstrip * nseg + 3) / 4, CQ, B);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((march_copy_kernel<DEPTH>), grid, dim3(256), 0, 0, buf[0], buf[1], buf[3], H, W, WP, nstrip, nseg, rps, CQ, sstep, halo);
+  (void)hipEventRecord(e0);
+  const int reps = 10;
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((march_copy_kernel<DEPTH>), grid, dim3(256), 0, 0, buf[0], buf[1], buf[3], H, W, WP, nstrip, nseg, rps, CQ, sstep, halo);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double bytes = 3.0 * B * 30 * H * W * 4;  // algorithmic: 30 channels, two tensors read, one written
+  printf("marching copy, row pitch %d px, strips of %d columns + %d halo, %d strips, %d rows ahead: %.3f ms  %.2f TB/s of algorithmic bytes\n", WP, sstep, halo, nstrip, DEPTH, ms,
+         bytes / ms * 1e-9);
+}
+
 template <int R, int W>
 void run(const char* name, float4* buf[5], size_t n4, int blocks) {
   hipEvent_t e0, e1;
@@ -49,14 +101,20 @@ int main() {
   float4* buf[5];
   for (int i = 0; i < 5; ++i) {
     if (hipMalloc(&buf[i], n4 * 16) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    hipMemset(buf[i], 0, n4 * 16);
+    (void)hipMemset(buf[i], 0, n4 * 16);
   }
-  for (int blocks : {2048, 8192, 65536}) {
+  for (int blocks : {8192}) {
     run<1, 0>("1 read", buf, n4, blocks);
     run<1, 1>("1 read + 1 write (copy)", buf, n4, blocks);
     run<2, 1>("2 reads + 1 write", buf, n4, blocks);
     run<3, 1>("3 reads + 1 write", buf, n4, blocks);
     run<1, 2>("1 read + 2 writes", buf, n4, blocks);
   }
+  run_march<3>(buf);
+  run_march<3>(buf, 176, 62, 1);
+  run_march<3>(buf, 176, 64, 0);
+  run_march<3>(buf, 172, 64, 0);
+  run_march<3>(buf, 176, 56, 1);
+  run_march<3>(buf, 176, 56, 0);
   return 0;
 }
