@@ -388,6 +388,58 @@ __global__ __launch_bounds__(256, 3) void stft_db_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------- STFT + dB for any power-of-two transform size (the reference reads nfft
+// from the parameter file, spectrogram.py:34-39; every shipped file says 512 and runs stft_db_kernel above).  Plain and slow by comparison: one
+// workgroup per frame, the windowed frame (centred, zero padding, periodic Hann: librosa.stft's defaults) bit-reversed into LDS, log2(nfft) radix-2
+// stages with a barrier each, twiddles by sincospif; L for the first k_crop bins, max |X|^2 over ALL 1 + nfft/2 bins.  The level-1 histogram is
+// taken by hist1_kernel in a second pass over L (the 512-point kernel builds it on the fly).
+constexpr int NFFT_ANY_MAX = 4096;
+
+__global__ __launch_bounds__(256) void stft_any_kernel(const float* __restrict__ pcm, int64_t n_samples, int n_fft, int log2n, int hop, int64_t n_frames, int k_crop,
+                                                        float* __restrict__ out_db, Workspace* __restrict__ ws) {
+  __shared__ float2 buf[NFFT_ANY_MAX];
+  __shared__ float wmax[4];
+  const int tid = threadIdx.x;
+  const int half = n_fft >> 1;
+  float pmax = 0.0f;
+  for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {
+    const int64_t s0 = t * hop - half;
+    for (int n = tid; n < n_fft; n += 256) {
+      const int64_t i = s0 + n;
+      const float x = (i >= 0 && i < n_samples) ? pcm[i] : 0.0f;
+      const float w = 0.5f - 0.5f * cospif(2.0f * (float)n / (float)n_fft);
+      buf[__brev((uint32_t)n) >> (32 - log2n)] = make_float2(x * w, 0.0f);
+    }
+    __syncthreads();
+    for (int st = 1; st <= log2n; ++st) {
+      const int hm = 1 << (st - 1);
+      for (int j = tid; j < half; j += 256) {
+        const int k = j & (hm - 1);
+        const int i0 = ((j >> (st - 1)) << st) + k, i1 = i0 + hm;
+        float sn, cs;
+        sincospif(-(float)k / (float)hm, &sn, &cs);  // exp(-2 pi i k / (2 hm))
+        const float2 a = buf[i0], b = buf[i1];
+        const float2 tb = make_float2(fmaf(b.x, cs, -b.y * sn), fmaf(b.x, sn, b.y * cs));
+        buf[i0] = make_float2(a.x + tb.x, a.y + tb.y);
+        buf[i1] = make_float2(a.x - tb.x, a.y - tb.y);
+      }
+      __syncthreads();
+    }
+    for (int k = tid; k <= half; k += 256) {
+      const float2 z = buf[k];
+      const float p = fmaf(z.x, z.x, z.y * z.y);
+      pmax = fmaxf(pmax, p);
+      if (k < k_crop) out_db[t * (int64_t)k_crop + k] = power_to_db(p);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64));
+  if ((tid & 63) == 0) wmax[tid >> 6] = pmax;
+  __syncthreads();
+  if (tid == 0) atomicMax(&ws->pmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 // ---------------------------------------------------------------- generic level-1 histogram
 __global__ __launch_bounds__(256) void hist1_kernel(const float* __restrict__ x, int64_t n, Workspace* __restrict__ ws) {
   __shared__ uint32_t h[NB1_PAD];
@@ -674,10 +726,20 @@ int orcai_frontend_reset(void* workspace, void* stream) {
 
 int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop, float* out_db, void* workspace,
                   void* stream) {
-  if (!pcm || !out_db || !workspace || n_samples <= 0 || hop <= 0 || k_crop < 1 || k_crop > 257) return ORCAI_E_BADARG;
-  if (n_fft != NFFT) return ORCAI_E_UNSUPPORTED;
+  if (!pcm || !out_db || !workspace || n_samples <= 0 || hop <= 0 || k_crop < 1 || n_fft < 2 || k_crop > 1 + n_fft / 2) return ORCAI_E_BADARG;
   if (n_frames != 1 + n_samples / hop) return ORCAI_E_BADARG;
   if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 15)) return ORCAI_E_BADARG;
+  if (n_fft != NFFT) {  // any other power of two from 32 to 4096: the plain kernel + a separate level-1 histogram pass
+    if (n_fft < 32 || n_fft > NFFT_ANY_MAX || (n_fft & (n_fft - 1))) return ORCAI_E_UNSUPPORTED;
+    int log2n = 0;
+    while ((1 << log2n) < n_fft) ++log2n;
+    const int64_t blocks = n_frames < 256 * 16 ? n_frames : 256 * 16;
+    hipLaunchKernelGGL(stft_any_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pcm, n_samples, n_fft, log2n, hop, n_frames, k_crop, out_db,
+                       (Workspace*)workspace);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return orcai_hist_level1(out_db, n_frames * (int64_t)k_crop, workspace, stream);
+  }
   std::call_once(g_tables_once, init_tables);  // no-op: orcai_frontend_workspace_bytes() already ran it (kept for callers that size the workspace themselves)
   if (g_tables_err) return g_tables_err;
   const int64_t n_groups = (n_frames + 15) / 16;

@@ -52,11 +52,13 @@ class FrontEnd:
 
     @staticmethod
     def _check_nfft(n_fft: int) -> None:
-        """The reference reads nfft from the parameter file (spectrogram.py:34-39); the HIP STFT kernel is built for the 512-point
-        transform every shipped parameter file uses (orcai-V1, default_orcai_parameter.json).  Say so instead of a bare error code."""
-        if int(n_fft) != 512:
-            raise NotImplementedError(f"spectrogram parameter nfft = {n_fft}: the MI355X front end implements nfft = 512 only (the value of "
-                                      "orcai-V1 and of default_orcai_parameter.json); other transform sizes need the reference's CPU path")
+        """The reference reads nfft from the parameter file (spectrogram.py:34-39).  512 -- orcai-V1 and default_orcai_parameter.json -- runs the
+        tuned STFT kernel, any other power of two from 32 to 4096 a plain radix-2 kernel; say what is not covered instead of a bare error code."""
+        n = int(n_fft)
+        if n < 32 or n > 4096 or (n & (n - 1)):
+            raise NotImplementedError(f"spectrogram parameter nfft = {n_fft}: the MI355X front end implements powers of two from 32 to 4096 "
+                                      "(512, the value of orcai-V1 and of default_orcai_parameter.json, on the tuned kernel); other transform "
+                                      "sizes need the reference's CPU path")
 
     # -- the whole of make_spectrogram after decode (spectrogram.py:90-147) -----------------
     def make_spectrogram(self, pcm: torch.Tensor, spectrogram_parameter: dict) -> torch.Tensor:

@@ -123,6 +123,36 @@ def test_make_spectrogram_vs_oracle(fe, seconds):
     assert out.min() == 0.0 and out.max() == 1.0
 
 
+@pytest.mark.parametrize("nfft,hop,seconds", [(256, 128, 7.3), (1024, 256, 7.3), (1024, 512, 20.0), (2048, 300, 3.1), (4096, 1024, 7.3), (64, 32, 0.5), (128, 77, 1.0)])
+def test_other_transform_sizes_vs_oracle(fe, nfft, hop, seconds):
+    """nfft is a field of the parameter file (spectrogram.py:34-39); sizes other than 512 run the plain radix-2 kernel and a separate level-1
+    histogram pass: same pipeline, same bars as the 512-point path, any hop (odd ones too), crop taken from the frequency vector."""
+    from oracle import frontend_ref as F
+
+    sp = dict(SPEC_PARAM, nfft=nfft, n_overlap=hop)
+    y = _pcm(seconds, seed=nfft)
+    ref, _, _ = F.make_spectrogram_ref(y, {"spectrogram": sp})
+    out = fe.make_spectrogram(torch.from_numpy(y).cuda(), sp).cpu().numpy()
+    k = int(np.argwhere(np.fft.rfftfreq(nfft, 1 / 48000) >= 16000)[0][0])
+    assert out.shape == ref.shape == (1 + len(y) // hop, k)
+    d = np.abs(out - ref)
+    assert d.max() <= 2e-4, d.max()
+    assert np.quantile(d, 0.999) <= 2e-5, np.quantile(d, 0.999)
+    assert out.min() == 0.0 and out.max() == 1.0
+    # and the dB matrix of all 1 + nfft/2 bins
+    refdb, _, _ = F.calculate_spectrogram_ref(y, sp)
+    db = fe.calculate_db(torch.from_numpy(y).cuda(), nfft, hop).cpu().numpy().T
+    assert db.shape == refdb.shape and db.max() == 0.0 and db.min() >= -80.0
+    live = refdb > -79.0
+    assert np.abs(db - refdb)[live].max() <= 5e-3
+
+
+def test_unsupported_transform_sizes_say_so(fe):
+    for nfft in (500, 16, 8192):
+        with pytest.raises(NotImplementedError, match="powers of two"):
+            fe.make_spectrogram(torch.zeros(48000, device="cuda"), dict(SPEC_PARAM, nfft=nfft))
+
+
 def test_calculate_db_vs_oracle(fe):
     from oracle import frontend_ref as F
 
