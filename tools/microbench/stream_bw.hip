@@ -56,9 +56,60 @@ __global__ __launch_bounds__(256) void march_copy_kernel(const float4* __restric
   }
 }
 
+// the whole row by one wave: NS consecutive 1-KiB pieces per tensor and step
+template <int NS>
+__global__ __launch_bounds__(256) void march_row_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ d, int H, int W, int WP, int nseg, int rps,
+                                                         int CQ) {
+  const int lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= nseg) return;
+  const int plane = (H + 2) * WP;
+  const size_t pbase = ((size_t)blockIdx.z * CQ + blockIdx.y) * plane;
+  const int r0 = seg * rps, r1 = min(r0 + rps, H);
+  auto pix = [&](int row, int s) { int i = (row + 1) * WP + s * 64 + lane; return i >= plane ? plane - 1 : i; };
+  float4 pa[2][NS], pb[2][NS];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { pa[k][s] = a[pbase + pix(r0 + k, s)]; pb[k][s] = b[pbase + pix(r0 + k, s)]; }
+  for (int r = r0; r < r1; r += 2) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float4 x = pa[k][s], y = pb[k][s];
+        pa[k][s] = a[pbase + pix(r + k + 2, s)];
+        pb[k][s] = b[pbase + pix(r + k + 2, s)];
+        if (s * 64 + lane < W && r + k < r1) d[pbase + (size_t)(r + k + 1) * WP + s * 64 + lane] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+    }
+  }
+}
+
+void run_row(float4* buf[5], int nseg) {
+  const int B = 64, CQ = 8, H = 736, W = 171, WP = 176;
+  const int rps = (H + nseg - 1) / nseg;
+  dim3 grid((nseg + 3) / 4, CQ, B);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((march_row_kernel<3>), grid, dim3(256), 0, 0, buf[0], buf[1], buf[3], H, W, WP, nseg, rps, CQ);
+  (void)hipEventRecord(e0);
+  const int reps = 10;
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((march_row_kernel<3>), grid, dim3(256), 0, 0, buf[0], buf[1], buf[3], H, W, WP, nseg, rps, CQ);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  const double bytes = 3.0 * B * 30 * H * W * 4;
+  printf("whole-row marching copy (3 pieces per step and wave), %d segments of %d rows: %.3f ms  %.2f TB/s of algorithmic bytes\n", nseg, rps, ms, bytes / ms * 1e-9);
+}
+
 template <int DEPTH>
-void run_march(float4* buf[5], int WP = 172, int sstep = 62, int halo = 1) {
-  const int B = 64, CQ = 8, H = 736, W = 171, nseg = 11, rps = 69;
+void run_march(float4* buf[5], int WP = 172, int sstep = 62, int halo = 1, int nseg = 11) {
+  const int B = 64, CQ = 8, H = 736, W = 171;
+  const int rps = (H + nseg - 1) / nseg;
   const int nstrip = (W + sstep - 1) / sstep;
   dim3 grid((nstrip * nseg + 3) / 4, CQ, B);
   hipEvent_t e0, e1;
@@ -74,8 +125,8 @@ void run_march(float4* buf[5], int WP = 172, int sstep = 62, int halo = 1) {
   (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
   const double bytes = 3.0 * B * 30 * H * W * 4;  // algorithmic: 30 channels, two tensors read, one written
-  printf("marching copy, row pitch %d px, strips of %d columns + %d halo, %d strips, %d rows ahead: %.3f ms  %.2f TB/s of algorithmic bytes\n", WP, sstep, halo, nstrip, DEPTH, ms,
-         bytes / ms * 1e-9);
+  printf("marching copy, row pitch %d px, strips of %d columns + %d halo, %d strips, %d segments, %d rows ahead: %.3f ms  %.2f TB/s of algorithmic bytes\n", WP, sstep, halo,
+         nstrip, nseg, DEPTH, ms, bytes / ms * 1e-9);
 }
 
 template <int R, int W>
@@ -111,10 +162,12 @@ int main() {
     run<1, 2>("1 read + 2 writes", buf, n4, blocks);
   }
   run_march<3>(buf);
-  run_march<3>(buf, 176, 62, 1);
   run_march<3>(buf, 176, 64, 0);
-  run_march<3>(buf, 172, 64, 0);
-  run_march<3>(buf, 176, 56, 1);
-  run_march<3>(buf, 176, 56, 0);
+  run_march<3>(buf, 176, 64, 0, 4);
+  run_march<3>(buf, 176, 64, 0, 31);
+  run_march<3>(buf, 176, 64, 0, 92);
+  run_row(buf, 11);
+  run_row(buf, 31);
+  run_row(buf, 92);
   return 0;
 }

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_frontend_gpu.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | cut -c1-1500 > gpurun_out/pytest_fe.log
-echo "pytest rc ${PIPESTATUS[0]}"; tail -n 25 gpurun_out/pytest_fe.log
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | grep -v amdgpu.ids | cut -c1-1500 > gpurun_out/pytest_full.log
+echo "pytest rc ${PIPESTATUS[0]}"; tail -n 6 gpurun_out/pytest_full.log
