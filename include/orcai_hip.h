@@ -181,6 +181,7 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
  *   -> out f32[B][C][ceil(H/2) + 2*(k/2)][orcai_padded_width(ceil(W/2), k)] padded planes */
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br,
                        float* out, int xpooled, void* stream);
+int orcai_pool_vertical(int on); /* experiments: 1 (default) = the inference pooling kernel on stacked tiles (4 output rows x 16 columns per wave: the row two windows share is loaded once) where the pooled plane is >= 40 columns wide; 0 = flat 64-pixel windows everywhere; < 0 queries; returns the previous value.  Bit-identical results. */
 
 /* C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]; act 0 = identity, 1 = ReLU; bias/scale/shift may be NULL.
  * Used for the LSTM input projections x*W + b (architectures.py:210-229) and Dense(128, relu) + BN (:231-237). */

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "orcai_sepconv_planes_u": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_dw_wgrad_march": (C.c_int, [C.c_int]),
+    "orcai_pool_vertical": (C.c_int, [C.c_int]),
     "orcai_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_h_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dw_wgrad_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),

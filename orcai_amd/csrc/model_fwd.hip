@@ -1413,11 +1413,16 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
 // the pooling loads made unconditional (row index clamped into the image: a duplicated row leaves a maximum unchanged) so that
 // they can be issued ahead of their use -- the loads of two 16-pixel tiles are in flight while the residual 1x1 convolution's
 // MFMAs run, instead of 24 load -> wait -> max round trips per wave.
-template <int MT>
+// VERT: the wave's four 16-pixel tiles are STACKED -- output rows 4 g .. 4 g + 3 of one 16-column tile -- instead of 64 consecutive flat pixels.
+// Consecutive output rows share one input row (2 i + 2 closes window i and opens window i + 1); with flat windows the two uses belong to
+// different tiles of neighbouring waves, are requested at about the same time and BOTH miss (PMC: 1.64 GB fetched per block-1 launch for 0.99 GB
+// of x-pooled input, the 3 / 2 of an unshared row; the kernel moves 5.9 TB/s of actual traffic).  Stacked, the shared row is one register set:
+// 9 row loads per wave and quad instead of 12.  Same maxima, same sums: bit-identical.  Used where 16-column tiles waste few lanes (Wo >= 40).
+template <int MT, bool VERT = false>
 __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(const float* __restrict__ s /*[B][CQ][H][WPx][4]*/, const float* __restrict__ prev, int C, int Cp, int H,
                                                               int W, int WP, int R, int Ho, int Wo, int WPo, int pad_top, const float* __restrict__ wr /*[Cp][C]*/,
                                                               const float* __restrict__ br, float* __restrict__ out /*[B][CQ][Ho+2R][WPo][4]*/, int prev_compact,
-                                                              int tasks, uint32_t magic_WPo) {
+                                                              int tasks, uint32_t magic_WPo, int ntc = 0 /*VERT: 16-column tiles per output row*/) {
   const int lane = threadIdx.x & 63;
   int bx, b;
   xcd_remap(bx, b);
@@ -1428,21 +1433,34 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
   const int plane = prev_compact ? Ho * Wo : (H + 2 * R) * WP, plane_o = (Ho + 2 * R) * WPo;
   const int WPx = (Wo + 3) & ~3;
   const int qbase = R * WPo + task * 64;
+  const int vrg = VERT ? task / ntc : 0, vct = VERT ? task - vrg * ntc : 0;  // VERT: row group (4 output rows), column tile
 
   // pooling operands: output pixel 16t + lj of the window, output quad m*4 + lk, rows 2i - pad_top + {0, 1, 2}
-  int soff[4][3], oidx[4];  // float4 index inside one quad plane of s; output pixel index (or -1)
+  constexpr int NROW = VERT ? 9 : 12;  // row sets: VERT shares the row between stacked tiles (tile t uses sets 2t, 2t + 1, 2t + 2)
+  int soff[NROW], oidx[4];  // float4 index inside one quad plane of s; output pixel index (or -1)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int flat = qbase + 16 * t + lj;
-    const int row = (int)__umulhi((uint32_t)flat, magic_WPo);
-    const int j = flat - row * WPo, i = row - R;
-    const bool valid = j < Wo && i < Ho;
+    int i, jj, flat;
+    if (VERT) {
+      i = vrg * 4 + t;
+      jj = vct * 16 + lj;
+      flat = (i + R) * WPo + jj;
+    } else {
+      flat = qbase + 16 * t + lj;
+      const int row = (int)__umulhi((uint32_t)flat, magic_WPo);
+      jj = flat - row * WPo;
+      i = row - R;
+    }
+    const bool valid = jj < Wo && i < Ho;
     oidx[t] = valid ? flat : -1;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
+      if (VERT && t > 0 && dy == 0) continue;  // = set 2t of the tile above
       int y = 2 * i - pad_top + dy;
       y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-      soff[t][dy] = valid ? y * WPx + j : 0;
+      // VERT: a lane past the last column / row still reads a pixel of the image (its column clamped): the set is shared with valid tiles
+      const int jc = jj < Wo ? jj : Wo - 1;
+      soff[VERT ? 2 * t + dy : 3 * t + dy] = VERT ? y * WPx + jc : (valid ? y * WPx + jj : 0);
     }
   }
   // uniform base of the snippet's planes + 32-bit byte offset per lane: one address register per load
@@ -1453,12 +1471,16 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
     const int oq = m * 4 + lk;
     qoff[m] = (uint32_t)((oq < CQ ? oq : 0) * H * WPx);
   }
-  float4 v[4][MT][3];
+  float4 v[NROW][MT];
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) v[t][m][dy] = *reinterpret_cast<const float4*>(sbase + (qoff[m] + (uint32_t)soff[t][dy]) * 16u);
+      for (int dy = 0; dy < 3; ++dy) {
+        if (VERT && t > 0 && dy == 0) continue;
+        const int e = VERT ? 2 * t + dy : 3 * t + dy;
+        v[e][m] = *reinterpret_cast<const float4*>(sbase + (qoff[m] + (uint32_t)soff[e]) * 16u);
+      }
   };
   float br_r[MT][4];  // residual bias of this lane's output channels
 #pragma unroll
@@ -1474,10 +1496,17 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
   if (DEPTH > 1) load_tile(1);
   __builtin_amdgcn_sched_barrier(0);
 
-  // residual branch: Conv2D(C, 1, strides 2)(prev) at this window's 64 output pixels (lane = pixel)
-  const int q = qbase + lane;
-  const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
-  const int pj = q - prow * WPo, pi = prow - R;
+  // residual branch: Conv2D(C, 1, strides 2)(prev) at this window's 64 output pixels (lane = pixel: lane 16 t + lj is pixel lj of tile t)
+  int pj, pi;
+  if (VERT) {
+    pi = vrg * 4 + lk;
+    pj = vct * 16 + lj;
+  } else {
+    const int q = qbase + lane;
+    const int prow = (int)__umulhi((uint32_t)q, magic_WPo);
+    pj = q - prow * WPo;
+    pi = prow - R;
+  }
   const bool pvalid = pj < Wo && pi < Ho;
   const int srcpix = pvalid ? (prev_compact ? pi * Wo + pj : (2 * pi + R) * WP + 2 * pj) : 0;
   const float4* pp = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane + srcpix;
@@ -1514,11 +1543,12 @@ __global__ __launch_bounds__(256, MT <= 2 ? 4 : 2) void pool_res_add_x_kernel(co
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int oq = m * 4 + lk;
-      float mx[4] = {v[t][m][0].x, v[t][m][0].y, v[t][m][0].z, v[t][m][0].w};
+      const int e0 = VERT ? 2 * t : 3 * t;
+      float mx[4] = {v[e0][m].x, v[e0][m].y, v[e0][m].z, v[e0][m].w};
 #pragma unroll
       for (int dy = 1; dy < 3; ++dy) {
-        mx[0] = fmaxf(mx[0], v[t][m][dy].x); mx[1] = fmaxf(mx[1], v[t][m][dy].y);
-        mx[2] = fmaxf(mx[2], v[t][m][dy].z); mx[3] = fmaxf(mx[3], v[t][m][dy].w);
+        mx[0] = fmaxf(mx[0], v[e0 + dy][m].x); mx[1] = fmaxf(mx[1], v[e0 + dy][m].y);
+        mx[2] = fmaxf(mx[2], v[e0 + dy][m].z); mx[3] = fmaxf(mx[3], v[e0 + dy][m].w);
       }
       if (oidx[t] >= 0 && oq < CQ) {
         float o[4];
@@ -1922,6 +1952,7 @@ struct SepArgs {
   InBn ib;                   // ib.mean != nullptr: BatchNorm + ReLU of the input applied on load (training forward with the statistics epilogue)
 };
 
+int g_pool_vert = 1;       // inference pooling kernel on stacked tiles where the plane is wide enough (orcai_pool_vertical: A/B)
 int g_entry_windows = 4;   // windows per wave of conv0_sep_kernel
 int g_entry_tile = 10;     // waves per workgroup of conv0_sep_tile_kernel (10 or 16); 0 = conv0_sep_kernel everywhere
 int g_tile_mode = 1;  // k = 3 launches with plane / x-pooled output: 1 = sepconv_tile_kernel for wide planes with two output tiles (<= 8 input quads,
@@ -2280,11 +2311,19 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   dim3 grid((tasks + 3) / 4, B);
   hipStream_t st = (hipStream_t)stream;
   const uint32_t mg = magic_for(WPo);
+  // stacked tiles (a wave = 4 output rows x 16 columns, the row two pooling windows share loaded once) where 16-column tiles waste few lanes
+  const int ntc = (Wo + 15) / 16, vtasks = ntc * ((Ho + 3) / 4);
+  const bool vert = g_pool_vert && Wo >= 40;
+  dim3 vgrid((vtasks + 3) / 4, B);
 #define ORCAI_POOL_LAUNCH(MT)                                                                                                                        \
-  if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28))                                                                     \
-    hipLaunchKernelGGL(pool_res_add_x_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out, (xpooled >> 1) & 1, \
-                       tasks, mg);                                                                                                                   \
-  else                                                                                                                                               \
+  if ((xpooled & 1) && !bn_mean && (int64_t)((C + 3) / 4) * H * (((Wo + 3) & ~3)) < (1ll << 28)) {                                                                   \
+    if (vert)                                                                                                                                        \
+      hipLaunchKernelGGL((pool_res_add_x_kernel<MT, true>), vgrid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out,            \
+                         (xpooled >> 1) & 1, vtasks, mg, ntc);                                                                                       \
+    else                                                                                                                                             \
+      hipLaunchKernelGGL((pool_res_add_x_kernel<MT, false>), grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, wr, br, out,            \
+                         (xpooled >> 1) & 1, tasks, mg, 0);                                                                                          \
+  } else                                                                                                                                               \
     hipLaunchKernelGGL(pool_res_add_kernel<MT>, grid, dim3(256), 0, st, s, prev, C, Cp, H, W, WP, R, Ho, Wo, WPo, tot_h / 2, tot_w / 2, wr, br, out, xpooled, tasks, mg, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps)
   switch ((C + 15) / 16) {
     case 1: ORCAI_POOL_LAUNCH(1); break;
@@ -2295,6 +2334,12 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
   }
 #undef ORCAI_POOL_LAUNCH
   return (int)hipGetLastError();
+}
+
+int orcai_pool_vertical(int on) {
+  const int prev = g_pool_vert;
+  if (on >= 0) g_pool_vert = on ? 1 : 0;
+  return prev;
 }
 
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br, float* out,
