@@ -158,8 +158,9 @@ class PredictWorkload:
             if mode >= 1:
                 return f"sepconv_ftile_kernel<{mt}, {xp}, {relu}, false, 8, 0, false>"  # <MT, XP, RELU, UOUT, NWV, EPI, BNIN>
             return f"sepconv_kernel<3, {mt}>"
-        if blk in couts and op == "pool_res":
-            return f"pool_res_add_x_kernel<{(couts[blk] + 15) // 16}>"  # inference: the x-pooled fast path
+        if blk in couts and op == "pool_res":  # inference: the x-pooled fast path, <MT, VERT>: stacked tiles where the pooled plane is >= 40 columns wide
+            vert = N.lib().orcai_pool_vertical(-1) and (widths[blk] + 1) // 2 >= 40
+            return f"pool_res_add_x_kernel<{(couts[blk] + 15) // 16}, {'true' if vert else 'false'}>"
         return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
@@ -290,7 +291,7 @@ class _TimedLib:
 
     @staticmethod
     def is_dominant(name, args):
-        return name == TRAIN_DOMINANT_LAUNCHER
+        return name == TRAIN_DOMINANT_LAUNCHER and _train_call_symbol(name, args) == TRAIN_DOMINANT_SYMBOL
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
@@ -315,12 +316,57 @@ class _TimedLib:
 # (profiles/r02_train_rocprofv3_kernel_stats.csv: bn_bwd_pw_kernel<*> 15.6 % of the step summed over its instantiations).  roofline()
 # re-derives the dominant launcher from its own table every run and reports whether the two agree.
 TRAIN_DOMINANT_LAUNCHER = "orcai_bn_bwd_pointwise_wgrad"
+TRAIN_DOMINANT_SYMBOL = "bn_bwd_pw_wgrad_kernel<2, 2, 4>"  # the top row of profiles/r03_train_rocprofv3_kernel_stats.csv: block 1's second separable conv
 LAUNCHER_KERNELS = {"orcai_bn_bwd_pointwise": "bn_bwd_pw_kernel<MT>", "orcai_outer_reduce": "outer_reduce_kernel<NP>", "orcai_dw_wgrad": "dw_wgrad_kernel<3>",
                     "orcai_sepconv_planes_stats": "sepconv_tile_kernel / sepconv_ftile_kernel<..., STATS = true>", "orcai_sepconv_planes_u": "sepconv_*_kernel",
                     "orcai_bn_planes_stats": "planes_sums_kernel", "orcai_bn_planes_apply": "bn_planes_apply_kernel",
                     "orcai_bn_bwd_pointwise_wgrad": "bn_bwd_pw_wgrad_kernel<MT, NT, 4>", "orcai_sepconv_planes_epi": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 2 | 3>",
                     "orcai_sepconv_planes_stats_bn": "sepconv_tile_kernel / sepconv_ftile_kernel<..., EPI = 1, BNIN>", "orcai_dw_wgrad_bn": "dw_wgrad_kernel<3, true>",
                     "orcai_dw_bwd_fused": "dw_bwd_march_kernel<SW, EPI, BNIN>"}
+
+
+def _train_call_symbol(name, a):
+    """The kernel symbol (template instantiation, as rocprofv3 --kernel-trace --stats prints it) a launcher call runs, for the launchers whose
+    launches top the training step; the family name of LAUNCHER_KERNELS otherwise.  rocprofv3 ranks SYMBOLS, so the roofline table does too."""
+    if name == "orcai_bn_bwd_pointwise_wgrad":  # dy,v,u,B,C,H,W,ksize,...,wt,Cin,...: MT = conv-input tiles, NT = conv-output tiles, four-wave workgroups up to 4 tiles
+        mt, nt = (a[19] + 15) // 16, (a[4] + 15) // 16
+        return f"bn_bwd_pw_wgrad_kernel<{mt}, {nt}, {4 if mt + nt <= 4 else 2}>"
+    if name == "orcai_dw_bwd_fused":  # x,du,B,C,H,W,relu_in,dw_rev,dr,dW,epi,bn_mean,...: strip width as the launcher picks it
+        W, epi, bn = a[5], a[10], a[11] is not None
+        best, lanes = 64, ((W + 61) // 62) * 64
+        if ((W + 29) // 30) * 32 < lanes:
+            best, lanes = 32, ((W + 29) // 30) * 32
+        if ((W + 13) // 14) * 16 < lanes:
+            best = 16
+        return f"dw_bwd_march_kernel<{best}, {epi}, {'true' if bn else 'false'}>"
+    if name == "orcai_bn_bwd_pointwise":  # ...,wt,Cin,dv,du,stream
+        return f"bn_bwd_pw_kernel<{(a[18] + 15) // 16}>"
+    if name in ("orcai_sepconv_planes_stats", "orcai_sepconv_planes_stats_bn"):  # the LDS-tile kernels with the depthwise-output store and the statistics epilogue
+        bn = name.endswith("_bn")
+        Cin, W, Cout = a[2], a[4], a[14 if bn else 10]
+        relu = "false" if bn else ("true" if a[5] else "false")
+        mt, cq, nstrip = (Cout + 15) // 16, (Cin + 3) // 4, (W + 61) // 62
+        if mt == 2 and cq <= 8 and nstrip >= 2 and W * 100 >= nstrip * 62 * 85:  # launch_sepconv_impl's rule for the strip tiles
+            return f"sepconv_tile_kernel<2, {4 if cq <= 4 else 8}, false, {relu}, 8, true, 1, {'true' if bn else 'false'}>"
+        return f"sepconv_ftile_kernel<{mt}, false, {relu}, true, 8, 1, {'true' if bn else 'false'}>"
+    if name == "orcai_outer_reduce":  # A,Ca,Bq,Cb,...: 256 pixels per pass up to 32 channels per operand, 128 beyond
+        return f"outer_reduce_kernel<{256 if max(a[1], a[3]) <= 32 else 128}>"
+    if name in ("orcai_pool_bwd_bn_bias", "orcai_pool_bwd_bn", "orcai_pool_bwd"):
+        return "pool_bwd_kernel"
+    if name == "orcai_pool_res_add_bn":  # s,prev,B,C,...
+        return f"pool_res_add_kernel<{(a[3] + 15) // 16}>"
+    return LAUNCHER_KERNELS.get(name, name)
+
+
+def measured_traffic_symbol(symbol: str, workload: str):
+    """HBM bytes per launch of one kernel symbol from the newest PMC table (None when it is not there)."""
+    import json
+
+    f = traffic_file()
+    if f is None:
+        return None
+    rec = json.loads(f.read_text()).get(workload, {}).get("kernels", {}).get(symbol)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
 def measured_traffic_prefix(prefix: str, workload: str):
@@ -420,12 +466,13 @@ class TrainWorkload:
             self.ev.append((e0, e1))
 
     def roofline(self):
-        """The step against the f32-MFMA peak, and the dominant LAUNCHER of the step against HBM.  Which launcher dominates is measured, not
+        """The step against the f32-MFMA peak, and the dominant kernel SYMBOL of the step against HBM.  Which symbol dominates is measured, not
         assumed: two extra steps after the timed region bracket every orcai_* launcher with HIP events (the brackets slow the step, so they
-        stay outside the timed region); the launcher with the largest summed time among those whose algorithmic bytes are known
-        (_train_call_bytes: every tensor read / written once at its true channel count) is reported -- per call, achieved = bytes / time.
-        The launchers bracketed INSIDE the timed steps (TimedLib.is_dominant) are last run's dominant one; `kernel_in_timed_steps` says
-        whether the timed-region figure and the table agree on the name."""
+        stay outside the timed region); the calls are grouped by the template instantiation they run (_train_call_symbol: what rocprofv3
+        --stats ranks) and the symbol with the largest summed time among those whose algorithmic bytes are known (_train_call_bytes: every
+        tensor read / written once at its true channel count) is reported -- per launch, achieved = bytes / time.  The calls bracketed INSIDE
+        the timed steps (TimedLib.is_dominant) are last run's dominant symbol; `kernel_in_timed_steps` says whether the timed-region figure
+        and the table agree on it."""
         ms = float(np.mean([a.elapsed_time(b) for a, b in self.ev]))
         n_steps = len(self.ev)
         timed_calls = dict(self.timed.events or {})
@@ -436,27 +483,35 @@ class TrainWorkload:
         for _ in range(2):
             self.trainer.train_step(self.x, 736 * 171, self.B, self.y, world_size=1)
         torch.cuda.synchronize()
-        table = {}
+        table, by_symbol = {}, {}
         for name, calls in self.timed.events.items():
             t = sum(a.elapsed_time(b) for a, b, _ in calls) / 2
             by = [_train_call_bytes(name, args) for _, _, args in calls]
             table[name] = (t, None if any(b is None for b in by) else sum(by) / 2, len(calls) // 2)
+            for (e0, e1, args), b in zip(calls, by):  # the same calls by kernel SYMBOL: what rocprofv3 --stats ranks
+                d = by_symbol.setdefault(_train_call_symbol(name, args), {"ms": 0.0, "bytes": 0.0, "n": 0, "launcher": name, "priced": True})
+                d["ms"] += e0.elapsed_time(e1) / 2
+                d["n"] += 0.5
+                d["priced"] = d["priced"] and b is not None
+                d["bytes"] += (b or 0.0) / 2
         self.timed.mode, self.timed.events = "dominant", None
         out["launcher_ms_per_step_instrumented"] = {k: round(v[0], 3) for k, v in sorted(table.items(), key=lambda kv: -kv[1][0])[:12]}
-        priced = {k: v for k, v in table.items() if v[1]}
+        out["symbol_ms_per_step_instrumented"] = {k: round(v["ms"], 3) for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        priced = {k: v for k, v in by_symbol.items() if v["priced"] and v["bytes"] > 0}
         if priced:
-            top = max(priced, key=lambda k: priced[k][0])
-            t, by, n = priced[top]
+            top = max(priced, key=lambda k: priced[k]["ms"])
+            d = priced[top]
+            t, by, n = d["ms"], d["bytes"], max(1, int(round(d["n"])))
             ach = by / (t * 1e-3) / 1e9
-            out.update({"bound": "hbm", "kernel": LAUNCHER_KERNELS.get(top, top), "launcher": top, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic_prefix(LAUNCHER_KERNELS.get(top, top).split("<")[0] + "<", "train") if traffic_has("train") else None,
+            out.update({"bound": "hbm", "kernel": top, "launcher": d["launcher"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic_symbol(top, "train") if traffic_has("train") else None,
                         "kernel_ms": round(t / n, 4), "launches_per_step": n, "algorithmic_bytes_per_launch": round(by / n),
                         "measured": "fully bracketed steps after the timed region"})
-            inside = timed_calls.get(top)
+            inside = [(e0, e1, args) for e0, e1, args in timed_calls.get(d["launcher"], []) if _train_call_symbol(d["launcher"], args) == top]
             out["kernel_in_timed_steps"] = bool(inside)
-            if inside:  # the same launcher bracketed inside the timed steps (only it: an event pair costs ~15 us of queue time)
+            if inside:  # the same symbol bracketed inside the timed steps (only it: an event pair costs ~15 us of queue time)
                 ti = sum(a.elapsed_time(b) for a, b, _ in inside)
-                bi = sum(_train_call_bytes(top, args) for _, _, args in inside)
+                bi = sum(_train_call_bytes(d["launcher"], args) for _, _, args in inside)
                 out.update({"achieved": round(bi / (ti * 1e-3) / 1e9, 1), "frac": round(bi / (ti * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(ti / len(inside), 4),
                             "launches_per_step": len(inside) // max(1, n_steps), "algorithmic_bytes_per_launch": round(bi / len(inside)), "measured": "inside the timed steps"})
         return out
