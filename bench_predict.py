@@ -338,9 +338,11 @@ def _train_call_symbol(name, a):
             best, lanes = 32, ((W + 29) // 30) * 32
         if ((W + 13) // 14) * 16 < lanes:
             best = 16
-        return f"dw_bwd_march_kernel<{best}, {epi}, {'true' if bn else 'false'}>"
+        return f"dw_bwd_march_kernel<{best}, {epi}, {'true' if bn else 'false'}, false>"
     if name == "orcai_bn_bwd_pointwise":  # ...,wt,Cin,dv,du,stream
         return f"bn_bwd_pw_kernel<{(a[18] + 15) // 16}>"
+    if name == "orcai_dw_bwd_fused_conv0":
+        return "dw_bwd_march_kernel<64, 2, true, true>"
     if name in ("orcai_sepconv_planes_stats", "orcai_sepconv_planes_stats_bn"):  # the LDS-tile kernels with the depthwise-output store and the statistics epilogue
         bn = name.endswith("_bn")
         Cin, W, Cout = a[2], a[4], a[14 if bn else 10]
@@ -410,6 +412,8 @@ def _train_call_bytes(name, a):
         return 4.0 * B * H * W * (2 * C + 2 * Cin)
     if name == "orcai_dw_bwd_fused":  # x,du,B,C,H,W,...: du and x read once, dr written once
         return 4.0 * a[2] * a[4] * a[5] * 3 * a[3]
+    if name == "orcai_dw_bwd_fused_conv0":  # in,stride,du,B,H,W,...: du read, dr written (16 channels), the snippet and the quarter-size residual gradient
+        return 4.0 * a[3] * a[4] * a[5] * (2 * 16 + 1 + 4)
     if name == "orcai_dw_wgrad_bn":  # v,du,B,C,H,W,...
         return 4.0 * a[2] * a[4] * a[5] * 2 * a[3]
     if name == "orcai_bn_bwd_pointwise":  # dy,v,B,C,H,W,ksize,mean,var,gamma,beta,eps,relu,scratch,sums_ready,dbeta,dgamma,wt,Cin,dv,du,stream

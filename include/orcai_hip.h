@@ -419,6 +419,19 @@ int orcai_dw_wgrad_bn(const float* v, const float* du, int B, int C, int H, int 
  * interior of dr is written.  ORCAI_E_UNSUPPORTED (nothing touched): C > 64, misaligned planes. */
 int orcai_dw_bwd_fused(const float* x, const float* du, int B, int C, int H, int W, int relu_in, const float* dw_rev, float* dr, float* dW, int epi, const float* bn_mean,
                        const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream);
+/* orcai_dw_bwd_fused(epi 2) for block 1's first separable conv when the training forward did not keep the entry conv's pre-normalisation tensor
+ * (orcai_conv0_stats + orcai_conv0_affine_bn): the conv input y0 = relu(bn0(conv0(snippet))) is rebuilt per pixel from the snippet's nine taps
+ * (w0 [9][16], bias0 [16], bn0's batch statistics) instead of read, and the sums left in `shards` (dbeta[16] | dgamma[16] doubles; >= 32 * 32 doubles
+ * of scratch) are bn0's backward sums over dr -- what the first pass of orcai_conv0_bn_bwd_x computes; orcai_conv0_bn_bwd_x_ready is that entry
+ * point without its first pass.  resq (optional): the residual branch's gradient w.r.t. y0 at the even pixels (2i, 2j) as planes of 16 channels at
+ * the pooled resolution [B][4][ceil(H/2) + 2][padded_width(ceil(W/2))][4] (a plain pointwise pass W_res^T dout): added to dr -- and so part of bn0's
+ * sums -- instead of a scatter-add pass over dr afterwards.  k = 3 planes. */
+int orcai_dw_bwd_fused_conv0(const float* in, int64_t snippet_stride, const float* du, int B, int H, int W, const float* w0, const float* bias0, const float* dw_rev, float* dr,
+                             float* dW, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, double* shards, const float* resq,
+                             void* stream);
+int orcai_conv0_bn_bwd_x_ready(const float* in, int64_t snippet_stride, const float* dy, int B, int H, int W, int ksize, const float* w0, const float* bias, const float* mean,
+                               const float* var, const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, float* workspace,
+                               int64_t workspace_floats, void* stream);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);
 /* Keras-Reshape layout f32[B][H][W*C] -> padded channel-quad planes (gradient entering the final separable conv) */

@@ -1019,21 +1019,36 @@ __global__ __launch_bounds__(256) void dw_wgrad_march_kernel(const float* __rest
 // SW lanes per strip (64, 32 or 16: SW - 2 output columns): a wave carries 64 / SW strips of the same (snippet, quad), so planes narrower than
 // 62 columns do not idle most lanes (W = 86: three 30-column strips = 96 lanes).  Strips beside each other in a wave exchange garbage through the
 // DPP shifts only into their halo lanes, which produce nothing.
-template <int SW, int EPI, bool BNIN>
+// C0 (block 1's first separable conv): its input y0 = relu(bn0(conv0(snippet))) is not read but REBUILT per pixel from the nine taps of the
+// 1-channel snippet -- conv0_kernel's fma chain in its order, fma(acc, 1, bias), then the BNIN stage -- so `x` is the entry conv's
+// pre-normalisation value v0 formed in registers: the pass reads du and 4 bytes per pixel of input instead of du and y0, and the EPI 2 sums it
+// leaves are bn0's backward sums (orcai_conv0_bn_bwd_x's first pass over dr1 and the input disappears).  The three input rows rotate with the du
+// rows; a strip's halo lanes hold the neighbouring input columns.
+struct Conv0In {
+  const float* in = nullptr;       // [B] snippets of H x W at snippet_stride
+  int64_t snippet_stride = 0;
+  const float* w0 = nullptr;       // [9][16]
+  const float* bias = nullptr;     // [16]
+  const float* resq = nullptr;     // optional [B][4][Ho + 2][WPo][4]: the residual branch's gradient w.r.t. y0 at the even pixels (2i, 2j), as planes of the
+  int Ho = 0, WPo = 0;             // pooled resolution; added to dr (and so part of bn0's sums) instead of a scatter-add pass over dr afterwards
+};
+
+template <int SW, int EPI, bool BNIN, bool C0 = false>
 __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restrict__ x, const float* __restrict__ du, int C, int H, int W, int WP, int relu_in,
                                                             const float* __restrict__ wrev /*[CQ][9][4] reversed taps*/, float* __restrict__ dr,
                                                             float* __restrict__ dW /*[9][C]*/, double* __restrict__ shards /*EPI 2: [32][CQ][8]*/, int nstrip,
-                                                            int nseg, int rps, InBnW ib, int epi_relu) {
+                                                            int nseg, int rps, InBnW ib, int epi_relu, Conv0In c0 = Conv0In{}) {
   static_assert(SW == 64 || SW == 32 || SW == 16, "strip lanes");
   static_assert(EPI == 0 || EPI == 2 || EPI == 3, "epilogue extras");
   static_assert(EPI != 2 || BNIN, "EPI 2: x is the pre-normalisation tensor of the BatchNorm whose backward sums are taken");
+  static_assert(!C0 || (BNIN && EPI == 2), "C0: the entry conv's pre-normalisation tensor rebuilt on the fly, bn0's sums in the epilogue");
   constexpr int KK = 9, NSUB = 64 / SW;
   const int lane = threadIdx.x & 63, sl = lane % SW, sub = lane / SW;
   const int cq = blockIdx.y, b = blockIdx.z;
   const int CQ = (C + 3) >> 2;
   const int plane = (H + 2) * WP;
   const int64_t pbase = ((int64_t)b * CQ + cq) * plane;
-  const float4* xp = reinterpret_cast<const float4*>(x) + pbase;
+  const float4* xp = reinterpret_cast<const float4*>(C0 ? du : x) + pbase;  // C0: x is not read
   const float4* dp = reinterpret_cast<const float4*>(du) + pbase;
   float4* op = reinterpret_cast<float4*>(dr) + pbase;
   const int task = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NSUB + sub;
@@ -1068,6 +1083,44 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
       }
     }
   }
+  // C0: the entry conv's taps and bias of this quad.  Wave-uniform, but deliberately in VECTOR registers: with the 36 depthwise taps and the
+  // BatchNorm constants already scalar, 40 more scalars spilled 134 SGPRs into v_readlane traffic inside the row loop (the kernel has the VGPRs to
+  // spare at its two waves per SIMD).  The opaque zero keeps the compiler from proving the addresses uniform.
+  float w0q[KK][4], b0q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (C0) {
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w0q[t][j] = c0.w0[t * 16 + cq * 4 + j + vz];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0q[j] = c0.bias[cq * 4 + j + vz];
+  }
+  const float* inb = C0 ? c0.in + (int64_t)b * c0.snippet_stride : nullptr;
+  struct InRow { float c, l, r; };
+  auto iload = [&](int row) -> float {  // snippet pixel (row, xcol), zero outside the image ("same" padding); unconditional, clamped
+    const int rr = row < 0 ? 0 : (row >= H ? H - 1 : row), cc = xcol < 0 ? 0 : (xcol >= W ? W - 1 : xcol);
+    const float v = inb[(int64_t)rr * W + cc];
+    return (row >= 0 && row < H && xcol >= 0 && xcol < W) ? v : 0.0f;
+  };
+  auto iarrive = [&](float v, InRow& o) {
+    o.c = v;
+    o.l = lsh<3, -1>(v);
+    o.r = lsh<3, 1>(v);
+  };
+  auto conv0_at = [&](const InRow& up, const InRow& mid, const InRow& dn) -> float4 {
+    const float a[KK] = {up.l, up.c, up.r, mid.l, mid.c, mid.r, dn.l, dn.c, dn.r};
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float cv = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) cv = fmaf(a[t], w0q[t][j], cv);  // conv0_kernel's chain, taps in (dy, dx) order
+      v[j] = fmaf(cv, 1.0f, b0q[j]);                                   // ... and its fma(acc, scale = 1, shift = bias)
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
   struct Row { float c[4], l[4], r[4]; };
   auto pix = [&](int row) -> int {  // image row `row` (-1 .. H): padded-plane row row + 1; clamped (rows past the segment feed dead steps only)
     const int i = (row + 1) * WP + xcol;
@@ -1082,9 +1135,11 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
       o.r[j] = lsh<3, 1>(v[j]);
     }
   };
+  float4 radd = make_float4(0.f, 0.f, 0.f, 0.f);  // C0 with a residual gradient: its value at this lane's pixel for the current step (0 off the even pixels)
   auto step = [&](const Row& up, const Row& mid, const Row& dn, const float4& x4, int row) {
     const bool live = out_lane && row < r_end;
     const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    const float ra[4] = {radd.x, radd.y, radd.z, radd.w};
     float d[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1096,6 +1151,7 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
       a = fmaf(up.c[j], wt[j][1], a); a = fmaf(up.r[j], wt[j][2], a);
       a = fmaf(mid.l[j], wt[j][3], a); a = fmaf(mid.c[j], wt[j][4], a); a = fmaf(mid.r[j], wt[j][5], a);
       a = fmaf(dn.l[j], wt[j][6], a); a = fmaf(dn.c[j], wt[j][7], a); a = fmaf(dn.r[j], wt[j][8], a);
+      if (C0) a += ra[j];  // the residual branch's gradient joins before the sums and the store
       acc[j][0] = fmaf(up.l[j], y, acc[j][0]); acc[j][1] = fmaf(up.c[j], y, acc[j][1]); acc[j][2] = fmaf(up.r[j], y, acc[j][2]);
       acc[j][3] = fmaf(mid.l[j], y, acc[j][3]); acc[j][4] = fmaf(mid.c[j], y, acc[j][4]); acc[j][5] = fmaf(mid.r[j], y, acc[j][5]);
       acc[j][6] = fmaf(dn.l[j], y, acc[j][6]); acc[j][7] = fmaf(dn.c[j], y, acc[j][7]); acc[j][8] = fmaf(dn.r[j], y, acc[j][8]);
@@ -1111,7 +1167,40 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
     }
     if (live) op[(row + 1) * WP + xcol] = make_float4(d[0], d[1], d[2], d[3]);
   };
-  if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+  if (C0) {
+    if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+      Row A, Bq, Cq;
+      InRow IA, IB, IC;
+      arrive(dp[pix(r_begin - 1)], A);
+      arrive(dp[pix(r_begin)], Bq);
+      iarrive(iload(r_begin - 1), IA);
+      iarrive(iload(r_begin), IB);
+      // in flight: (du row r + 1, snippet row r + 1) of the next three steps
+      float4 pg0 = dp[pix(r_begin + 1)], pg1 = dp[pix(r_begin + 2)], pg2 = dp[pix(r_begin + 3)];
+      float pi0 = iload(r_begin + 1), pi1 = iload(r_begin + 2), pi2 = iload(r_begin + 3);
+      // residual gradient of row r (compact planes at the pooled resolution): requested three steps ahead as well; every lane loads (its pixel's
+      // pair partner the same 16 bytes), only even (row, column) keep the value
+      const bool has_res = c0.resq != nullptr;
+      const float4* rqp = has_res ? reinterpret_cast<const float4*>(c0.resq) + ((int64_t)b * CQ + cq) * ((int64_t)(c0.Ho + 2) * c0.WPo) : dp;
+      const bool col_even = xcol >= 0 && (xcol & 1) == 0;
+      const int jq = xcol < 0 ? 0 : (xcol >> 1);
+      auto rload = [&](int row) -> float4 {
+        if (!has_res) return make_float4(0.f, 0.f, 0.f, 0.f);  // wave-uniform
+        int iq = row >> 1;
+        iq = iq < 0 ? 0 : (iq >= c0.Ho ? c0.Ho - 1 : iq);
+        const int jc = jq >= c0.WPo ? c0.WPo - 1 : jq;
+        return rqp[(iq + 1) * c0.WPo + jc];
+      };
+      auto rkeep = [&](const float4& v, int row) { radd = (col_even && (row & 1) == 0) ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
+      float4 pr0 = rload(r_begin), pr1 = rload(r_begin + 1), pr2 = rload(r_begin + 2);
+      for (int i = 0; i < rps; i += 3) {
+        const int r = r_begin + i;
+        { const float4 gr = pg0, rr = pr0; const float ir = pi0; pg0 = dp[pix(r + 4)]; pi0 = iload(r + 4); pr0 = rload(r + 3); arrive(gr, Cq); iarrive(ir, IC); rkeep(rr, r); step(A, Bq, Cq, conv0_at(IA, IB, IC), r); }
+        { const float4 gr = pg1, rr = pr1; const float ir = pi1; pg1 = dp[pix(r + 5)]; pi1 = iload(r + 5); pr1 = rload(r + 4); arrive(gr, A); iarrive(ir, IA); rkeep(rr, r + 1); step(Bq, Cq, A, conv0_at(IB, IC, IA), r + 1); }
+        { const float4 gr = pg2, rr = pr2; const float ir = pi2; pg2 = dp[pix(r + 6)]; pi2 = iload(r + 6); pr2 = rload(r + 5); arrive(gr, Bq); iarrive(ir, IB); rkeep(rr, r + 2); step(Cq, A, Bq, conv0_at(IC, IA, IB), r + 2); }
+      }
+    }
+  } else if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
     Row A, Bq, Cq;
     arrive(dp[pix(r_begin - 1)], A);
     arrive(dp[pix(r_begin)], Bq);
@@ -1471,7 +1560,7 @@ __global__ __launch_bounds__(256) void relu_bwd4_kernel(const float4* __restrict
 
 template <int SW>
 static int launch_dw_bwd(hipStream_t st, const float* x, const float* du, int B, int C, int H, int W, int WP, int relu_in, const float* wrev, float* dr, float* dW, int epi,
-                         const InBnW& ib, int epi_relu, double* shards, int nstrip) {
+                         const InBnW& ib, int epi_relu, double* shards, int nstrip, const Conv0In* c0 = nullptr) {
   constexpr int NSUB = 64 / SW;
   const int CQ = (C + 3) / 4;
   const int64_t per_seg = (int64_t)B * CQ * nstrip;
@@ -1483,10 +1572,11 @@ static int launch_dw_bwd(hipStream_t st, const float* x, const float* du, int B,
   nseg = (H + rps - 1) / rps;
   const int waves = (nstrip * nseg + NSUB - 1) / NSUB;
   dim3 grid((waves + 3) / 4, CQ, B);
-  if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu);
-  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
-  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
-  else hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  if (c0) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 2, true, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 1, *c0);
+  else if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu, Conv0In{});
+  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, Conv0In{});
+  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, Conv0In{});
+  else hipLaunchKernelGGL((dw_bwd_march_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, Conv0In{});
   return (int)hipGetLastError();
 }
 
@@ -1851,6 +1941,66 @@ int orcai_dw_bwd_fused(const float* x, const float* du, int B, int C, int H, int
   else rc = launch_dw_bwd<16>(st, x, du, B, C, H, W, WP, relu_in, dw_rev, dr, dW, epi, ib, bn_relu, shards, (W + 13) / 14);
   if (rc != 0) return rc;
   if (epi == 2) hipLaunchKernelGGL(bwd_sums_compact_kernel, dim3(1), dim3(256), 0, st, shards, CQ);
+  return (int)hipGetLastError();
+}
+
+int orcai_dw_bwd_fused_conv0(const float* in, int64_t snippet_stride, const float* du, int B, int H, int W, const float* w0, const float* bias0, const float* dw_rev, float* dr,
+                             float* dW, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, double* shards, const float* resq,
+                             void* stream) {
+  if (!in || !du || !w0 || !bias0 || !dw_rev || !dr || !dW || !bn_mean || !bn_var || !bn_gamma || !bn_beta || !shards || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  const int C = 16, CQ = 4, WP = orcai_padded_width(W, 3);
+  if (B > 65535 || (int64_t)(H + 2) * WP >= (1ll << 27) || (int64_t)H * W >= (1ll << 30) || ((uintptr_t)du & 15) || ((uintptr_t)dr & 15) || ((uintptr_t)resq & 15))
+    return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  InBnW ib;
+  ib.mean = bn_mean; ib.var = bn_var; ib.gamma = bn_gamma; ib.beta = bn_beta; ib.eps = bn_eps;
+  Conv0In c0;
+  c0.in = in; c0.snippet_stride = snippet_stride; c0.w0 = w0; c0.bias = bias0;
+  c0.resq = resq; c0.Ho = (H + 1) / 2; c0.WPo = orcai_padded_width((W + 1) / 2, 3);
+  hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * CQ * 32, st);
+  if (e != hipSuccess) return (int)e;
+  int best = 64, best_lanes = ((W + 61) / 62) * 64;
+  if (((W + 29) / 30) * 32 < best_lanes) { best = 32; best_lanes = ((W + 29) / 30) * 32; }
+  if (((W + 13) / 14) * 16 < best_lanes) { best = 16; best_lanes = ((W + 13) / 14) * 16; }
+  int rc;
+  if (best == 64) rc = launch_dw_bwd<64>(st, nullptr, du, B, C, H, W, WP, 0, dw_rev, dr, dW, 2, ib, 1, shards, (W + 61) / 62, &c0);
+  else if (best == 32) rc = launch_dw_bwd<32>(st, nullptr, du, B, C, H, W, WP, 0, dw_rev, dr, dW, 2, ib, 1, shards, (W + 29) / 30, &c0);
+  else rc = launch_dw_bwd<16>(st, nullptr, du, B, C, H, W, WP, 0, dw_rev, dr, dW, 2, ib, 1, shards, (W + 13) / 14, &c0);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(bwd_sums_compact_kernel, dim3(1), dim3(256), 0, st, shards, CQ);
+  return (int)hipGetLastError();
+}
+
+int orcai_conv0_bn_bwd_x_ready(const float* in, int64_t snippet_stride, const float* dy, int B, int H, int W, int ksize, const float* w0, const float* bias, const float* mean,
+                               const float* var, const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, float* workspace,
+                               int64_t workspace_floats, void* stream) {
+  // orcai_conv0_bn_bwd_x whose first pass already happened: scratch2C holds bn0's backward sums dbeta[16] | dgamma[16] (orcai_dw_bwd_fused_conv0)
+  if (!in || !dy || !w0 || !bias || !dW || !scratch2C || !dbeta || !dgamma || !workspace || B <= 0) return ORCAI_E_BADARG;
+  if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = 16, R = ksize / 2, WP = orcai_padded_width(W, ksize), KK = ksize * ksize;
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  const int64_t ntiles = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * B;
+  if (plane >= (1ll << 31) || ntiles >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  int gx = (int)(ntiles < 512 ? ntiles : 512);
+  if ((int64_t)gx * KK * 16 > workspace_floats) gx = (int)(workspace_floats / (KK * 16));
+  if (gx < 1) return ORCAI_E_BADARG;
+  double* db = scratch2C;
+  double* dg = scratch2C + 16;
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+  dim3 grid(gx, 4);
+#define ORCAI_C0XR(KS_)                                                                                                                                    \
+  hipLaunchKernelGGL((conv0_bn_bwd_x_kernel<KS_, true>), grid, dim3(256), 0, st, in, snippet_stride, dy, H, W, WP, B, w0, bias, mean, var, gamma, beta, eps,  \
+                     (double*)nullptr, db, dg, inv_count, workspace)
+  switch (ksize) {
+    case 3: ORCAI_C0XR(3); break;
+    case 5: ORCAI_C0XR(5); break;
+    case 7: ORCAI_C0XR(7); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_C0XR
+  hipLaunchKernelGGL(add_partials_kernel, dim3(blocks_for(KK * 16), 8), dim3(256), 0, st, workspace, gx, KK * 16, dW);
+  hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();
 }
 

@@ -389,6 +389,9 @@ class TrunkTrainer:
         self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
+        self.conv0_in_dgrad = True  # block 1's first conv: y0 rebuilt from the snippet inside the marching depthwise backward, bn0's sums in its epilogue (A/B: tools/ab_flags.py)
+        self.bn0_sums_ready = False
+        self._resq = None
         self.fused_dw_bwd = True  # input gradient + its epilogue extra + depthwise weight gradient of a k = 3 separable conv in one marching pass (A/B: tools/ab_flags.py)
         self.fused_pw_wgrad = True  # BN backward apply + du + pointwise weight gradient in one pass where the layer is narrow enough (A/B: tools/ab_train.py)
         self.fused_stats_under_capture = True  # the epilogue statistics also inside a captured step (tools/debug_graph_divergence.py)
@@ -503,6 +506,7 @@ class TrunkTrainer:
         b = {}
         h, w, _ = shapes[0]
         b["v0"], b["y0"] = self._planes(B, 16, h, w), self._planes(B, 16, h, w)
+        b["rq1"] = self._planes(B, 16, shapes[1][0], shapes[1][1])  # block 1's residual gradient w.r.t. y0 at the even pixels (compact; see conv0_in_dgrad)
         for i, f in enumerate(m.filters, start=1):
             h, w, cprev = shapes[i - 1]
             for n in ("va", "ya", "vb"):  # y_b = BN_b(v_b) is never materialised (the pooling kernels apply BN on the fly)
@@ -699,11 +703,26 @@ class TrunkTrainer:
         self._sep(du, Cin, H, W, k, 0, dw, eye, zeros, Cin, dr)
         return False
 
+    def _conv0_dgrad_ok(self, x) -> bool:
+        """Block 1's first conv may rebuild its input y0 from the snippet (orcai_dw_bwd_fused_conv0): f32, k = 3, the two-pass entry conv (v0 not stored)."""
+        return bool(self.conv0_in_dgrad and self.fused_dw_bwd and not self.v0_stored and not self.half and self.k == 3 and x.data_ptr() == self.buf["y0"].data_ptr())
+
     def _dw_bwd_fused(self, name, x, relu_in, Cin, H, W, du, dr, epi, x_bn):
         """orcai_dw_bwd_fused for one separable conv: dr, the depthwise weight gradient and the epilogue extra `epi` of _dgrad in one pass over
         (du, x).  Returns whether the epilogue extra ran (True / False), or None when the launch is not this kernel's (the caller runs the
         separate passes): the extras read the conv's own input, so ("bsums", ref, ...) needs ref to be the pre-normalisation tensor x."""
         P = self.P
+        if name == "b1/sep_a" and epi is None and x_bn is None and self._conv0_dgrad_ok(x):
+            # block 1's first conv: y0 rebuilt from the snippet's taps instead of read, bn0's backward sums left in self.scratch for orcai_conv0_bn_bwd_x_ready
+            mean0, var0 = self.stats["bn0"]
+            rc = self.lib.orcai_dw_bwd_fused_conv0(self.src.data_ptr(), self.snippet_stride, du.data_ptr(), self.B, H, W, P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(),
+                                                   self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(), P.G(name + "/depthwise").data_ptr(), mean0.data_ptr(), var0.data_ptr(),
+                                                   P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(),
+                                                   None if self._resq is None else self._resq.data_ptr(), N.stream_ptr())
+            if rc != N.E_UNSUPPORTED:
+                N.check(rc, "orcai_dw_bwd_fused_conv0")
+                self.bn0_sums_ready = True
+                return False
         mode, bn, bn_relu = 0, x_bn, 0
         if epi is not None and self.dgrad_epilogues:
             if epi[0] == "bsums":
@@ -776,6 +795,7 @@ class TrunkTrainer:
         shapes = m.stage_shapes()
         L = len(m.filters)
         h, w, c = shapes[-1]
+        self.bn0_sums_ready = False
         N.check(self._fn("feat_to_planes")(dfeatv.data_ptr(), B, FINAL_FILTERS, h, w, k, b["dvf"].data_ptr(), st), "feat_to_planes")
         dprev = b["dprev_f"]
         self._sep_backward("sep_f", self.final_in, 0, c, FINAL_FILTERS, h, w, b["dvf"], b["u_f"], b["du_f"], dprev)
@@ -818,14 +838,22 @@ class TrunkTrainer:
             # through the ReLU in front of sep_a (folded into the input-gradient pass of sep_a where its kernel has the epilogue), then add the
             # residual branch (scatter-add to the even pixels).  For block 1, x_in = relu(bn0(v0)): its ReLU mask is the one the bn0 backward
             # applies anyway (mask * mask = mask)
+            wrt = self._w_pwT(f"b{i}/res/kernel", cprev, f)  # residual weights transposed [f][cprev]
+            self._resq = None
+            if i == 1 and self._conv0_dgrad_ok(x_in):
+                # the residual branch's gradient w.r.t. y0 lives on the even pixels only: one plain pointwise pass at the pooled resolution, added inside
+                # the marching pass below (where bn0's sums are taken over the TOTAL gradient) instead of scatter-added to dr afterwards
+                self._resq = b["rq1"]
+                self._sep(dout, f, ho, wo, 1, 0, self._w_ones_dw(f), wrt, self._zeros(64), cprev, self._resq)
             relu_done = self._bn_sep_backward(dya, b[f"va{i}"], f"b{i}/bn_a", 1, f"b{i}/sep_a", x_in, 1, cprev, f, h, w, b[f"u_a{i}"], b[f"du_a{i}"], dr,
                                               sums_ready=1 if sums_a else 0, epi=("relu", x_in) if i > 1 else None)
             if i > 1 and not relu_done:
                 N.check(self._fn("planes_relu_bwd")(dr.data_ptr(), x_in.data_ptr(), dr.numel(), dr.data_ptr(), st), "planes_relu_bwd")
             if self.block_masks is not None and i > 1:  # x_in = Dropout(prev_{i-1}): back to the un-dropped tensor before the residual gradient joins
                 N.check(lib.orcai_mask_scale(dr.data_ptr(), self.block_masks[i - 2].data_ptr(), 1.0 / (1.0 - self.block_rate), dr.numel(), dr.data_ptr(), st), "mask_scale")
-            wrt = self._w_pwT(f"b{i}/res/kernel", cprev, f)  # residual weights transposed [f][cprev]
-            self._sep(dout, f, ho, wo, 1, 0, self._w_ones_dw(f), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
+            if not (i == 1 and self._resq is not None and self.bn0_sums_ready):  # (block 1 with the residual gradient already inside dr)
+                self._sep(dout, f, ho, wo, 1, 0, self._w_ones_dw(f), wrt, self._zeros(64), cprev, dr, layout=3, H2=h, W2=w)
+            self._resq = None
             dprev = dr
         H, W = m.input_hw
         mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
@@ -834,7 +862,7 @@ class TrunkTrainer:
                                              P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
                                              P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
         else:
-            N.check(lib.orcai_conv0_bn_bwd_x(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), B, H, W, k, P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(),
+            N.check((lib.orcai_conv0_bn_bwd_x_ready if self.bn0_sums_ready else lib.orcai_conv0_bn_bwd_x)(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), B, H, W, k, P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(),
                                              mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(),
                                              P.G("bn0/beta").data_ptr(), P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), self.partials.data_ptr(), self.partials.numel(),
                                              st), "conv0_bn_bwd_x")

@@ -466,3 +466,63 @@ def test_depthwise_backward_in_one_marching_pass(C, H, W, B, mode):
         s = shards.cpu().numpy()
         tol_s = 3e-6 * np.sqrt(n) * max(1.0, np.abs(dy).max() * 3)
         assert np.abs(s[:C] - db_ref).max() <= tol_s and np.abs(s[4 * CQ : 4 * CQ + C] - dg_ref).max() <= tol_s, (np.abs(s[:C] - db_ref).max(), np.abs(s[4 * CQ : 4 * CQ + C] - dg_ref).max(), tol_s)
+
+
+@pytest.mark.parametrize("H,W,B,res", [(37, 171, 2, True), (40, 171, 1, False), (16, 12, 5, True), (9, 33, 3, True), (25, 86, 2, True), (7, 1, 2, True)])
+def test_depthwise_backward_rebuilds_the_entry_activation(H, W, B, res):
+    """orcai_dw_bwd_fused_conv0 (block 1's first separable conv: y0 = relu(bn0(conv0(snippet))) rebuilt from the snippet's nine taps instead of read,
+    the residual branch's even-pixel gradient added in the pass, bn0's backward sums over the TOTAL gradient in the epilogue) against the
+    materialised path -- orcai_conv0_affine_bn for y0, orcai_dw_bwd_fused on it, the residual gradient added at the even pixels -- and float64:
+    input gradient (the same nine products + one addend), depthwise weight gradient, sums dbeta | dgamma as orcai_conv0_bn_bwd_x's first pass
+    defines them (gate and xhat from the recomputed pre-normalisation value)."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    rng = np.random.default_rng(H * 5 + W)
+    k = 3
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)  # noqa: E731
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    xin = rng.random((B, H, W), dtype=np.float32)
+    w0, bias = (f(9, 16) / 3).astype(np.float32), (0.1 * f(16)).astype(np.float32)
+    mean, var = (0.2 * f(16)).astype(np.float32), (0.3 + rng.random(16)).astype(np.float32)
+    gamma, beta = (1 + 0.3 * f(16)).astype(np.float32), (0.2 * f(16)).astype(np.float32)
+    du = f(B, 16, H, W)
+    taps = f(9, 16)
+    rev = np.ascontiguousarray(taps[::-1].T.reshape(4, 4, 9).transpose(0, 2, 1))  # [CQ][9][4] reversed taps
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    rq = f(B, 16, Ho, Wo)
+    xd, w0d, bd, md, vd, gd, btd, dud, revd = dev(xin), dev(w0), dev(bias), dev(mean), dev(var), dev(gamma), dev(beta), dev(_quad_planes(du, k)), dev(rev)
+    rqd = dev(_quad_planes(rq, k)) if res else None
+    ones = torch.ones(16, device="cuda")
+    st = N.stream_ptr()
+    # the materialised path
+    y0 = torch.zeros_like(dud)
+    N.check(lib.orcai_conv0_affine_bn(N.ptr(xd), H * W, B, H, W, k, N.ptr(w0d), N.ptr(ones), N.ptr(bd), N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(btd), 1e-3, 1, N.ptr(y0), st), "conv0_affine_bn")
+    dr_ref, dW_ref = torch.zeros_like(dud), torch.zeros((9, 16), device="cuda")
+    N.check(lib.orcai_dw_bwd_fused(N.ptr(y0), N.ptr(dud), B, 16, H, W, 1, N.ptr(revd), N.ptr(dr_ref), N.ptr(dW_ref), 0, None, None, None, None, 0.0, 0, None, st), "dw_bwd_fused")
+    dr_ref = _from_quad(dr_ref.cpu().numpy(), 16, H, W, k).astype(np.float64)
+    if res:
+        dr_ref[:, :, ::2, ::2] += rq.astype(np.float64)
+    # one pass from the snippet
+    dr, dW = torch.zeros_like(dud), torch.zeros((9, 16), device="cuda")
+    shards = torch.full((8 * 16 * 32,), 7.0, dtype=torch.float64, device="cuda")
+    N.check(lib.orcai_dw_bwd_fused_conv0(N.ptr(xd), H * W, N.ptr(dud), B, H, W, N.ptr(w0d), N.ptr(bd), N.ptr(revd), N.ptr(dr), N.ptr(dW), N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(btd), 1e-3,
+                                         N.ptr(shards), None if rqd is None else N.ptr(rqd), st), "dw_bwd_fused_conv0")
+    torch.cuda.synchronize()
+    got = _from_quad(dr.cpu().numpy(), 16, H, W, k).astype(np.float64)
+    assert np.abs(got - dr_ref).max() <= 2e-6 * max(1.0, np.abs(dr_ref).max())
+    pads = dr.cpu().numpy().copy()
+    pads[:, :, 1 : 1 + H, :W, :] = 0
+    assert float(np.abs(pads).max()) == 0.0
+    assert float((dW - dW_ref).abs().max()) <= 1e-4 * max(1.0, float(dW_ref.abs().max()))  # the same y0, another summation order
+    # bn0's backward sums over the total gradient (float64)
+    xp = np.zeros((B, H + 2, W + 2))
+    xp[:, 1:-1, 1:-1] = xin
+    v0 = sum(w0[dy * 3 + dx].astype(np.float64)[None, :, None, None] * xp[:, None, dy : dy + H, dx : dx + W] for dy in range(3) for dx in range(3)) + bias[None, :, None, None]
+    inv = 1.0 / np.sqrt(var.astype(np.float64) + 1e-3)
+    xh = (v0 - mean[None, :, None, None]) * inv[None, :, None, None]
+    g = np.where(xh * gamma[None, :, None, None] + beta[None, :, None, None] > 0, dr_ref, 0.0)
+    s = shards.cpu().numpy()
+    n = B * H * W
+    tol = 3e-6 * np.sqrt(n) * max(1.0, np.abs(dr_ref).max() * 3) + 2e-3  # + a gate decision or two within f32 rounding of zero
+    assert np.abs(s[:16] - g.sum(axis=(0, 2, 3))).max() <= tol and np.abs(s[16:32] - (g * xh).sum(axis=(0, 2, 3))).max() <= tol, (np.abs(s[:16] - g.sum(axis=(0, 2, 3))).max(), np.abs(s[16:32] - (g * xh).sum(axis=(0, 2, 3))).max(), tol)
