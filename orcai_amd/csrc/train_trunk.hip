@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
   auto iload = [&](int row) -> float {  // snippet pixel (row, xcol), zero outside the image ("same" padding); unconditional, clamped
     const int rr = row < 0 ? 0 : (row >= H ? H - 1 : row), cc = xcol < 0 ? 0 : (xcol >= W ? W - 1 : xcol);
     const float v = inb[(int64_t)rr * W + cc];
-    return (row >= 0 && row < H && xcol >= 0 && xcol < W) ? v : 0.0f;
+    // multiplied, not selected: a select lets the compiler predicate the LOAD (a branch in the steady state, and with it vmcnt(0) at every step)
+    return v * ((row >= 0 && row < H && xcol >= 0 && xcol < W) ? 1.0f : 0.0f);
   };
   auto iarrive = [&](float v, InRow& o) {
     o.c = v;
@@ -1165,7 +1166,12 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
       if (EPI == 3) a = xv[j] > 0.0f ? a : 0.0f;
       d[j] = a;
     }
-    if (live) op[(row + 1) * WP + xcol] = make_float4(d[0], d[1], d[2], d[3]);
+    if (C0) {  // unconditional store: a dead lane writes zeros to its pixel of the top pad row (zeros, never anything else), so the steady state has no branch
+      const int pc = xcol < 0 ? 0 : (xcol >= WP ? WP - 1 : xcol);
+      op[live ? (row + 1) * WP + xcol : pc] = make_float4(live ? d[0] : 0.f, live ? d[1] : 0.f, live ? d[2] : 0.f, live ? d[3] : 0.f);
+    } else if (live) {
+      op[(row + 1) * WP + xcol] = make_float4(d[0], d[1], d[2], d[3]);
+    }
   };
   if (C0) {
     if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
@@ -1180,15 +1186,16 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
       float pi0 = iload(r_begin + 1), pi1 = iload(r_begin + 2), pi2 = iload(r_begin + 3);
       // residual gradient of row r (compact planes at the pooled resolution): requested three steps ahead as well; every lane loads (its pixel's
       // pair partner the same 16 bytes), only even (row, column) keep the value
+      // (no branch anywhere in the steady state: without a residual gradient the loads read the du plane at the same small indices and are discarded --
+      // a wave-uniform branch around them makes the wait-count pass drain every request of the step at its join)
       const bool has_res = c0.resq != nullptr;
       const float4* rqp = has_res ? reinterpret_cast<const float4*>(c0.resq) + ((int64_t)b * CQ + cq) * ((int64_t)(c0.Ho + 2) * c0.WPo) : dp;
-      const bool col_even = xcol >= 0 && (xcol & 1) == 0;
+      const bool col_even = has_res && xcol >= 0 && (xcol & 1) == 0;
       const int jq = xcol < 0 ? 0 : (xcol >> 1);
+      const int jc = jq >= c0.WPo ? c0.WPo - 1 : jq;
       auto rload = [&](int row) -> float4 {
-        if (!has_res) return make_float4(0.f, 0.f, 0.f, 0.f);  // wave-uniform
         int iq = row >> 1;
         iq = iq < 0 ? 0 : (iq >= c0.Ho ? c0.Ho - 1 : iq);
-        const int jc = jq >= c0.WPo ? c0.WPo - 1 : jq;
         return rqp[(iq + 1) * c0.WPo + jc];
       };
       auto rkeep = [&](const float4& v, int row) { radd = (col_even && (row & 1) == 0) ? v : make_float4(0.f, 0.f, 0.f, 0.f); };
