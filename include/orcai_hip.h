@@ -432,6 +432,11 @@ int orcai_dw_bwd_fused_conv0(const float* in, int64_t snippet_stride, const floa
 int orcai_conv0_bn_bwd_x_ready(const float* in, int64_t snippet_stride, const float* dy, int B, int H, int W, int ksize, const float* w0, const float* bias, const float* mean,
                                const float* var, const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, float* workspace,
                                int64_t workspace_floats, void* stream);
+/* The entry conv's two reduction passes on a marching kernel (k = 3; csrc/train_trunk.hip conv0_march_kernel): orcai_conv0_stats_march is
+ * orcai_conv0_stats (shards: [32][4][8] sums | sums of squares for orcai_bn_finish_sharded) without tiles, LDS or barriers; orcai_conv0_march(1)
+ * (default) lets orcai_conv0_bn_bwd_x_ready run its weight-gradient pass the same way (0: the tile kernel; < 0 queries; returns the previous value). */
+int orcai_conv0_stats_march(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w, const float* scale, const float* shift, double* shards, void* stream);
+int orcai_conv0_march(int on);
 /* dW0[tap][c] += sum in[p + off(tap)] * dv[c][p]  (entry conv weight gradient; `in` is the unpadded snippet view) */
 int orcai_conv0_wgrad(const float* in, int64_t snippet_stride, const float* dv, int B, int H, int W, int ksize, float* dW, void* stream);
 /* Keras-Reshape layout f32[B][H][W*C] -> padded channel-quad planes (gradient entering the final separable conv) */

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "orcai_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dw_bwd_fused_conv0": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 9 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_conv0_bn_bwd_x_ready": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 5 + [c_i64, C.c_void_p]),
+    "orcai_conv0_stats_march": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_int] * 3 + [C.c_void_p] * 5),
+    "orcai_conv0_march": (C.c_int, [C.c_int]),
     "orcai_h_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dw_wgrad_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_stats_bn": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),

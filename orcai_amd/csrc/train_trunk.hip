@@ -1252,6 +1252,130 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------- the entry conv's two reduction passes, marching (k = 3)
+// conv0_stats_kernel / conv0_bn_bwd_x_kernel<.., true> work on 8 x 32-pixel tiles with the input halo staged in LDS: two barriers, ~40
+// instructions of tile arithmetic and an LDS round trip per 256 pixels, for a conv of 144 multiply-adds per pixel -- they run at 4 x the time their
+// arithmetic needs (0.17 and 0.23 ms per step).  The marching form of dw_bwd_march_kernel<.., C0> has neither: a wave owns a 62-column strip of
+// one channel quad, the three snippet rows rotate through registers (each value loaded once, 4 bytes per lane), the taps are scalars, partial sums
+// live in registers over a segment of rows and are reduced once per workgroup.
+//   MODE 0: batch statistics of v0 = fma(conv, scale, shift) -> shards [32][4][8] (sum | sum of squares per quad), as conv0_stats_kernel
+//   MODE 1: entry conv weight gradient with bn0's backward applied on the fly (conv0_bn_bwd_x_kernel<3, true>): dW0[tap][c] += in_tap * dv0[c]
+template <int MODE>
+__global__ __launch_bounds__(256) void conv0_march_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP, const float* __restrict__ w0 /*[9][16]*/,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, double* __restrict__ shards,
+                                                           const float* __restrict__ dy /*MODE 1: [B][4][H + 2][WP][4]*/, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           const double* __restrict__ dbeta, const double* __restrict__ dgamma, float inv_count,
+                                                           float* __restrict__ dW /*MODE 1: [9][16]*/, int nstrip, int nseg, int rps) {
+  constexpr int KK = 9;
+  const int lane = threadIdx.x & 63;
+  const int cq = blockIdx.y, b = blockIdx.z;
+  const int plane = (H + 2) * WP;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool has_task = task < nstrip * nseg;
+  const int strip = has_task ? task % nstrip : 0, seg = has_task ? task / nstrip : 0;
+  const int xcol = strip * 62 - 1 + lane;
+  const bool out_lane = has_task && lane >= 1 && lane <= 62 && xcol < W;
+  const int r_begin = seg * rps, r_end = min(r_begin + rps, H);
+  const float* inb = in + (int64_t)b * snippet_stride;
+  const float4* dp = MODE == 1 ? reinterpret_cast<const float4*>(dy) + ((int64_t)b * 4 + cq) * plane : nullptr;
+  float wq[KK][4], sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cq * 4 + j;
+    sc[j] = MODE == 1 ? 1.0f : scale[c];  // MODE 1: conv0_bn_bwd_x_kernel's fma(cv, 1, bias)
+    sh[j] = shift[c];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) wq[t][j] = w0[t * 16 + c];
+  }
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, bt[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f},
+        c2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 1) {
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cq * 4 + j;
+      mu[j] = mean[c]; inv[j] = uni(rsqrtf(var[c] + eps)); g[j] = gamma[c]; bt[j] = beta[c];
+      c1[j] = uni((float)dbeta[c] * inv_count);
+      c2[j] = uni((float)dgamma[c] * inv_count);
+    }
+  }
+  constexpr int NACC = MODE == 1 ? 4 * KK : 8;
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+  struct InRow { float c, l, r; };
+  auto iload = [&](int row) -> float {  // zero outside the image; multiplied, not selected, so that the load itself stays unconditional
+    const int rr = row < 0 ? 0 : (row >= H ? H - 1 : row), cc = xcol < 0 ? 0 : (xcol >= W ? W - 1 : xcol);
+    return inb[(int64_t)rr * W + cc] * ((row >= 0 && row < H && xcol >= 0 && xcol < W) ? 1.0f : 0.0f);
+  };
+  auto dload = [&](int row) -> float4 {
+    if (MODE != 1) return make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = (row + 1) * WP + xcol;
+    i = i < 0 ? 0 : (i >= plane ? plane - 1 : i);
+    return dp[i];
+  };
+  auto iarrive = [&](float v, InRow& o) {
+    o.c = v;
+    o.l = lsh<3, -1>(v);
+    o.r = lsh<3, 1>(v);
+  };
+  auto step = [&](const InRow& up, const InRow& mid, const InRow& dn, const float4& d4, int row) {
+    const bool live = out_lane && row < r_end;
+    const float a[KK] = {up.l, up.c, up.r, mid.l, mid.c, mid.r, dn.l, dn.c, dn.r};
+    const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float cv = 0.0f;
+#pragma unroll
+      for (int t = 0; t < KK; ++t) cv = fmaf(a[t], wq[t][j], cv);  // conv0_kernel's chain, taps in (dy, dx) order
+      const float v = fmaf(cv, sc[j], sh[j]);
+      if (MODE == 0) {
+        const float lv = live ? v : 0.0f;
+        acc[j] += lv;
+        acc[4 + j] = fmaf(lv, lv, acc[4 + j]);
+      } else {
+        const float xh = (v - mu[j]) * inv[j];
+        const float de = (live && fmaf(xh, g[j], bt[j]) > 0.0f) ? dd[j] : 0.0f;  // bn0 is followed by a ReLU
+        const float gq = live ? g[j] * inv[j] * (de - c1[j] - xh * c2[j]) : 0.0f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc[j * KK + t] = fmaf(a[t], gq, acc[j * KK + t]);
+      }
+    }
+  };
+  if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+    InRow IA, IB, IC;
+    iarrive(iload(r_begin - 1), IA);
+    iarrive(iload(r_begin), IB);
+    float pi0 = iload(r_begin + 1), pi1 = iload(r_begin + 2), pi2 = iload(r_begin + 3);
+    float4 pd0 = dload(r_begin), pd1 = dload(r_begin + 1), pd2 = dload(r_begin + 2);
+    for (int i = 0; i < rps; i += 3) {
+      const int r = r_begin + i;
+      { const float ir = pi0; const float4 dr_ = pd0; pi0 = iload(r + 4); pd0 = dload(r + 3); iarrive(ir, IC); step(IA, IB, IC, dr_, r); }
+      { const float ir = pi1; const float4 dr_ = pd1; pi1 = iload(r + 5); pd1 = dload(r + 4); iarrive(ir, IA); step(IB, IC, IA, dr_, r + 1); }
+      { const float ir = pi2; const float4 dr_ = pd2; pi2 = iload(r + 6); pd2 = dload(r + 5); iarrive(ir, IB); step(IC, IA, IB, dr_, r + 2); }
+    }
+  }
+  __shared__ float red[4][NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (MODE == 0) {
+      atomicAdd(&shards[((int64_t)((blockIdx.x + 7 * b + 3 * cq) & 31) * 4 + cq) * 8 + threadIdx.x], (double)tot);  // [sum 4 | sum of squares 4]
+    } else {
+      const int j = threadIdx.x / KK, t = threadIdx.x - j * KK;
+      atomicAdd(&dW[t * 16 + cq * 4 + j], tot);
+    }
+  }
+}
+
 // the 32 accumulator copies [32][CQ][8] -> scratch2C = dbeta[4 CQ] | dgamma[4 CQ] (doubles), in place by one workgroup (all reads before the first write)
 __global__ __launch_bounds__(256) void bwd_sums_compact_kernel(double* __restrict__ shards, int CQ) {
   const int t = threadIdx.x;
@@ -1951,6 +2075,40 @@ int orcai_dw_bwd_fused(const float* x, const float* du, int B, int C, int H, int
   return (int)hipGetLastError();
 }
 
+static int g_conv0_march = 1;  // k = 3: the entry conv's statistics pass and the second pass of its backward on conv0_march_kernel (orcai_conv0_march: A/B)
+
+int orcai_conv0_march(int on) {
+  const int prev = g_conv0_march;
+  if (on >= 0) g_conv0_march = on ? 1 : 0;
+  return prev;
+}
+
+static void conv0_march_geometry(int B, int H, int W, int& nstrip, int& nseg, int& rps) {
+  nstrip = (W + 61) / 62;
+  const int64_t per_seg = (int64_t)B * 4 * nstrip;
+  nseg = (int)((16384 + per_seg - 1) / per_seg);
+  if (nseg < 1) nseg = 1;
+  if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;
+  rps = (H + nseg - 1) / nseg;
+  rps = (rps + 2) / 3 * 3;
+  nseg = (H + rps - 1) / rps;
+}
+
+int orcai_conv0_stats_march(const float* in, int64_t snippet_stride, int B, int H, int W, const float* w, const float* scale, const float* shift, double* shards, void* stream) {
+  if (!in || !w || !scale || !shift || !shards || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  if (B > 65535 || (int64_t)H * W >= (1ll << 30)) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = orcai_zero::zero_async(shards, sizeof(double) * 8 * 4 * 32, st);
+  if (e != hipSuccess) return (int)e;
+  int nstrip, nseg, rps;
+  conv0_march_geometry(B, H, W, nstrip, nseg, rps);
+  dim3 grid((nstrip * nseg + 3) / 4, 4, B);
+  hipLaunchKernelGGL((conv0_march_kernel<0>), grid, dim3(256), 0, st, in, snippet_stride, H, W, orcai_padded_width(W, 3), w, scale, shift, shards, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, (const double*)nullptr, (const double*)nullptr, 0.0f,
+                     (float*)nullptr, nstrip, nseg, rps);
+  return (int)hipGetLastError();
+}
+
 int orcai_dw_bwd_fused_conv0(const float* in, int64_t snippet_stride, const float* du, int B, int H, int W, const float* w0, const float* bias0, const float* dw_rev, float* dr,
                              float* dW, const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, double* shards, const float* resq,
                              void* stream) {
@@ -1995,6 +2153,15 @@ int orcai_conv0_bn_bwd_x_ready(const float* in, int64_t snippet_stride, const fl
   double* db = scratch2C;
   double* dg = scratch2C + 16;
   const float inv_count = (float)(1.0 / ((double)B * H * W));
+  if (ksize == 3 && g_conv0_march && B <= 65535) {  // marching second pass: no tiles, no LDS, weight gradient straight into dW (36 atomics per workgroup)
+    int nstrip, nseg, rps;
+    conv0_march_geometry(B, H, W, nstrip, nseg, rps);
+    dim3 gm((nstrip * nseg + 3) / 4, 4, B);
+    hipLaunchKernelGGL((conv0_march_kernel<1>), gm, dim3(256), 0, st, in, snippet_stride, H, W, WP, w0, (const float*)nullptr, bias, (double*)nullptr, dy, mean, var, gamma, beta, eps,
+                       (const double*)db, (const double*)dg, inv_count, dW, nstrip, nseg, rps);
+    hipLaunchKernelGGL(f64_to_f32_pair_kernel, dim3(1), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
+    return (int)hipGetLastError();
+  }
   dim3 grid(gx, 4);
 #define ORCAI_C0XR(KS_)                                                                                                                                    \
   hipLaunchKernelGGL((conv0_bn_bwd_x_kernel<KS_, true>), grid, dim3(256), 0, st, in, snippet_stride, dy, H, W, WP, B, w0, bias, mean, var, gamma, beta, eps,  \

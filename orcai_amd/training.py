@@ -389,6 +389,7 @@ class TrunkTrainer:
         self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
+        self.conv0_march = True  # entry conv statistics on the marching kernel (A/B: tools/ab_flags.py; its backward twin: orcai_conv0_march)
         self.conv0_in_dgrad = True  # block 1's first conv: y0 rebuilt from the snippet inside the marching depthwise backward, bn0's sums in its epilogue (A/B: tools/ab_flags.py)
         self.bn0_sums_ready = False
         self._resq = None
@@ -597,7 +598,10 @@ class TrunkTrainer:
             # is never written (the backward pass rebuilds it from the input taps: orcai_conv0_bn_bwd_x)
             w0, b0, ones = P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(), self._ones(16).data_ptr()
             mean0, var0 = P.B("bn0/mean"), P.B("bn0/var")
-            N.check(lib.orcai_conv0_stats(src.data_ptr(), snippet_stride, B, H, W, k, w0, ones, b0, self.scratch.data_ptr(), st), "conv0_stats")
+            if self.conv0_march and k == 3:  # the marching form: no tiles, LDS or barriers (csrc/train_trunk.hip conv0_march_kernel)
+                N.check(lib.orcai_conv0_stats_march(src.data_ptr(), snippet_stride, B, H, W, w0, ones, b0, self.scratch.data_ptr(), st), "conv0_stats_march")
+            else:
+                N.check(lib.orcai_conv0_stats(src.data_ptr(), snippet_stride, B, H, W, k, w0, ones, b0, self.scratch.data_ptr(), st), "conv0_stats")
             N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), B, 16, H, W, mean0.data_ptr(), var0.data_ptr(), st), "bn_finish_sharded")
             self.stats["bn0"] = (mean0, var0)
             N.check(lib.orcai_conv0_affine_bn(src.data_ptr(), snippet_stride, B, H, W, k, w0, ones, b0, mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(),

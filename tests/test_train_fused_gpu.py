@@ -274,6 +274,30 @@ def test_entry_conv_in_two_passes_without_v0(H, W, B, k):
         out[recompute] = [t.cpu().numpy() for t in (dbeta, dgamma, dW)]
     for a, b_, name in zip(out[True], out[False], ("dbeta", "dgamma", "dW")):
         assert np.abs(a - b_).max() <= 2e-5 * max(1.0, np.abs(b_).max()), (name, np.abs(a - b_).max())
+    if k == 3:
+        # the marching forms (csrc/train_trunk.hip conv0_march_kernel): statistics pass, and the weight-gradient pass behind sums that are already in
+        # the scratch (orcai_conv0_bn_bwd_x left dbeta[16] | dgamma[16] doubles there) -- against the tile kernels
+        sc2 = torch.zeros(8 * 16 * 32, dtype=torch.float64, device="cuda")
+        mean_c, var_c = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda")
+        N.check(lib.orcai_conv0_stats_march(N.ptr(x), H * W, B, H, W, N.ptr(w0), N.ptr(ones), N.ptr(bias), N.ptr(sc2), st), "conv0_stats_march")
+        N.check(lib.orcai_bn_finish_sharded(N.ptr(sc2), B, 16, H, W, N.ptr(mean_c), N.ptr(var_c), st), "finish")
+        assert float((mean_c - mean_b).abs().max()) <= 2e-6 * max(1.0, float(mean_b.abs().max())) and float((var_c - var_b).abs().max()) <= 1e-5 * float(var_b.abs().max())
+        sums = scratch[:32].clone()
+        ws = torch.empty(512 * 64 * 64, device="cuda")
+        prev = lib.orcai_conv0_march(-1)
+        try:
+            for march in (0, 1):
+                lib.orcai_conv0_march(march)
+                sc3 = torch.zeros_like(scratch)
+                sc3[:32] = sums
+                dbeta, dgamma, dW = torch.zeros(16, device="cuda"), torch.zeros(16, device="cuda"), torch.zeros((9, 16), device="cuda")
+                N.check(lib.orcai_conv0_bn_bwd_x_ready(N.ptr(x), H * W, N.ptr(dy), B, H, W, k, N.ptr(w0), N.ptr(bias), N.ptr(mean_a), N.ptr(var_a), N.ptr(gamma), N.ptr(beta), 1e-3,
+                                                       N.ptr(sc3), N.ptr(dbeta), N.ptr(dgamma), N.ptr(dW), N.ptr(ws), ws.numel(), st), "conv0_bn_bwd_x_ready")
+                torch.cuda.synchronize()
+                for a, b_, name in zip((dbeta, dgamma, dW), out[True], ("dbeta", "dgamma", "dW")):
+                    assert np.abs(a.cpu().numpy() - b_).max() <= 2e-5 * max(1.0, np.abs(b_).max()), (march, name, np.abs(a.cpu().numpy() - b_).max())
+        finally:
+            lib.orcai_conv0_march(prev)
 
 
 @pytest.mark.parametrize("U,B,T", [(128, 20, 46), (64, 7, 12)])
