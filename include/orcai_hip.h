@@ -536,6 +536,14 @@ int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, 
  * ceil(C/8) * 32 doubles; epi 2 leaves dbeta[8 CO] | dgamma[8 CO] there for orcai_h_bn_bwd_pointwise(sums_ready = 1). */
 int orcai_h_dw_bwd_fused(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
                          const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream);
+/* orcai_h_dw_bwd_fused(epi 2) with a gradient that lives on the even pixels only added inside the pass (resq: f16 planes of C channels at the pooled
+ * resolution [B][ceil(C/8)][ceil(H/2) + 2][padded_width(ceil(W/2))][8]): for block 1's first conv with x = the entry conv's stored v0 the sums left in
+ * `shards` are bn0's backward sums over the TOTAL gradient (orcai_h_conv0_bn_bwd_ready = orcai_h_conv0_bn_bwd without its own sums pass), and the
+ * residual branch needs no scatter-add pass over dr. */
+int orcai_h_dw_bwd_fused_res(const void* x, const void* du, int B, int C, int H, int W, const void* dw_rev, void* dr, float* dW, const float* bn_mean, const float* bn_var,
+                             const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, const void* resq, void* stream);
+int orcai_h_conv0_bn_bwd_ready(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream);
 int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
                          const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream);
 int orcai_h_pack_weights(const float* w, const int* desc, int n_desc, void* out, void* stream);

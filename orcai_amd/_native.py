@@ -90,6 +90,8 @@ _SIGNATURES = {
     "orcai_conv0_stats_march": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_int] * 3 + [C.c_void_p] * 5),
     "orcai_conv0_march": (C.c_int, [C.c_int]),
     "orcai_h_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "orcai_h_dw_bwd_fused_res": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_h_conv0_bn_bwd_ready": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 5),
     "orcai_dw_wgrad_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_sepconv_planes_stats_bn": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_sepconv_planes_epi": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),

@@ -663,11 +663,14 @@ __device__ __forceinline__ void mixacc(int hi, float& acc, uint32_t d, float y) 
   else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(d), "v"(y));
 }
 
-template <int SW, int EPI, bool BNIN>
+// RES: a gradient that lives on the even pixels only (the block's strided 1x1 residual branch, as compact planes [B][CO][Ho + 2][WPo][8] at the
+// pooled resolution) is added to dr inside the pass, before the sums and the store -- instead of a scatter-add pass over dr afterwards, which for
+// block 1 would also come too late for bn0's sums (EPI 2 with x = the entry conv's stored v0).
+template <int SW, int EPI, bool BNIN, bool RES = false>
 __global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restrict__ x, const h16* __restrict__ du, int C, int H, int W, int WP, int relu_in,
                                                               const h16* __restrict__ wrev /*[CO][9][8] reversed taps*/, h16* __restrict__ dr,
                                                               float* __restrict__ dW /*[9][C]*/, double* __restrict__ shards /*EPI 2: [32][CO][16]*/, int nstrip,
-                                                              int nseg, int rps, InBnH ib, int epi_relu) {
+                                                              int nseg, int rps, InBnH ib, int epi_relu, const h16* __restrict__ resq = nullptr, int Ho = 0, int WPo = 0) {
   static_assert(SW == 64 || SW == 32 || SW == 16, "strip lanes");
   static_assert(EPI == 0 || EPI == 2 || EPI == 3, "epilogue extras");
   static_assert(EPI != 2 || BNIN, "EPI 2: x is the pre-normalisation tensor of the BatchNorm whose backward sums are taken");
@@ -722,6 +725,7 @@ __global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restri
     o.l = lane_shift_h<-1>(raw);
     o.r = lane_shift_h<1>(raw);
   };
+  h16x8 radd = zero_h();  // RES: the even-pixel gradient at this lane's pixel for the current step (zero off the even pixels)
   auto step = [&](const Row& up, const Row& mid, const Row& dn, const h16x8& x8, int row) {
     const bool live = out_lane && row < r_end;
     // input gradient: nine packed products per dword, f16 (the arithmetic class of dw_octet)
@@ -729,6 +733,7 @@ __global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restri
     a = up.c * wt[1] + a; a = up.r * wt[2] + a;
     a = mid.l * wt[3] + a; a = mid.c * wt[4] + a; a = mid.r * wt[5] + a;
     a = dn.l * wt[6] + a; a = dn.c * wt[7] + a; a = dn.r * wt[8] + a;
+    if (RES) a = a + radd;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xv = (float)x8[j];
@@ -753,7 +758,30 @@ __global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restri
     }
     if (live) op[(row + 1) * WP + xcol] = a;
   };
-  if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+  if (RES) {
+    if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
+      Row A, Bq, Cq;
+      arrive(dp[pix(r_begin - 1)], A);
+      arrive(dp[pix(r_begin)], Bq);
+      h16x8 pg0 = dp[pix(r_begin + 1)], px0 = xp[pix(r_begin)], pg1 = dp[pix(r_begin + 2)], px1 = xp[pix(r_begin + 1)], pg2 = dp[pix(r_begin + 3)], px2 = xp[pix(r_begin + 2)];
+      const h16x8* rqp = reinterpret_cast<const h16x8*>(resq) + ((int64_t)b * CO + co) * ((int64_t)(Ho + 2) * WPo);
+      const bool col_even = xcol >= 0 && (xcol & 1) == 0;
+      const int jq = xcol < 0 ? 0 : (xcol >> 1), jc = jq >= WPo ? WPo - 1 : jq;
+      auto rload = [&](int row) -> h16x8 {  // every lane loads (pair partners the same 16 bytes); only even (row, column) keep the value
+        int iq = row >> 1;
+        iq = iq < 0 ? 0 : (iq >= Ho ? Ho - 1 : iq);
+        return rqp[(iq + 1) * WPo + jc];
+      };
+      auto rkeep = [&](const h16x8& v, int row) { radd = (col_even && (row & 1) == 0) ? v : zero_h(); };
+      h16x8 pr0 = rload(r_begin), pr1 = rload(r_begin + 1), pr2 = rload(r_begin + 2);
+      for (int i = 0; i < rps; i += 3) {
+        const int r = r_begin + i;
+        { const h16x8 gr = pg0, xr = px0, rr = pr0; pg0 = dp[pix(r + 4)]; px0 = xp[pix(r + 3)]; pr0 = rload(r + 3); arrive(gr, Cq); rkeep(rr, r); step(A, Bq, Cq, xr, r); }
+        { const h16x8 gr = pg1, xr = px1, rr = pr1; pg1 = dp[pix(r + 5)]; px1 = xp[pix(r + 4)]; pr1 = rload(r + 4); arrive(gr, A); rkeep(rr, r + 1); step(Bq, Cq, A, xr, r + 1); }
+        { const h16x8 gr = pg2, xr = px2, rr = pr2; pg2 = dp[pix(r + 6)]; px2 = xp[pix(r + 5)]; pr2 = rload(r + 5); arrive(gr, Bq); rkeep(rr, r + 2); step(Cq, A, Bq, xr, r + 2); }
+      }
+    }
+  } else if (__builtin_amdgcn_ballot_w64(has_task) != 0) {  // wave-uniform
     Row A, Bq, Cq;
     arrive(dp[pix(r_begin - 1)], A);
     arrive(dp[pix(r_begin)], Bq);
@@ -811,7 +839,7 @@ __global__ __launch_bounds__(256) void bwd_sums_compact_h_kernel(double* __restr
 
 template <int SW>
 int launch_dw_bwd_h(hipStream_t st, const h16* x, const h16* du, int B, int C, int H, int W, int WP, int relu_in, const h16* wrev, h16* dr, float* dW, int epi,
-                    const InBnH& ib, int epi_relu, double* shards, int nstrip) {
+                    const InBnH& ib, int epi_relu, double* shards, int nstrip, const h16* resq = nullptr) {
   constexpr int NSUB = 64 / SW;
   const int CO = (C + 7) / 8;
   const int64_t per_seg = (int64_t)B * CO * nstrip;
@@ -823,10 +851,13 @@ int launch_dw_bwd_h(hipStream_t st, const h16* x, const h16* du, int B, int C, i
   nseg = (H + rps - 1) / rps;
   const int waves = (nstrip * nseg + NSUB - 1) / NSUB;
   dim3 grid((waves + 3) / 4, CO, B);
-  if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu);
-  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
-  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
-  else hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0);
+  const int Ho = (H + 1) / 2, WPo = orcai_padded_width((W + 1) / 2, 3);
+  if (epi == 2 && resq)
+    hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 2, true, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu, resq, Ho, WPo);
+  else if (epi == 2) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 2, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, epi_relu, (const h16*)nullptr, 0, 0);
+  else if (epi == 3) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 3, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, (const h16*)nullptr, 0, 0);
+  else if (ib.mean) hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, true>), grid, dim3(256), 0, st, x, du, C, H, W, WP, 0, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, (const h16*)nullptr, 0, 0);
+  else hipLaunchKernelGGL((dw_bwd_march_h_kernel<SW, 0, false>), grid, dim3(256), 0, st, x, du, C, H, W, WP, relu_in, wrev, dr, dW, shards, nstrip, nseg, rps, ib, 0, (const h16*)nullptr, 0, 0);
   return (int)hipGetLastError();
 }
 
@@ -1120,8 +1151,22 @@ int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, 
   return (int)hipGetLastError();
 }
 
+static int h_dw_bwd_fused_impl(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
+                               const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, const void* resq, void* stream);
+
 int orcai_h_dw_bwd_fused(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
                          const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, void* stream) {
+  return h_dw_bwd_fused_impl(x, du, B, C, H, W, relu_in, dw_rev, dr, dW, epi, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, bn_relu, shards, nullptr, stream);
+}
+
+int orcai_h_dw_bwd_fused_res(const void* x, const void* du, int B, int C, int H, int W, const void* dw_rev, void* dr, float* dW, const float* bn_mean, const float* bn_var,
+                             const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, const void* resq, void* stream) {
+  if (!resq || ((uintptr_t)resq & 15)) return ORCAI_E_BADARG;
+  return h_dw_bwd_fused_impl(x, du, B, C, H, W, 0, dw_rev, dr, dW, 2, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, bn_relu, shards, resq, stream);
+}
+
+static int h_dw_bwd_fused_impl(const void* x, const void* du, int B, int C, int H, int W, int relu_in, const void* dw_rev, void* dr, float* dW, int epi, const float* bn_mean,
+                               const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, int bn_relu, double* shards, const void* resq, void* stream) {
   if (!x || !du || !dw_rev || !dr || !dW || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (epi != 0 && epi != 2 && epi != 3)) return ORCAI_E_BADARG;
   const bool bn = bn_mean != nullptr;
   if (bn && (!bn_var || !bn_gamma || !bn_beta)) return ORCAI_E_BADARG;
@@ -1141,29 +1186,44 @@ int orcai_h_dw_bwd_fused(const void* x, const void* du, int B, int C, int H, int
   if (((W + 13) / 14) * 16 < best_lanes) { best = 16; best_lanes = ((W + 13) / 14) * 16; }
   const h16 *xh = (const h16*)x, *dh = (const h16*)du, *wh = (const h16*)dw_rev;
   int rc;
-  if (best == 64) rc = launch_dw_bwd_h<64>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 61) / 62);
-  else if (best == 32) rc = launch_dw_bwd_h<32>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 29) / 30);
-  else rc = launch_dw_bwd_h<16>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 13) / 14);
+  if (best == 64) rc = launch_dw_bwd_h<64>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 61) / 62, (const h16*)resq);
+  else if (best == 32) rc = launch_dw_bwd_h<32>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 29) / 30, (const h16*)resq);
+  else rc = launch_dw_bwd_h<16>(st, xh, dh, B, C, H, W, WP, relu_in, wh, (h16*)dr, dW, epi, ib, bn_relu, shards, (W + 13) / 14, (const h16*)resq);
   if (rc != 0) return rc;
   if (epi == 2) hipLaunchKernelGGL(bwd_sums_compact_h_kernel, dim3(1), dim3(256), 0, st, shards, CO);
   return (int)hipGetLastError();
 }
 
+static int h_conv0_bn_bwd_impl(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, int sums_ready, void* stream);
+
 int orcai_h_conv0_bn_bwd(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
                          const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream) {
+  return h_conv0_bn_bwd_impl(in, snippet_stride, dy, v, B, H, W, ksize, mean, var, gamma, beta, eps, scratch2C, dbeta, dgamma, dW, 0, stream);
+}
+
+int orcai_h_conv0_bn_bwd_ready(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, void* stream) {
+  return h_conv0_bn_bwd_impl(in, snippet_stride, dy, v, B, H, W, ksize, mean, var, gamma, beta, eps, scratch2C, dbeta, dgamma, dW, 1, stream);
+}
+
+static int h_conv0_bn_bwd_impl(const float* in, int64_t snippet_stride, const void* dy, const void* v, int B, int H, int W, int ksize, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float eps, double* scratch2C, float* dbeta, float* dgamma, float* dW, int sums_ready, void* stream) {
   if (!in || !dy || !v || !dW || !scratch2C || !dbeta || !dgamma || B <= 0) return ORCAI_E_BADARG;
   if ((int64_t)H * W >= (1ll << 30)) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int C = 16, CO = 2, R = ksize / 2, WP = orcai_padded_width(W, ksize);
   const int64_t plane = (int64_t)(H + 2 * R) * WP;
   if (plane >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
-  hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
-  if (e != hipSuccess) return (int)e;
-  int gx = (int)((B * plane + 255) / 256);
-  if (gx > 128) gx = 128;
   double* db = scratch2C;
   double* dg = scratch2C + 8 * CO;
-  hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, 1, db, dg);
+  if (!sums_ready) {  // sums_ready: bn0's backward sums dbeta[16] | dgamma[16] are in scratch2C already (orcai_h_dw_bwd_fused_res with x = v0)
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
+    if (e != hipSuccess) return (int)e;
+    int gx = (int)((B * plane + 255) / 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, 1, db, dg);
+  }
   const float inv_count = (float)(1.0 / ((double)B * H * W));
   dim3 grid(256, ksize == 3 ? 2 : 4);  // k = 3: one block column per octet; k = 5, 7: per half octet (accumulator registers)
   switch (ksize) {

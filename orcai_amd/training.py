@@ -711,11 +711,27 @@ class TrunkTrainer:
         """Block 1's first conv may rebuild its input y0 from the snippet (orcai_dw_bwd_fused_conv0): f32, k = 3, the two-pass entry conv (v0 not stored)."""
         return bool(self.conv0_in_dgrad and self.fused_dw_bwd and not self.v0_stored and not self.half and self.k == 3 and x.data_ptr() == self.buf["y0"].data_ptr())
 
+    def _conv0_dgrad_half_ok(self, x) -> bool:
+        """f16 path: block 1's first conv takes bn0's sums and the residual gradient into its marching pass (x = the stored v0)."""
+        return bool(self.half and self.conv0_in_dgrad and self.fused_dw_bwd and self.v0_stored and self.k == 3 and self.block_masks is None
+                    and x.data_ptr() == self.buf["y0"].data_ptr())
+
     def _dw_bwd_fused(self, name, x, relu_in, Cin, H, W, du, dr, epi, x_bn):
         """orcai_dw_bwd_fused for one separable conv: dr, the depthwise weight gradient and the epilogue extra `epi` of _dgrad in one pass over
         (du, x).  Returns whether the epilogue extra ran (True / False), or None when the launch is not this kernel's (the caller runs the
         separate passes): the extras read the conv's own input, so ("bsums", ref, ...) needs ref to be the pre-normalisation tensor x."""
         P = self.P
+        if name == "b1/sep_a" and epi is None and x_bn is None and self._resq is not None and self._conv0_dgrad_half_ok(x):
+            # f16 path: the entry conv's stored v0 is the pass's x (y0 formed from it on load), bn0's backward sums over the total gradient in its
+            # epilogue, the residual branch's even-pixel gradient added inside (orcai_h_dw_bwd_fused_res + orcai_h_conv0_bn_bwd_ready)
+            mean0, var0 = self.stats["bn0"]
+            rc = self.lib.orcai_h_dw_bwd_fused_res(self.buf["v0"].data_ptr(), du.data_ptr(), self.B, Cin, H, W, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
+                                                   P.G(name + "/depthwise").data_ptr(), mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(),
+                                                   BN_EPS, 1, self.scratch.data_ptr(), self._resq.data_ptr(), N.stream_ptr())
+            if rc != N.E_UNSUPPORTED:
+                N.check(rc, "orcai_h_dw_bwd_fused_res")
+                self.bn0_sums_ready = True
+                return False
         if name == "b1/sep_a" and epi is None and x_bn is None and self._conv0_dgrad_ok(x):
             # block 1's first conv: y0 rebuilt from the snippet's taps instead of read, bn0's backward sums left in self.scratch for orcai_conv0_bn_bwd_x_ready
             mean0, var0 = self.stats["bn0"]
@@ -844,7 +860,7 @@ class TrunkTrainer:
             # applies anyway (mask * mask = mask)
             wrt = self._w_pwT(f"b{i}/res/kernel", cprev, f)  # residual weights transposed [f][cprev]
             self._resq = None
-            if i == 1 and self._conv0_dgrad_ok(x_in):
+            if i == 1 and (self._conv0_dgrad_ok(x_in) or self._conv0_dgrad_half_ok(x_in)):
                 # the residual branch's gradient w.r.t. y0 lives on the even pixels only: one plain pointwise pass at the pooled resolution, added inside
                 # the marching pass below (where bn0's sums are taken over the TOTAL gradient) instead of scatter-added to dr afterwards
                 self._resq = b["rq1"]
@@ -862,7 +878,8 @@ class TrunkTrainer:
         H, W = m.input_hw
         mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
         if self.v0_stored:
-            N.check(self._fn("conv0_bn_bwd")(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
+            c0bwd = self.lib.orcai_h_conv0_bn_bwd_ready if (self.half and self.bn0_sums_ready) else self._fn("conv0_bn_bwd")
+            N.check(c0bwd(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
                                              P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(), P.G("bn0/beta").data_ptr(),
                                              P.G("bn0/gamma").data_ptr(), P.G("conv0/kernel").data_ptr(), st), "conv0_bn_bwd")
         else:
