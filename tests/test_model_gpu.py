@@ -455,3 +455,47 @@ def test_forward_is_hip_graph_capturable():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(static_out, want)
+
+
+@pytest.mark.parametrize("C,Cp,H,W,compact", [(30, 16, 736, 171, 1), (40, 30, 368, 86, 0), (30, 16, 37, 171, 0), (40, 30, 9, 87, 0), (50, 40, 21, 80, 0), (20, 9, 5, 161, 1)])
+def test_pooling_on_stacked_tiles_is_bit_identical(C, Cp, H, W, compact):
+    """pool_res_add_x_kernel<MT, true> (a wave = 4 output rows x 16 columns, the input row two pooling windows share loaded once) against the
+    flat-window instantiation: the same maxima and sums, bit for bit, pads of the output untouched -- orcai-V1's blocks 1 and 2, odd heights and
+    widths (clamped last rows / columns), a partial last row group, the compact (2i, 2j) subsample of the entry fusion as residual input."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(C * 100 + W)
+    B, k = 2, 3
+    CQ, CQp = (C + 3) // 4, (Cp + 3) // 4
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    assert Wo >= 40  # the launcher's rule for the stacked tiles
+    WPx = (Wo + 3) // 4 * 4
+    s = torch.randn(B, CQ, H, WPx, 4, generator=g).to(dev)  # x-pooled conv output
+    if compact:
+        prev = torch.randn(B, CQp, Ho, Wo, 4, generator=g).to(dev)
+    else:
+        WP = lib.orcai_padded_width(W, k)
+        prev = torch.zeros(B, CQp, H + 2, WP, 4)
+        prev[:, :, 1:H + 1, :W] = torch.randn(B, CQp, H, W, 4, generator=g)
+        prev = prev.to(dev)
+    wr = (torch.randn(Cp, C, generator=g) / Cp ** 0.5).to(dev)
+    br = torch.randn(C, generator=g).to(dev)
+    WPo = lib.orcai_padded_width(Wo, k)
+    outs = {}
+    before = lib.orcai_pool_vertical(-1)
+    try:
+        for vert in (0, 1):
+            lib.orcai_pool_vertical(vert)
+            out = torch.full((B, CQ, Ho + 2, WPo, 4), 3.0, device=dev)
+            rc = lib.orcai_pool_res_add(N.ptr(s), N.ptr(prev), B, C, Cp, H, W, k, N.ptr(wr), N.ptr(br), N.ptr(out), 1 | (2 if compact else 0), N.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs[vert] = out
+    finally:
+        lib.orcai_pool_vertical(before)
+    assert torch.equal(outs[0], outs[1])
+    pads = outs[1].clone()
+    pads[:, :, 1:Ho + 1, :Wo] = 3.0
+    assert float((pads - 3.0).abs().max()) == 0.0  # only the interior is written
