@@ -992,20 +992,34 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_split_kernel(const float* __re
   float dc[4] = {0.f, 0.f, 0.f, 0.f}, dhr[4] = {0.f, 0.f, 0.f, 0.f};
   const int pl = wave * 64 + (lj >> 3) * 32 + (lj & 7);
   float pg[4][4], pc[4], pcp[4], pdh[4];
+  // per-row element offsets once (32 bits: the launcher refuses tensors of 2^31 elements), a wave-uniform term per step -- the 28 loads of a step
+  // cost one add each instead of a 64-bit index computation (the forward kernel's change)
+  uint32_t go_[4], co_[4], ho_[4];
+  bool rowok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int bb = b0 + lk * 4 + r;
+    rowok[r] = bb < B;
+    const uint32_t bc = rowok[r] ? (uint32_t)bb : 0u;
+    go_[r] = (bc * (uint32_t)T * 2u + (uint32_t)dir) * (uint32_t)(4 * U) + (uint32_t)pl;
+    co_[r] = (bc * (uint32_t)T * 2u + (uint32_t)dir) * (uint32_t)U + (uint32_t)unit;
+    ho_[r] = bc * (uint32_t)T * (uint32_t)(2 * U) + (uint32_t)(dir * U + unit);
+  }
   auto load_step = [&](int step) {
     const int t = dir ? step : (T - 1 - step);
     const int tprev = dir ? t + 1 : t - 1;
     const bool has_prev = dir ? (t + 1 < T) : (t > 0);
+    const bool in_t = step < T;
+    const uint32_t tc = (uint32_t)(in_t ? t : 0), tp = (uint32_t)((in_t && has_prev) ? tprev : 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int bb = b0 + lk * 4 + r;
-      const bool ok = bb < B && step < T;
-      const int64_t gbase = ok ? (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + pl : 0;
-      pg[r][0] = ok ? gates[gbase] : 0.f; pg[r][1] = ok ? gates[gbase + 8] : 0.f;
-      pg[r][2] = ok ? gates[gbase + 16] : 0.f; pg[r][3] = ok ? gates[gbase + 24] : 0.f;
-      pc[r] = ok ? cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] : 0.f;
-      pcp[r] = (ok && has_prev) ? cstate[(((int64_t)bb * T + tprev) * 2 + dir) * U + unit] : 0.f;
-      pdh[r] = ok ? dH[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] : 0.f;
+      const bool ok = rowok[r] && in_t;
+      const float* gp = gates + (go_[r] + tc * (uint32_t)(8 * U));
+      pg[r][0] = ok ? gp[0] : 0.f; pg[r][1] = ok ? gp[8] : 0.f;
+      pg[r][2] = ok ? gp[16] : 0.f; pg[r][3] = ok ? gp[24] : 0.f;
+      pc[r] = ok ? cstate[co_[r] + tc * (uint32_t)(2 * U)] : 0.f;
+      pcp[r] = (ok && has_prev) ? cstate[co_[r] + tp * (uint32_t)(2 * U)] : 0.f;
+      pdh[r] = ok ? dH[ho_[r] + tc * (uint32_t)(2 * U)] : 0.f;
     }
   };
   load_step(0);
@@ -1389,6 +1403,7 @@ int orcai_h_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int u
 
 int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream) {
   if (!dH || !gates || !cstate || !Uw || !dxz || B <= 0 || T <= 0) return ORCAI_E_BADARG;
+  if ((int64_t)B * T * 8 * units >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;  // 32-bit element offsets inside the split kernel
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
   if (g_orcai_lstm_split && (units == 128 || units == 64)) {
