@@ -147,6 +147,21 @@ def _reduce(dist, t, op):
     return t
 
 
+def allreduce_probe(dist, wl) -> dict:
+    """The one collective of a training step, alone: all-reduce of the flat gradient bucket (3.98 MB for orcai-V1) over RCCL / xGMI.  Collective: every rank calls it."""
+    tr = wl.trainer if hasattr(wl, "trainer") else next(iter(wl.trainers.values()))
+    g = tr.P.g
+    for _ in range(3):
+        _reduce(dist, g, dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        _reduce(dist, g, dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    return {"allreduce_us": round((time.perf_counter() - t1) / 20 * 1e6, 1), "allreduce_bytes": int(g.numel() * 4)}
+
+
 def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     """BASELINE.json's metric has a second half -- training snippets/s at 1/2/4/8 GPUs -- that a single JSON line cannot carry as
     `value`.  After the headline measurement every rank also times the training step (configs[3]: batch 64 per GPU, data parallel,
@@ -185,21 +200,11 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
         _reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = {"metric": tw.metric, "value": round(tw.units_per_step * steps * world / elapsed, 1), "unit": tw.unit, "n_gpus": world, "steps": steps,
-           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": tw.dtype, "data": "synthetic",
-           "config": {"workload": tw.name, "units_per_step_per_gpu": tw.units_per_step,
+           "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": dp_scaling(), "dtype": tw.dtype, "data": "synthetic",
+           "config": {"workload": tw.name, "units_per_step_per_gpu": tw.units_per_step, "dp_batch": dp_batch_mode(), "per_rank_batch": tw.B, "global_batch": tw.B * world,
                       "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"}}
-    if dist:  # the one collective of the step, alone: all-reduce of the flat gradient bucket (3.98 MB for orcai-V1) over RCCL / xGMI
-        g = tw.trainer.P.g
-        for _ in range(3):
-            _reduce(dist, g, dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(20):
-            _reduce(dist, g, dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
-        out["allreduce_us"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
-        out["allreduce_bytes"] = int(g.numel() * 4)
+    if dist:
+        out.update(allreduce_probe(dist, tw))
     if rank == 0:  # both halves of BASELINE's metric carry a roofline: the step against the f32 MFMA peak, its dominant kernel against HBM
         r = tw.roofline()
         r["step_frac_of_f32_mfma_peak"] = round(r["step_tflops"] / MFMA_F32_PEAK_TFLOPS, 4)
@@ -245,11 +250,21 @@ def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
         _reduce(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = {"metric": hw.metric, "value": round(hw.units_per_step * steps * world / elapsed, 1), "unit": hw.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "weak", "dtype": hw.dtype, "data": "synthetic",
-           "config": {"workload": hw.name, "units_per_step_per_gpu": hw.units_per_step, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket per variant)"}}
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": dp_scaling(), "dtype": hw.dtype, "data": "synthetic",
+           "config": {"workload": hw.name, "units_per_step_per_gpu": hw.units_per_step, "dp_batch": dp_batch_mode(), "per_rank_batch": hw.B, "global_batch": hw.B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket per variant)"}}
     if rank == 0:
         out["roofline"] = hw.roofline()
     return out
+
+
+def dp_batch_mode() -> str:
+    """Batch semantics of the data-parallel training workloads (orcai_amd/datasets.py dp_batch, reference hpsearch.py:170-205): "replicate" keeps 64 snippets per
+    rank (weak scaling: the throughput mode), "split" cuts the reference's GLOBAL batch of 64 into world slices -- MirroredStrategy's contract, strong scaling."""
+    return os.environ.get("ORCAI_BENCH_DP_BATCH", "replicate")
+
+
+def dp_scaling() -> str:
+    return "strong" if dp_batch_mode() == "split" else "weak"
 
 
 def launch_ranks(n: int, argv: list[str]) -> int:
@@ -282,7 +297,12 @@ def main():
                     help="process-group backend for N > 1; gloo + --one-device rehearses the multi-rank control flow on a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (never a measurement)")
     ap.add_argument("--curve-steps", type=int, default=200)
+    ap.add_argument("--dp-batch", default=None, choices=["replicate", "split"],
+                    help="training workloads at N > 1: replicate = 64 snippets per rank (weak scaling, default); split = the reference's global batch of 64 cut into N slices "
+                         "(MirroredStrategy, hpsearch.py:170-205; strong scaling)")
     args = ap.parse_args()
+    if args.dp_batch is not None:
+        os.environ["ORCAI_BENCH_DP_BATCH"] = args.dp_batch  # read by the training workloads (and inherited by self-launched ranks)
 
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -346,6 +366,7 @@ def main():
         torch.cuda.empty_cache()
         secondary2 = measure_sweep(device, rank, world, dist)
 
+    ar_probe = allreduce_probe(dist, wl) if dist and args.workload in ("train", "hpsearch") else {}  # a collective: every rank
     if rank == 0:
         value = wl.units_per_step * args.steps * world / elapsed
         line = {
@@ -364,8 +385,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
         if args.workload in ("train", "hpsearch"):
-            line["scaling"] = "weak"
+            line["scaling"] = dp_scaling()
+            line["config"].update({"dp_batch": dp_batch_mode(), "per_rank_batch": wl.B, "global_batch": wl.B * world})
             line["config"]["parallelism"] = f"dp{world} (RCCL all-reduce of one flat fp32 gradient bucket)"
+            line.update(ar_probe)
         if args.workload == "hpsearch" and world == 1 and not args.no_loss_curves:
             line["loss_curves_f16_vs_f32"] = wl.loss_curves(args.curve_steps)
         print(json.dumps(line), flush=True)

@@ -71,7 +71,7 @@ def measured_traffic(symbol: str, workload: str = "predict"):
         return None
     rec = json.loads(f.read_text()).get(workload, {}).get("kernels", {}).get(symbol)
     if rec is None:
-        print(f"bench: {f.name} has no PMC traffic for kernel symbol {symbol!r} of workload {workload!r}: stale profile, re-run tools/evidence_r03.sh", file=sys.stderr)
+        print(f"bench: {f.name} has no PMC traffic for kernel symbol {symbol!r} of workload {workload!r}: stale profile, re-run the newest tools/evidence_rNN_*.sh", file=sys.stderr)
         return None
     return rec["hbm_bytes_per_launch"]
 
@@ -161,7 +161,7 @@ class PredictWorkload:
         if blk in couts and op == "pool_res":  # inference: the x-pooled fast path, <MT, VERT>: stacked tiles where the pooled plane is >= 40 columns wide
             vert = N.lib().orcai_pool_vertical(-1) and (widths[blk] + 1) // 2 >= 40
             return f"pool_res_add_x_kernel<{(couts[blk] + 15) // 16}, {'true' if vert else 'false'}>"
-        return {"gemm": "gemm_kernel", "rec": "lstm_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
+        return {"gemm": "gemm_kernel", "rec": "lstm_split_kernel<128>"}.get(op, "dense_sigmoid_kernel" if label == "dense2" else "gemm_kernel")
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
     # (sepconv_tile_kernel<2, 8, true, false, 8, false, 0, false>) is the top symbol of rocprofv3 --stats for this workload
@@ -274,6 +274,17 @@ class PredictWorkload:
                 "sample": (f"CPU restatement (numpy/scipy + torch-CPU fp32; not librosa/Keras): 1 h extrapolated from the 60 s recording's front end / post-processing "
                            f"({fe_per_audio_s * 1e3:.2f} ms per audio-s) and {len(snippets) + n_more} snippets of the model on {cores} threads ({per_snippet * 1e3:.0f} ms per snippet)"),
                 "config1_60s_wall_split_s": cpu1}
+
+
+def _per_rank_batch(world: int) -> int:
+    """64 snippets per rank ("replicate": weak scaling), or the reference's GLOBAL batch of 64 cut into `world` slices (ORCAI_BENCH_DP_BATCH=split, bench.py
+    --dp-batch split: MirroredStrategy's contract, hpsearch.py:170-205 -- the same number of optimiser steps per epoch as one GPU, strong scaling)."""
+    B = int(os.environ.get("ORCAI_BENCH_BATCH", "64"))
+    if os.environ.get("ORCAI_BENCH_DP_BATCH", "replicate") == "split":
+        if B % world:
+            raise SystemExit(f"bench: --dp-batch split needs the global batch {B} divisible by the {world} ranks")
+        B //= world
+    return B
 
 
 class _TimedLib:
@@ -444,8 +455,8 @@ class TrainWorkload:
         from orcai_amd.architectures import ResNetLSTM
         from orcai_amd.training import Trainer
 
-        self.B = int(os.environ.get("ORCAI_BENCH_BATCH", "64"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.B = _per_rank_batch(self.world)
         self.model = ResNetLSTM((736, 171, 1), 7, FILTERS, 3, 0.5, 128, seed=1)
         self.trainer = Trainer(self.model, 1e-4, seed=rank)
         self.timed = _TimedLib(self.trainer.trunk.lib)
@@ -574,8 +585,8 @@ class HpsearchWorkload:
         from orcai_amd.architectures import ResNetLSTM
         from orcai_amd.training import Trainer
 
-        self.B = int(os.environ.get("ORCAI_BENCH_BATCH", "64"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.B = _per_rank_batch(self.world)
         self.device, self.rank, self.precision = device, rank, precision
         g = torch.Generator(device=device)
         g.manual_seed(5 + rank)

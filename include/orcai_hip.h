@@ -181,6 +181,18 @@ int orcai_sepconv_bn(const float* in, int B, int Cin, int H, int W, int ksize, i
  *   -> out f32[B][C][ceil(H/2) + 2*(k/2)][orcai_padded_width(ceil(W/2), k)] padded planes */
 int orcai_pool_res_add(const float* s, const float* prev, int B, int C, int Cp, int H, int W, int ksize, const float* wr, const float* br,
                        float* out, int xpooled, void* stream);
+/* A residual block's second separable convolution WITH the block's tail in its epilogue (architectures.py:172-196, predict.py:265-268):
+ *   out = MaxPooling2D((3,2), strides 2, "same")(scale * SepConv(relu_in ? relu(in) : in) + shift [relu_out]) + Conv2D(C, 1, strides 2)(prev) + br
+ * = orcai_sepconv_bn(out_layout = 2) followed by orcai_pool_res_add(xpooled bit 0), bit for bit, without the x-pooled tensor in HBM.
+ *   in f32[B][ceil(Cin/4)][H+2][orcai_padded_width(W,3)][4] planes, dw f32[ceil(Cin/4)][9][4], pw f32[Cin][C], scale / shift f32[C] (folded BatchNorm);
+ *   prev: the block input, padded planes of Cp channels at H x W, or (prev_compact) its (2i, 2j) subsample f32[B][ceil(Cp/4)][H/2][ceil(W/2)][4];
+ *   wr f32[Cp][C], br f32[C] -> out f32[B][ceil(C/4)][H/2 + 2][orcai_padded_width(ceil(W/2),3)][4] padded planes (pads untouched).
+ * ORCAI_E_UNSUPPORTED (the caller runs the two launches) unless ksize == 3, 17 <= C <= 32, 17 <= Cin <= 32, Cp <= 16, H even and the plane is wide
+ * enough for 60-column strips (orcai-V1 block 1).  orcai_pool_fused(nt): tiles of 8 conv rows a workgroup marches over (default 8); 0 switches the
+ * fused tail off; < 0 queries; returns the previous value. */
+int orcai_sepconv_pool_res(const float* in, const float* prev, int B, int Cin, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
+                           const float* scale, const float* shift, int relu_out, const float* wr, const float* br, float* out, int prev_compact, void* stream);
+int orcai_pool_fused(int nt);
 int orcai_pool_vertical(int on); /* experiments: 1 (default) = the inference pooling kernel on stacked tiles (4 output rows x 16 columns per wave: the row two windows share is loaded once) where the pooled plane is >= 40 columns wide; 0 = flat 64-pixel windows everywhere; < 0 queries; returns the previous value.  Bit-identical results. */
 
 /* C[M][N] = act(A[M][K] * Bm[K][N] + bias[N]) [* scale[N] + shift[N]]; act 0 = identity, 1 = ReLU; bias/scale/shift may be NULL.
@@ -253,7 +265,12 @@ int orcai_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int uni
  * term dz U^T of orcai_lstm_bwd (dz rounded to f16 for the product only; dxz is written in f32). */
 int orcai_h_lstm_train_fwd(const float* xz, const float* Uw, int B, int T, int units, float* out, float* gates, float* cstate, void* stream);
 int orcai_h_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream);
-/* Backward through time: dH f32[B][T][2*units] (gradient of the layer output) -> dxz f32[B][T][2][4*units] (permuted columns). */
+/* Backward through time: dH f32[B][T][2*units] (gradient of the layer output) -> dxz f32[B][T][2][4*units] (permuted columns).
+ * With orcai_lstm_split(1) the launch rescales dz by a power of two taken from max|dH| (two tiny launches in front of the recurrence); that scale
+ * travels through one device global, so at most ONE orcai_lstm_bwd may be in flight per device (calls on one stream are ordered and fine;
+ * concurrent calls on two streams of the same device are not supported).  Device-symbol addresses and the > 64 KiB LDS opt-ins are looked up
+ * per device on the device's first call, which must not be inside a stream capture.  dz is saturated at 2^15 x the largest incoming gradient
+ * before the f16 split: exploding recurrences are clipped, never turned into inf / NaN. */
 int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, const float* Uw, int B, int T, int units, float* dxz, void* stream);
 /* hprev[b][t][dir][u] = h[b][t-1 (dir 0) | t+1 (dir 1)][dir*units + u], 0 at the sequence start: left operand of dU = hprev^T dxz. */
 int orcai_lstm_hprev(const float* h, int B, int T, int units, float* hprev, void* stream);
@@ -458,6 +475,10 @@ int orcai_counter_advance(uint64_t* counter, void* stream);
  *   finite, else 0, and skipped[0] += 1; nothing returns to the host, so the decision stays inside a captured graph.
  *   The *_guarded twins do nothing when ok[0] == 0: weights, Adam moments, moving statistics and the step counter keep their values. */
 int orcai_step_ok(const float* g, int64_t ng, const float* stats, int64_t ns, int32_t* ok, int64_t* skipped, void* stream);
+/* Data parallel replicas must reach the SAME verdict (the reference's MirroredStrategy applies or skips an update on all replicas together,
+ * hpsearch.py:186-205): before the gradient all-reduce, g[0] = NaN when any of this rank's stats[0, ns) is not finite -- the summed bucket is then
+ * non-finite on every rank and each rank's orcai_step_ok voids the step.  Nothing is written when all statistics are finite. */
+int orcai_poison_if_nonfinite(const float* stats, int64_t ns, float* g, void* stream);
 int orcai_adam_step_guarded(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter,
                             float gscale, const int32_t* ok, void* stream);
 int orcai_ema_update_guarded(float* moving, const float* batch, int n, float momentum, const int32_t* ok, void* stream);

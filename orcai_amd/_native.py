@@ -84,6 +84,8 @@ _SIGNATURES = {
     "orcai_sepconv_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_dw_wgrad_march": (C.c_int, [C.c_int]),
     "orcai_pool_vertical": (C.c_int, [C.c_int]),
+    "orcai_pool_fused": (C.c_int, [C.c_int]),
+    "orcai_sepconv_pool_res": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]),
     "orcai_dw_bwd_fused": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_dw_bwd_fused_conv0": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p] * 9 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_conv0_bn_bwd_x_ready": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 5 + [c_i64, C.c_void_p]),
@@ -129,6 +131,7 @@ _SIGNATURES = {
     "orcai_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_counter_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orcai_step_ok": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_poison_if_nonfinite": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "orcai_adam_step_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_ema_update_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_counter_advance_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -324,17 +324,25 @@ class ResNetLSTM:
         d["dense2/W"] = self._upload(w["dense2/kernel"])
         d["dense2/b"] = self._upload(w["dense2/bias"])
 
-    def _launch(self, label: str, what: str, fn, *args) -> None:
-        """Call one C-ABI launcher; optionally bracket it with HIP events on the launch stream (bench.py)."""
+    def _launch(self, label: str, what: str, fn, *args, may_refuse: bool = False) -> bool:
+        """Call one C-ABI launcher; optionally bracket it with HIP events on the launch stream (bench.py).  may_refuse: ORCAI_E_UNSUPPORTED (the
+        launcher refused the shape before touching anything) returns False and the caller launches its alternative; otherwise True."""
         ev = self.kernel_events
         if ev is None or (self.kernel_event_labels is not None and label not in self.kernel_event_labels):
-            N.check(fn(*args), what)
-            return
+            rc = fn(*args)
+            if may_refuse and rc == N.E_UNSUPPORTED:
+                return False
+            N.check(rc, what)
+            return True
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        N.check(fn(*args), what)
+        rc = fn(*args)
+        if may_refuse and rc == N.E_UNSUPPORTED:
+            return False
+        N.check(rc, what)
         e1.record()
         ev.setdefault(label, []).append((e0, e1))
+        return True
 
     def trunk_device(self, src: torch.Tensor, snippet_stride: int, B: int, feat: torch.Tensor, keep: dict | None = None, first: int = 0,
                      last: int | None = None, ws: dict | None = None) -> dict:
@@ -370,6 +378,12 @@ class ResNetLSTM:
             else:
                 self._launch(pa, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(prev), B, c, h, wd, k, 1, N.ptr(d[pa + "/dw"]), N.ptr(d[pa + "/pw"]),
                              N.ptr(d[pa + "/scale"]), N.ptr(d[pa + "/shift"]), f, 1, 0, N.ptr(a), st)
+            # second separable conv + the block's tail (pool, residual conv, add) in one launch where the marching kernel has the shape (orcai-V1
+            # block 1): the x-pooled tensor never reaches HBM; otherwise the two launches -- the same bits either way
+            if keep is None and self._launch(f"b{b}/sep_b+pool_res", "orcai_sepconv_pool_res", lib.orcai_sepconv_pool_res, N.ptr(a), N.ptr(prev), B, f, f, c, h, wd, k, 0,
+                                             N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]), N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), 0, N.ptr(d[f"b{b}/res/w"]),
+                                             N.ptr(d[f"b{b}/res/b"]), N.ptr(nxt), 1 if entry else 0, st, may_refuse=True):
+                continue
             self._launch(pb, "orcai_sepconv_bn", lib.orcai_sepconv_bn, N.ptr(a), B, f, h, wd, k, 0, N.ptr(d[pb + "/dw"]), N.ptr(d[pb + "/pw"]),
                          N.ptr(d[pb + "/scale"]), N.ptr(d[pb + "/shift"]), f, 0, 2, N.ptr(bb), st)
             self._launch(f"b{b}/pool_res", "orcai_pool_res_add", lib.orcai_pool_res_add, N.ptr(bb), N.ptr(prev), B, f, c, h, wd, k, N.ptr(d[f"b{b}/res/w"]),

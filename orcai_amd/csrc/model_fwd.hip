@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "lds_dma.h"
 #include "orcai_hip.h"
@@ -1011,6 +1012,269 @@ __global__ __launch_bounds__(64 * TR) void sepconv_tile_kernel(const float* __re
 }
 
 // =========================================================================================
+// sepconv_pool_march: a residual block's SECOND separable convolution (+ folded BatchNorm) with the block's tail in its epilogue
+// (architectures.py:172-196): MaxPooling2D((3, 2), strides 2, "same") of the conv output + Conv2D(C, 1, strides 2)(prev) + add, written as
+// the next block's padded input planes.  The x-pooled conv output (7.6 MB per snippet in block 1, written by sepconv_tile_kernel<.., XP> and
+// read straight back by pool_res_add_x_kernel) never reaches HBM.
+//   * The conv part is sepconv_tile_kernel<2, CQ, XP = true>: 8 waves = 8 conv rows x 64 lanes (60 valid columns), the tile's 10 input rows
+//     of a quad fetched once by LDS-DMA into one of two slots, one raw barrier per quad -- the same fma / MFMA chains, bit for bit.
+//   * A workgroup MARCHES down its column strip over NT tiles.  A pooling window needs conv rows 2i, 2i + 1, 2i + 2: row 2i + 2 is shared
+//     with window i + 1, and for the last window of a tile it is the NEXT tile's first row -- so the elementwise maximum of the tile's rows
+//     6 and 7 is carried (in LDS) to the next tile instead of recomputing a conv row per tile.  A segment of NT tiles yields 4 NT - 1 pooled
+//     rows from 8 NT - 1 conv rows (one wave idles in the last tile; one conv row per segment is computed by two segments).
+//   * Tail of a tile: every wave writes its x-pooled row to an LDS exchange area [row][quad][30 pooled pixels][4] (two of the nine rows
+//     alias the input slot of the tile's last quad, which is free until the next tile's second DMA), one barrier, then wave w finishes
+//     pooled row (w >> 1) - 1 (-1 = the carried window) for output tile w & 1: max of three rows, residual 1x1 conv of prev at the pooled
+//     pixel on the MFMA (prev read as 16-byte pixels, 4x4 lane-row transpose as everywhere), + bias, add, one 16-byte store per lane.
+//     The next tile's first DMA is issued before the tail and lands while it runs.
+// Arithmetic order = pool_res_add_x_kernel's (max first, then mx + (acc + bias)): bit-identical to the two-launch path.
+// LDS: 20 KB slots + 7 x 3840 B exchange + 4 KB pointwise weights = 51.7 KB -> three workgroups per compute unit (measured: the conv part
+// loses 1.5 % at three instead of four; profiles/r04_ab_lds_pad.log), registers capped at 80 for six waves per SIMD.
+// =========================================================================================
+template <int CQ, bool RELU>
+__global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float* __restrict__ in /*[B][CQr][H+2][WP][4]*/, int Cin, int H, int W, int WP,
+                                                                   const float* __restrict__ dw /*[CQ][9][4]*/, const float* __restrict__ pw /*[Cin][Cout]*/,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
+                                                                   const float* __restrict__ prev, int Cp, int prev_compact, const float* __restrict__ wr /*[Cp][Cout]*/,
+                                                                   const float* __restrict__ br, float* __restrict__ out /*[B][CQo][Ho+2][WPo][4]*/, int Ho, int Wo, int WPo,
+                                                                   int nstrip, int NT, int dbg /*timing experiments: bit 0 = no tail items*/) {
+  constexpr int KK = 9, R = 1, lo = 2, VAL = 60, TR = 8, MT = 2, NPX = VAL / 2, XROW = 8 * NPX * 4;  // XROW floats per exchange row: [8 quads][NPX][4]
+  constexpr int SLOT = (TR + 2) * 256;  // floats per input slot: [tile row][lane][4]
+  // one array, so that every pointer below is an LDS pointer to the compiler: [2 input slots][7 exchange rows: rows 2 .. 7 of the tile, then the carry
+  // max(row 6, row 7) of the previous tile]; exchange rows 0 and 1 alias the input slot of the tile's last quad
+  __shared__ __attribute__((aligned(16))) float lds_f[2 * SLOT + 7 * XROW];
+  __shared__ float pw_s[CQ * 4 * 16 * MT];
+  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
+  __shared__ float wr_s[16 * MT * 16], br_s[MT * 16];  // residual conv: [ci][co] (zero outside Cp x Cout), bias -- read in the tail (kept in registers they spill)
+  static_assert(2 * XROW <= (TR + 2) * 256, "two exchange rows alias one input slot");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bx, b;
+  xcd_remap(bx, b);
+  const int seg = bx / nstrip, strip = bx - seg * nstrip;
+  const int NPS = 4 * NT - 1;  // pooled rows per segment
+  const int p0 = seg * NPS, pend = (p0 + NPS < Ho) ? p0 + NPS : Ho;
+  const int rb = 2 * p0, c0 = strip * VAL;
+  const int need = 2 * (pend - p0) + 1, have = H - rb;  // conv rows the segment's windows touch / rows of the image below rb (H even: window Ho - 1 has two rows)
+  const int ntile = ((need < have ? need : have) + TR - 1) / TR;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int plane = (H + 2 * R) * WP;
+  const int CQo = (Cout + 3) >> 2, CQp = (Cp + 3) >> 2;
+  constexpr int CQr = CQ;  // the launcher instantiates the exact number of input quads
+  const char* src = reinterpret_cast<const char*>(in) + (int64_t)b * CQr * plane * 16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)&lds_f[0];
+  const bool two = wave < 2;
+
+  // DMA of tile t, quad cq into slot sl: tile row j (0 .. TR + 1) is padded-plane row rb + t TR + j; this wave fetches row `wave`, waves 0 and 1
+  // also rows TR and TR + 1.  Offsets are clamped into the quad plane: only lanes / rows whose outputs are discarded can leave it.
+  int64_t plane16 = (int64_t)plane * 16;
+  auto issue = [&](int t, int cq, int sl, int lane) {
+    const int r0 = rb + t * TR;
+    auto goff = [&](int j) {
+      const int i = (r0 + j) * WP + c0 - lo + lane;
+      return (uint32_t)(i < 0 ? 0 : (i >= plane ? plane - 1 : i)) * 16u;
+    };
+    const char* base = src + (int64_t)cq * plane16;
+    const uint32_t slot = lds0 + (uint32_t)(sl * (TR + 2) * 1024);
+    glds16(base + goff(wave), slot + (uint32_t)wave * 1024u);
+    if (two) glds16(base + goff(TR + (wave & 1)), slot + (uint32_t)(TR + wave) * 1024u);
+  };
+  issue(0, 0, 0, lane);
+
+  for (int i = threadIdx.x; i < CQ * 4 * 16 * MT; i += 64 * TR) {
+    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
+    pw_s[i] = (ci < Cin && co < Cout) ? pw[ci * Cout + co] : 0.0f;
+  }
+  if (threadIdx.x < MT * 16) {
+    const int co = threadIdx.x;
+    sc_s[co] = co < Cout ? scale[co] : 0.0f;
+    sh_s[co] = co < Cout ? shift[co] : 0.0f;
+  }
+  {
+    const int ci = threadIdx.x >> 5, co = threadIdx.x & 31;  // 16 x 32 = 512 threads
+    const bool ok = ci < Cp && co < Cout;
+    const float av = wr[ok ? ci * Cout + co : 0];
+    wr_s[threadIdx.x] = ok ? av : 0.0f;
+    if (threadIdx.x < MT * 16) {
+      const float bv = br[co < Cout ? co : 0];
+      br_s[threadIdx.x] = co < Cout ? bv : 0.0f;
+    }
+  }
+  const int tm = wave & 1, tk = (wave >> 1) - 1;  // this wave's tail item: output tile tm of pooled row 4 t + tk
+  __syncthreads();
+  const float lo_out = relu_out ? 0.0f : -INFINITY;
+  const int plane_p = prev_compact ? Ho * Wo : plane, plane_o = (Ho + 2 * R) * WPo;
+  const float4* prevb = reinterpret_cast<const float4*>(prev) + (int64_t)b * CQp * plane_p;
+  float4* outb = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane_o;
+  bool vm_clean = false;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int r0 = rb + t * TR;
+    const int par = (t * CQr) & 1;  // slot of this tile's quad cq = (cq & 1) ^ par (a running count over tiles and quads)
+    // the depthwise taps are re-read through the scalar cache every tile: hoisted out of the tile loop, the 36 CQ scalars do not fit the SGPR file
+    // and come back as v_readlane traffic and spilled vector registers
+    // ... and everything lane-dependent inside the tile loop is derived from an opaque copy of the lane id: hoisted out of the loop, two dozen
+    // loop-invariant registers are spilled and come back through scratch memory (vector-memory operations in front of the counted waits)
+    // (the lane id itself is re-derived by v_mbcnt: kept live across the loop it is the one register that still spilled, and its reload at the
+    // top of a tile -- a vector-memory operation -- made the wave wait for its output stores after all)
+    int lane_t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+    const int tlk = lane_t >> 4, tlj = lane_t & 15;
+    int opaque_zero = 0;
+    asm volatile("" : "+s"(opaque_zero));
+    plane16 = (int64_t)plane * 16 + opaque_zero;  // (and the per-quad plane bases are formed where they are used)
+    const float* dwt = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq) {
+      {
+        // this quad's DMAs have landed; every wave has finished reading the other slot (and, at cq = 0, the previous tile's tail).  A wave that finished a tail
+        // item has already waited for loads it issued AFTER this tile's first DMA (in-order return): it must not wait for its output stores here
+        if (cq == 0 && vm_clean) asm volatile("s_barrier" ::: "memory"); else wait_vm_barrier<0>();
+        const int sl = (cq & 1) ^ par;
+        if (cq + 1 < CQr) issue(t, cq + 1, sl ^ 1, lane_t);
+        else if (t + 1 < ntile) issue(t + 1, 0, sl ^ 1, lane_t);  // lands during the tail
+        float4 rows[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&lds_f[sl * SLOT + (wave + dy) * 256 + lane_t * 4]);
+        float afrag[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + tlk) * 16 + tlj) * MT + m];
+        float d[4];
+        dw_quad_impl<3, RELU>(rows, dwt + cq * 4 * KK, d);
+        swap32(d[0], d[2]);
+        swap32(d[1], d[3]);
+        swap16(d[0], d[1]);
+        swap16(d[2], d[3]);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
+      }
+    }
+    // ---- the tail's operands that come from HBM are requested NOW, a barrier pair and the epilogue arithmetic ahead of their use: prev at the pooled
+    // pixel (2 pr, 2 j), lane = pooled pixel of the strip, 4 channels per load.  Everything lane-dependent of the tail is derived from an opaque copy
+    // of the lane id INSIDE the tile loop: hoisted out of it, two dozen loop-invariant registers are spilled and come back through scratch memory.
+    const int pr = p0 + 4 * t + tk;  // this wave's pooled row (tk = -1: the window the previous tile left open, closed by this tile's first row)
+    const bool item = (tk >= 0 || t > 0) && pr < pend;  // wave-uniform
+    // the segment's (= the image's) last window has two rows when the image ends with this tile: closed here, by waves 0 and 1 as a second item
+    const int pr_last = p0 + 4 * t + 3;
+    const bool item2 = tk < 0 && pr_last < pend && r0 + TR >= H;
+    float4 pv[4];
+    auto request_prev = [&](int prow) {
+      const int jq = (c0 >> 1) + (lane_t < NPX ? lane_t : NPX - 1);
+      const int jqc = jq < Wo ? jq : Wo - 1;
+      const int srcpix = prev_compact ? prow * Wo + jqc : (2 * prow + R) * WP + 2 * jqc;
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) pv[cq] = prevb[(int64_t)(cq < CQp ? cq : 0) * plane_p + srcpix];
+    };
+    if (item && !(dbg & 1)) request_prev(pr);
+
+    // ---- folded BatchNorm (+ ReLU) and the column-pair maximum, exactly sepconv_tile_kernel<.., XP>'s epilogue; the values stay in `acc`
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int x = c0 - lo + 16 * tt + tlj;
+      const bool pair_ok = x + 1 < W;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + tlk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + tlk];
+        float v[4] = {fmaf(acc[m][tt][0], sc.x, sh.x), fmaf(acc[m][tt][1], sc.y, sh.y), fmaf(acc[m][tt][2], sc.z, sh.z), fmaf(acc[m][tt][3], sc.w, sh.w)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = max2(v[r], lo_out);
+          const float other = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v[r]), 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true));
+          acc[m][tt][r] = max2(v[r], pair_ok ? other : v[r]);
+        }
+      }
+    }
+    // E0: every wave has consumed the last quad's rows -- its slot is free until the DMA after next (issued behind the next tile's first barrier)
+    asm volatile("s_barrier" ::: "memory");
+    const int sfree = ((CQr - 1) & 1) ^ par;
+    auto xrow = [&](int j) -> float* { return &lds_f[j < 2 ? sfree * SLOT + j * XROW : 2 * SLOT + (j - 2) * XROW]; };
+    {
+      float* xme = xrow(wave);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int wl = 16 * tt + tlj;
+        if ((tlj & 1) == 0 && wl >= lo && wl < 64 - lo) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            *reinterpret_cast<float4*>(&xme[((m * 4 + tlk) * NPX + ((wl - lo) >> 1)) * 4]) = make_float4(acc[m][tt][0], acc[m][tt][1], acc[m][tt][2], acc[m][tt][3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // E1: the tile's eight x-pooled rows are in LDS
+
+    // ---- tail: pooled row `prow` of output tile tm = max of the exchange rows pa, pb, pc (+ residual conv of prev, bias) -> out
+    float* carry = &lds_f[2 * SLOT + 6 * XROW];
+    auto finish = [&](int prow, const float* pa, const float* pb, const float* pc) {
+      float4 mx[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int px = 16 * t2 + tlj, pxc = px < NPX ? px : NPX - 1;
+        const int idx = ((tm * 4 + tlk) * NPX + pxc) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(&pa[idx]), bq = *reinterpret_cast<const float4*>(&pb[idx]), c = *reinterpret_cast<const float4*>(&pc[idx]);
+        mx[t2] = make_float4(fmaxf(fmaxf(a.x, bq.x), c.x), fmaxf(fmaxf(a.y, bq.y), c.y), fmaxf(fmaxf(a.z, bq.z), c.z), fmaxf(fmaxf(a.w, bq.w), c.w));
+      }
+      f32x4 racc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {
+        if (cq < CQp) {
+          float d[4] = {pv[cq].x, pv[cq].y, pv[cq].z, pv[cq].w};
+          swap32(d[0], d[2]);
+          swap32(d[1], d[3]);
+          swap16(d[0], d[1]);
+          swap16(d[2], d[3]);
+          const float wa = wr_s[(cq * 4 + tlk) * 32 + tm * 16 + tlj];
+          racc[0] = mfma16(wa, d[0], racc[0]);
+          racc[1] = mfma16(wa, d[1], racc[1]);
+        }
+      }
+      const int oq = tm * 4 + tlk;
+      const float4 br4 = reinterpret_cast<const float4*>(br_s)[oq];
+      const float brr[4] = {br4.x, br4.y, br4.z, br4.w};
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int px = 16 * t2 + tlj, j = (c0 >> 1) + px;
+        if (px < NPX && j < Wo && oq < CQo) {
+          const float mv[4] = {mx[t2].x, mx[t2].y, mx[t2].z, mx[t2].w};
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < Cout) ? mv[r] + (racc[t2][r] + brr[r]) : 0.0f;
+          outb[(int64_t)oq * plane_o + (prow + R) * WPo + j] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    };
+    if (item && !(dbg & 1)) {
+      const float* pa = tk < 0 ? carry : xrow(2 * tk);
+      const float* pb = tk < 0 ? (r0 < H ? xrow(0) : pa) : xrow(2 * tk + 1);
+      const float* pc = (tk >= 0 && r0 + 2 * tk + 2 < H) ? xrow(2 * tk + 2) : pa;
+      finish(pr, pa, pb, pc);
+    }
+    if (item2 && !(dbg & 1)) {  // rows 6 and 7 are the image's last two: their window closes here (the prev loads are exposed once per strip)
+      request_prev(pr_last);
+      finish(pr_last, xrow(6), xrow(7), xrow(6));
+    }
+    if (tk < 0 && t + 1 < ntile) {  // waves 0 and 1: the new carry, max(row 6, row 7), for their half of the channels (the old carry was read above: same wave, in order)
+      const float* p6 = xrow(6);
+      const float* p7 = xrow(7);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int px = 16 * t2 + tlj, pxc = px < NPX ? px : NPX - 1;
+        const int idx = ((tm * 4 + tlk) * NPX + pxc) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(&p6[idx]), bq = *reinterpret_cast<const float4*>(&p7[idx]);
+        *reinterpret_cast<float4*>(&carry[idx]) = make_float4(fmaxf(a.x, bq.x), fmaxf(a.y, bq.y), fmaxf(a.z, bq.z), fmaxf(a.w, bq.w));
+      }
+    }
+    vm_clean = item && !item2 && !(dbg & 1);  // this wave waited for loads younger than the next tile's first DMA: that DMA has landed, only stores are in flight
+  }
+}
+
+// =========================================================================================
 // sepconv_ftile: the LDS-shared rows of sepconv_tile for ANY plane width.  The NWV waves of a workgroup own NWV consecutive 64-pixel
 // windows of the flat padded plane (the mapping of sepconv_kernel: no strip waste on narrow planes); the rows above and below are
 // the same flat range shifted by -WP / +WP, so the three rows of all NWV windows are ONE contiguous range of
@@ -1965,8 +2229,9 @@ template <int MT, int CQ>
 int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
   constexpr int TR = 8;
   dim3 grid(nstrip * ((a.H + TR - 1) / TR), a.B);
+  static const int exp_pad = getenv("ORCAI_EXP_LDS_PAD") ? atoi(getenv("ORCAI_EXP_LDS_PAD")) : 0;  // EXPERIMENT (occupancy sensitivity): unused dynamic LDS
 #define ORCAI_TILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
-  hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
+  hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), exp_pad, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
   if (a.epi == 2) {  // input-gradient pass with the BatchNorm backward sums of its output (no ReLU on load, no depthwise-output store)
     if constexpr (MT == 2)
@@ -2335,6 +2600,42 @@ int orcai_pool_res_add_bn(const float* s, const float* prev, int B, int C, int C
     default: return ORCAI_E_UNSUPPORTED;
   }
 #undef ORCAI_POOL_LAUNCH
+  return (int)hipGetLastError();
+}
+
+int g_pool_fused_nt = 8;  // tiles per workgroup of sepconv_pool_march_kernel (orcai_pool_fused); 0 = the two-launch tail everywhere
+
+int orcai_pool_fused(int nt) {
+  const int prev = g_pool_fused_nt;
+  if (nt >= 0) g_pool_fused_nt = nt > 64 ? 64 : nt;
+  return prev;
+}
+
+int orcai_sepconv_pool_res(const float* in, const float* prev, int B, int Cin, int C, int Cp, int H, int W, int ksize, int relu_in, const float* dw, const float* pw,
+                           const float* scale, const float* shift, int relu_out, const float* wr, const float* br, float* out, int prev_compact, void* stream) {
+  if (!in || !prev || !dw || !pw || !scale || !shift || !wr || !br || !out || B <= 0 || Cin <= 0 || C <= 0 || Cp <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  // the marching kernel's shapes: k = 3, two output tiles (17 .. 32 channels), <= 8 input quads, <= 4 quads of prev, an even number of rows (pooling pads
+  // at the bottom only), a plane wide enough for the 60-column strips of sepconv_tile_kernel; everything else: the caller's two launches
+  const int nstrip = (W + 59) / 60, CQ = (Cin + 3) / 4, WP = orcai_padded_width(W, 3);
+  if (g_pool_fused_nt <= 0 || g_tile_mode != 1 || ksize != 3 || (C + 15) / 16 != 2 || CQ < 5 || CQ > 8 || Cp > 16 || (H & 1) || nstrip < 2 || W * 100 < nstrip * 60 * 85 ||
+      ((uintptr_t)in & 15) || ((uintptr_t)prev & 15) || ((uintptr_t)out & 15) || B > 65535 || (int64_t)8 * (H + 2) * WP >= (1ll << 27))
+    return ORCAI_E_UNSUPPORTED;
+  const int Ho = H / 2, Wo = (W + 1) / 2, WPo = orcai_padded_width(Wo, 3);
+  const int NT = g_pool_fused_nt, nseg = (Ho + 4 * NT - 2) / (4 * NT - 1);
+  dim3 grid(nstrip * nseg, B);
+  hipStream_t st = (hipStream_t)stream;
+  static const int exp_dbg = getenv("ORCAI_EXP_PM_DBG") ? atoi(getenv("ORCAI_EXP_PM_DBG")) : 0;  // EXPERIMENT: timing-only variants of the marching kernel (wrong results)
+#define ORCAI_PM_LAUNCH(CQT, RELU)                                                                                                                          \
+  hipLaunchKernelGGL((sepconv_pool_march_kernel<CQT, RELU>), grid, dim3(512), 0, st, in, Cin, H, W, WP, dw, pw, scale, shift, C, relu_out, prev, Cp, prev_compact ? 1 : 0, \
+                     wr, br, out, Ho, Wo, WPo, nstrip, NT, exp_dbg)
+  switch (CQ) {  // C in 17 .. 32 and Cin = C for a block's second conv: 5 .. 8 input quads
+    case 5: if (relu_in) ORCAI_PM_LAUNCH(5, true); else ORCAI_PM_LAUNCH(5, false); break;
+    case 6: if (relu_in) ORCAI_PM_LAUNCH(6, true); else ORCAI_PM_LAUNCH(6, false); break;
+    case 7: if (relu_in) ORCAI_PM_LAUNCH(7, true); else ORCAI_PM_LAUNCH(7, false); break;
+    case 8: if (relu_in) ORCAI_PM_LAUNCH(8, true); else ORCAI_PM_LAUNCH(8, false); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+#undef ORCAI_PM_LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -437,6 +437,16 @@ __global__ __launch_bounds__(256) void all_finite_kernel(const float* __restrict
   }
   if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(ok, 0);
 }
+// g[0] = NaN when any statistic is not finite: a rank-local verdict folded into the gradient bucket BEFORE the all-reduce, so that every rank's
+// orcai_step_ok sees it in the summed gradient and all replicas void the step together
+__global__ __launch_bounds__(256) void poison_if_nonfinite_kernel(const float* __restrict__ a, int64_t n, float* __restrict__ g) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t bits = __float_as_uint(a[i]);
+    bad |= (bits & 0x7f800000u) == 0x7f800000u;
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) g[0] = __uint_as_float(0x7fc00000u);
+}
 __global__ void count_skipped_kernel(const int32_t* ok, int64_t* skipped) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && !ok[0]) skipped[0] += 1;
 }
@@ -1051,7 +1061,9 @@ __global__ __launch_bounds__(U * 4) void lstm_bwd_split_kernel(const float* __re
       for (int q = 0; q < 4; ++q) {
         zr[8 * q] = z[q];
         lh16 hi, lo;
-        split_f16(z[q] * S, hi, lo);
+        // saturated at +-2^15 (the largest magnitude whose lo part still fits f16): under exploding gradients dz can exceed 2^16 x max|dH| --
+        // the recurrent term is then clipped instead of turning hi into inf and the whole gradient into NaN (the f32-MFMA kernel stays finite too)
+        split_f16(__builtin_amdgcn_fmed3f(z[q] * S, -32768.0f, 32768.0f), hi, lo);
         zh[8 * q] = hi;
         zl[8 * q] = lo;
       }
@@ -1372,12 +1384,16 @@ int orcai_h_lstm_bwd(const float* dH, const float* gates, const float* cstate, c
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
   if (units == 128) {
-    const size_t lds = (size_t)2 * 16 * (4 * 128 + 4) * 4 + (size_t)2 * 16 * (4 * 128 + 8) * 2;  // 99 328 B > 64 KiB: opt in once
-    static bool opted = false;
-    if (!opted) {
-      hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_h_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)2 * 16 * (4 * 128 + 4) * 4 + (size_t)2 * 16 * (4 * 128 + 8) * 2;  // 99 328 B > 64 KiB: opt in once per device
+    static bool opted_dev[64] = {};
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    if (e != hipSuccess) return (int)e;
+    if (devid < 0 || devid >= 64) return ORCAI_E_UNSUPPORTED;
+    if (!opted_dev[devid]) {
+      e = hipFuncSetAttribute((const void*)lstm_bwd_h_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
-      opted = true;
+      opted_dev[devid] = true;
     }
     hipLaunchKernelGGL(lstm_bwd_h_kernel<128>, grid, dim3(512), lds, st, dH, gates, cstate, Uw, B, T, dxz);
   } else if (units == 64) {
@@ -1407,30 +1423,37 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
   dim3 grid((B + 15) / 16, 2);
   hipStream_t st = (hipStream_t)stream;
   if (g_orcai_lstm_split && (units == 128 || units == 64)) {
-    static uint32_t* maxbits = nullptr;  // looked up once (the first call is never inside a stream capture: warm-up steps come first)
-    hipError_t e = hipSuccess;
-    if (!maxbits) {
-      e = hipGetSymbolAddress((void**)&maxbits, HIP_SYMBOL(g_lstm_grad_maxbits));
+    // per DEVICE: the address of the max accumulator (a __device__ symbol has one instance per device) and the > 64 KiB LDS opt-ins (function
+    // attributes are per device too).  Looked up on a device's first call, which is never inside a stream capture (warm-up steps come first).
+    // The scale itself travels through the device global g_lstm_grad_scale: ONE backward recurrence in flight per device (include/orcai_hip.h).
+    constexpr int MAXDEV = 64;
+    static uint32_t* maxbits_dev[MAXDEV] = {};
+    static bool opted_dev[MAXDEV][2] = {};
+    int devid = 0;
+    hipError_t e = hipGetDevice(&devid);
+    if (e != hipSuccess) return (int)e;
+    if (devid < 0 || devid >= MAXDEV) return ORCAI_E_UNSUPPORTED;
+    if (!maxbits_dev[devid]) {
+      e = hipGetSymbolAddress((void**)&maxbits_dev[devid], HIP_SYMBOL(g_lstm_grad_maxbits));
       if (e != hipSuccess) return (int)e;
     }
+    uint32_t* maxbits = maxbits_dev[devid];
     const int64_t n = (int64_t)B * T * 2 * units;
     hipLaunchKernelGGL(lstm_grad_max_kernel, dim3((unsigned)((n + 256 * 16 - 1) / (256 * 16))), dim3(256), 0, st, dH, n, maxbits);
     hipLaunchKernelGGL(lstm_grad_scale_kernel, dim3(1), dim3(64), 0, st, maxbits);
     const size_t lds = (size_t)2 * 16 * (4 * units + 4) * 4 + (size_t)2 * 2 * 16 * (4 * units + 8) * 2;  // f32 rows + hi + lo operands
     if (units == 128) {
-      static bool opted = false;  // 132 352 B > 64 KiB: opt in once
-      if (!opted) {
+      if (!opted_dev[devid][0]) {  // 132 352 B > 64 KiB: opt in once per device
         e = hipFuncSetAttribute((const void*)lstm_bwd_split_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        opted = true;
+        opted_dev[devid][0] = true;
       }
       hipLaunchKernelGGL(lstm_bwd_split_kernel<128>, grid, dim3(512), lds, st, dH, gates, cstate, Uw, B, T, dxz);
     } else {
-      static bool opted64 = false;  // 66 816 B
-      if (!opted64) {
+      if (!opted_dev[devid][1]) {  // 66 816 B
         e = hipFuncSetAttribute((const void*)lstm_bwd_split_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        opted64 = true;
+        opted_dev[devid][1] = true;
       }
       hipLaunchKernelGGL(lstm_bwd_split_kernel<64>, grid, dim3(256), lds, st, dH, gates, cstate, Uw, B, T, dxz);
     }
@@ -1470,6 +1493,13 @@ int orcai_step_ok(const float* g, int64_t ng, const float* stats, int64_t ns, in
   hipLaunchKernelGGL(all_finite_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, st, g, ng, ok);
   if (ns > 0) hipLaunchKernelGGL(all_finite_kernel, dim3(blocks_for(ns) > 1024 ? 1024 : blocks_for(ns)), dim3(256), 0, st, stats, ns, ok);
   hipLaunchKernelGGL(count_skipped_kernel, dim3(1), dim3(64), 0, st, ok, skipped);
+  return (int)hipGetLastError();
+}
+
+int orcai_poison_if_nonfinite(const float* stats, int64_t ns, float* g, void* stream) {
+  if (!stats || !g || ns <= 0) return ORCAI_E_BADARG;
+  const unsigned blocks = blocks_for(ns);
+  hipLaunchKernelGGL(poison_if_nonfinite_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, (hipStream_t)stream, stats, ns, g);
   return (int)hipGetLastError();
 }
 

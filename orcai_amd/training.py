@@ -992,6 +992,10 @@ class Trainer:
         if world_size > 1:
             import torch.distributed as dist
 
+            if self.half:
+                # one verdict for all replicas: a rank whose batch statistics are not finite poisons the bucket it contributes, so the all-reduced
+                # gradient is non-finite everywhere and every rank's orcai_step_ok below voids the step (weights, moments, counters stay identical)
+                N.check(N.lib().orcai_poison_if_nonfinite(self.P.batch_flat.data_ptr(), self.P.batch_flat.numel(), self.P.g.data_ptr(), N.stream_ptr()), "poison_if_nonfinite")
             if dist.get_backend() == "nccl":
                 dist.all_reduce(self.P.g, op=dist.ReduceOp.SUM)  # one flat 4 MB bucket over RCCL / xGMI
             else:  # gloo (tests): stage through the host

@@ -280,7 +280,7 @@ def test_half_forward_intermediates():
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Training on the f16 path: f16 activations / activation gradients (static loss scale), f16 MFMA contractions, f32 master weights.
-def _train_setup(cfg, B, seed, rate, precision):
+def _train_setup(cfg, B, seed, rate, precision, record=False):
     from oracle import train_ref as T
     from orcai_amd.architectures import ResNetLSTM
     from orcai_amd.training import Trainer
@@ -301,6 +301,10 @@ def _train_setup(cfg, B, seed, rate, precision):
     model = ResNetLSTM(cfg["input_shape"], L, list(cfg["filters"]), cfg["kernel_size"], rate, u, precision=precision)
     model.set_weights_dict(p)
     tr = Trainer(model, learning_rate=1e-3)
+    if record:
+        from recording_lib import RecordingLib
+
+        tr.trunk.lib = RecordingLib(tr.trunk.lib)
     xd = torch.from_numpy(np.ascontiguousarray(x[..., 0])).cuda().view(-1)
     out = tr.forward_backward(xd, H * W, B, torch.from_numpy(y).cuda(), masks={k: torch.from_numpy(v).cuda() for k, v in masks.items()})
     tr._test_inputs = (p, x, y, masks)
@@ -326,11 +330,19 @@ def test_half_training_step_gradients_vs_autograd(cfg, B):
     rectified tensors) and forced on the oracle (oracle.train_ref `forced`, self-checked on the CPU in tests/test_oracle_golden.py).  Held to:
     probabilities 5e-3, loss 5e-3 relative, every gradient tensor to relative L2 <= 2e-2 of the branch-matched float64 gradient."""
     ref, tr, out = _train_setup(cfg, B, seed=5, rate=0.5, precision="f16")
+    _check_half_step(cfg, B, ref, tr, out, seed=5)
+
+
+def _check_half_step(cfg, B, ref, tr, out, seed, probs_free_bar=5e-3):
     assert tr.half and tr.trunk.buf["v0"].dtype == torch.float16
     acc = out["acc"].cpu().numpy()
-    assert np.abs(out["probs"].cpu().numpy() - ref["probs"]).max() <= 5e-3
+    dp_free = float(np.abs(out["probs"].cpu().numpy() - ref["probs"]).max())
+    assert dp_free <= probs_free_bar, dp_free
     assert abs(acc[0] / acc[1] + acc[3] - ref["loss"]) <= 5e-3 * max(1.0, abs(ref["loss"]))
-    matched = _branch_matched_reference(cfg, B, tr, seed=5, rate=0.5)
+    matched = _branch_matched_reference(cfg, B, tr, seed=seed, rate=0.5)
+    dp_matched = float(np.abs(out["probs"].cpu().numpy() - matched["probs"]).max())
+    print(f"f16 probabilities: max|dp| {dp_free:.1e} vs the free-running float64 oracle, {dp_matched:.1e} vs the branch-matched one")
+    assert dp_matched <= 5e-3, dp_matched
     rel, relm, cos, bad = {}, {}, {}, {}
     for name, g in ref["grads"].items():
         got = tr.P.G(name).cpu().numpy().astype(np.float64) / tr.grad_scale
@@ -349,6 +361,28 @@ def test_half_training_step_gradients_vs_autograd(cfg, B):
     print(f"f16 training step {cfg['filters']} k={cfg['kernel_size']}: relative L2 gradient error vs the branch-matched oracle median {np.median(list(relm.values())):.1e}, "
           f"worst {[(k, f'{v:.1e}') for k, v in top]}; vs the free-running oracle median {np.median(list(rel.values())):.1e}, worst {max(rel.values()):.1e}, min cosine {min(cos.values()):.4f}")
     assert not bad, bad
+
+
+@pytest.mark.parametrize("filters", [(10, 20, 30, 40), (20, 30, 40, 50), (30, 40, 50, 60)])
+def test_half_training_step_at_the_benchmarked_shapes(filters):
+    """BASELINE configs[4] as bench.py times it: the three hyper-parameter-search width sets at 736 x 171, k 3, 128 units, B = 2, on the f16
+    path against the branch-matched float64 oracle at the bars of the small shapes -- with a record of the launchers that ran, so that a
+    fused pass refusing the benchmarked shape (ORCAI_E_UNSUPPORTED -> silent fallback in training.py) fails the test (reference
+    hpsearch.py:21-85, train.py:155-219)."""
+    from orcai_amd import _native as N
+
+    cfg = dict(input_shape=(736, 171, 1), filters=filters, kernel_size=3, lstm_units=128, num_labels=7)
+    ref, tr, out = _train_setup(cfg, 2, seed=13, rate=0.5, precision="f16", record=True)
+    # probabilities: 5e-3 (SURVEY 8d's f16 bar) against the oracle on the f16 forward's own branches; against the free-running oracle a batch of TWO
+    # snippets (batch statistics over 2 x 736 x 171 pixels, 1 % of the ReLU inputs on the other side of zero) reaches 5.5e-3 on one of the three sets
+    rec = tr.trunk.lib
+    tr.trunk.lib = rec._lib
+    _check_half_step(cfg, 2, ref, tr, out, seed=13, probs_free_bar=1e-2)
+    names = sorted({n for n, _, _ in rec.calls})
+    print(f"launchers of the f16 training step {filters}:", {n: (len(rec.rcs(n)), sum(rc == N.E_UNSUPPORTED for rc in rec.rcs(n))) for n in names})
+    assert rec.rcs("orcai_h_sepconv_stats") == [0] * 8  # every k = 3 separable conv of the blocks: statistics in the epilogue
+    assert rec.rcs("orcai_h_dw_bwd_fused") == [0] * 8 and rec.rcs("orcai_h_dw_bwd_fused_res") == [0] and rec.rcs("orcai_h_conv0_bn_bwd_ready") == [0]
+    assert not rec.rcs("orcai_h_dw_wgrad") and not rec.rcs("orcai_h_planes_relu_bwd")
 
 
 def _branch_matched_reference(cfg, B, tr, seed, rate):

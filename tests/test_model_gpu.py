@@ -499,3 +499,70 @@ def test_pooling_on_stacked_tiles_is_bit_identical(C, Cp, H, W, compact):
     pads = outs[1].clone()
     pads[:, :, 1:Ho + 1, :Wo] = 3.0
     assert float((pads - 3.0).abs().max()) == 0.0  # only the interior is written
+
+
+@pytest.mark.parametrize("C,Cp,H,W,compact,relu_in,nt", [(30, 16, 736, 171, 1, 0, 8), (30, 16, 62, 171, 0, 0, 2), (32, 16, 16, 120, 0, 1, 1), (20, 9, 30, 104, 1, 0, 3), (24, 12, 8, 171, 0, 0, 8),
+                                                       (28, 16, 54, 230, 0, 1, 4), (30, 16, 2, 171, 1, 0, 8), (30, 16, 130, 171, 1, 0, 64)])
+def test_fused_block_tail_is_bit_identical(C, Cp, H, W, compact, relu_in, nt):
+    """orcai_sepconv_pool_res (sepconv_pool_march_kernel: a block's second separable conv with the vertical max-pool, the strided residual 1x1 conv and the
+    add in its epilogue; workgroups march down a column strip and carry the row two pooling windows of neighbouring tiles share) against the two launches
+    it replaces, orcai_sepconv_bn(out_layout = 2) + orcai_pool_res_add: the same bits, pads of the output untouched.  orcai-V1 block 1 at full size, ragged
+    segment / tile counts (H = 62: 4 tiles in segments of 2; H = 54, 30, 130), a single tile and a two-row image, every quad count the launcher instantiates
+    (5 .. 8), both residual-input layouts, ReLU on load, strips with a partial last strip (W = 104, 230)."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(C * 1000 + H + W)
+    B, k = 2, 3
+    CQ, CQp, CQo = (C + 3) // 4, (Cp + 3) // 4, (C + 3) // 4
+    Ho, Wo = H // 2, (W + 1) // 2
+    WP, WPo, WPx = lib.orcai_padded_width(W, k), lib.orcai_padded_width(Wo, k), (Wo + 3) // 4 * 4
+    a = torch.zeros(B, CQ, H + 2, WP, 4)
+    a[:, :, 1:H + 1, :W] = torch.randn(B, CQ, H, W, 4, generator=g)
+    chan = torch.arange(CQ * 4).view(CQ, 4) < C  # channels past C inside the last quad are kept at zero
+    a = (a * chan.view(1, CQ, 1, 1, 4)).to(dev)
+    if compact:
+        prev = torch.randn(B, CQp, Ho, Wo, 4, generator=g).to(dev)
+    else:
+        prev = torch.zeros(B, CQp, H + 2, WP, 4)
+        prev[:, :, 1:H + 1, :W] = torch.randn(B, CQp, H, W, 4, generator=g)
+        prev = prev.to(dev)
+    dw = (torch.randn(CQ, 9, 4, generator=g) / 3).to(dev)
+    pw = (torch.randn(C, C, generator=g) / C ** 0.5).to(dev)
+    scale, shift = (0.5 + torch.rand(C, generator=g)).to(dev), torch.randn(C, generator=g).to(dev)
+    scale[::3] *= -1.0  # negative folded BatchNorm scales: BatchNorm must come BEFORE the maxima
+    wr = (torch.randn(Cp, C, generator=g) / Cp ** 0.5).to(dev)
+    br = torch.randn(C, generator=g).to(dev)
+    st = N.stream_ptr()
+    xp = torch.zeros(B, CQo, H, WPx, 4, device=dev)
+    assert lib.orcai_sepconv_bn(N.ptr(a), B, C, H, W, k, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), C, 0, 2, N.ptr(xp), st) == 0
+    want = torch.full((B, CQo, Ho + 2, WPo, 4), 3.0, device=dev)
+    assert lib.orcai_pool_res_add(N.ptr(xp), N.ptr(prev), B, C, Cp, H, W, k, N.ptr(wr), N.ptr(br), N.ptr(want), 1 | (2 if compact else 0), st) == 0
+    got = torch.full((B, CQo, Ho + 2, WPo, 4), 3.0, device=dev)
+    before = lib.orcai_pool_fused(nt)
+    try:
+        rc = lib.orcai_sepconv_pool_res(N.ptr(a), N.ptr(prev), B, C, C, Cp, H, W, k, relu_in, N.ptr(dw), N.ptr(pw), N.ptr(scale), N.ptr(shift), 0, N.ptr(wr), N.ptr(br),
+                                        N.ptr(got), compact, st)
+    finally:
+        lib.orcai_pool_fused(before)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    diff = (got - want).abs()
+    assert torch.equal(got, want), (float(diff.max()), int((diff > 0).sum()), [int(v) for v in torch.nonzero(diff > 0)[0]] if (diff > 0).any() else None)
+    pads = got.clone()
+    pads[:, :, 1:Ho + 1, :Wo] = 3.0
+    assert float((pads - 3.0).abs().max()) == 0.0  # only the interior is written
+
+
+def test_fused_block_tail_refuses_other_shapes():
+    """The launcher answers ORCAI_E_UNSUPPORTED before touching anything for shapes the marching kernel does not have: the caller's two launches follow."""
+    from orcai_amd import _native as N
+
+    lib = N.lib()
+    t = torch.zeros(1 << 20, device="cuda")
+    p = N.ptr(t)
+    for C, Cp, H, W, k in ((40, 30, 368, 86, 3), (30, 16, 737, 171, 3), (30, 16, 736, 60, 3), (30, 16, 736, 171, 5), (16, 16, 736, 171, 3), (30, 20, 736, 171, 3)):
+        assert lib.orcai_sepconv_pool_res(p, p, 1, C, C, Cp, H, W, k, 0, p, p, p, p, 0, p, p, p, 0, N.stream_ptr()) == N.E_UNSUPPORTED, (C, Cp, H, W, k)
+    torch.cuda.synchronize()
+    assert float(t.abs().max()) == 0.0
