@@ -43,6 +43,9 @@ def kernel_costs():
         costs[f"b{b}/sep_b"] = _sep_cost(f, f, h, w, w_out=wx)
         # pool + residual: read the x-pooled s, read prev at the sampled (2i, 2j) pixels, write out
         costs[f"b{b}/pool_res"] = (4.0 * (h * wx * f + ho * wo * cin + ho * wo * f), 2.0 * ho * wo * cin * f)
+        # the second conv with the block's tail in its epilogue (orcai_sepconv_pool_res): a read once, prev at the sampled pixels, the block output written once --
+        # the x-pooled tensor of the two-launch path (h * wx * f, written and read back) does not exist
+        costs[f"b{b}/sep_b+pool_res"] = (4.0 * (h * w * f + ho * wo * cin + ho * wo * f), costs[f"b{b}/sep_b"][1] + costs[f"b{b}/pool_res"][1])
     costs["sep_f"] = _sep_cost(60, 36, 46, 11)
     # fused entry (orcai_conv0_sepconv): read the 1-channel snippet, write a1 and the (2i, 2j) subsample of the entry activation
     costs["conv0+b1/sep_a"] = (4.0 * (736 * 171 * (1 + 30) + 368 * 86 * 16), costs["conv0"][1] + costs["b1/sep_a"][1])
@@ -146,6 +149,8 @@ class PredictWorkload:
         if label == "sep_f":
             return "sepconv_kernel<3, 3>"  # Keras-reshape output layout: not a streaming shape
         blk, _, op = label.partition("/")
+        if blk in couts and op == "sep_b+pool_res":  # <CQ = input quads, RELU on load>
+            return f"sepconv_pool_march_kernel<{(couts[blk] + 3) // 4}, false>"
         if blk in couts and op in ("sep_a", "sep_b"):
             cin, cout = (cins[blk] if op == "sep_a" else couts[blk]), couts[blk]
             mt, cqr = (cout + 15) // 16, (cin + 3) // 4
@@ -165,7 +170,7 @@ class PredictWorkload:
 
     # the layers bracketed with HIP events inside the timed steps: the two heaviest launches of block 1; the second one
     # (sepconv_tile_kernel<2, 8, true, false, 8, false, 0, false>) is the top symbol of rocprofv3 --stats for this workload
-    DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b")
+    DOMINANT = ("conv0+b1/sep_a", "b1/sep_a", "b1/sep_b", "b1/sep_b+pool_res")
 
     def roofline(self):
         """Dominant kernel SYMBOL (as rocprofv3 names it): average launch duration from HIP events recorded on the launch stream
@@ -173,7 +178,7 @@ class PredictWorkload:
         are bracketed in the timed region (an event pair costs ~15 us of queue time); the per-layer table comes from one more
         step, after the timed region, with every launch bracketed."""
         timed_events = self.events
-        n_steps = max(1, len(timed_events.get("b1/sep_b", [])) // max(1, -(-self.n_snippets // self.chunk)))
+        n_steps = max(1, max(len(timed_events.get(k, [])) for k in ("b1/sep_b", "b1/sep_b+pool_res")) // max(1, -(-self.n_snippets // self.chunk)))
         self.events, self.model.kernel_event_labels = {}, None
         self.step(True)  # all layers bracketed, outside the timed region
         self.drain()
@@ -570,6 +575,66 @@ def _train_flops_per_snippet(filters, k=3, units=128, H=736, W=171):
     return 6.0 * mac
 
 
+def _h_call_symbol(name, a):
+    """Kernel symbol of an f16-path launcher call (csrc/half_fwd.hip, half_bwd.hip), as tools/summarize_pmc.py names it in the PMC tables."""
+    mt = lambda c: (c + 15) // 16  # noqa: E731
+    if name == "orcai_h_sepconv":  # in,B,Cin,H,W,ksize_planes,ktap,relu_in,dw,pwf,scale,shift,Cout,relu_out,out_layout,H2,W2,out,u_out,stream
+        ktap, cout, layout, u_out = a[6], a[12], a[14], a[18]
+        if ktap == 3 and layout in (0, 2) and not (layout == 2 and u_out):
+            return f"sepconv_h_ftile_kernel<{mt(cout)}, {'true' if layout == 2 else 'false'}, {'true' if u_out else 'false'}, false, false>"
+        return f"sepconv_h_kernel<{ktap}, {mt(cout)}>"
+    if name == "orcai_h_sepconv_stats":
+        return f"sepconv_h_ftile_kernel<{mt(a[10])}, false, true, true, false>"
+    if name == "orcai_h_sepconv_stats_bn":
+        return f"sepconv_h_ftile_kernel<{mt(a[14])}, false, true, true, true>"
+    if name == "orcai_h_bn_bwd_pointwise":  # dy,v,B,C,H,W,ksize,mean,var,gamma,beta,eps,relu,scratch,sums_ready,dbeta,dgamma,wt,Cin,dv,du,stream
+        return f"bn_bwd_pw_h_kernel<{mt(a[18])}>"
+    if name in ("orcai_h_dw_bwd_fused", "orcai_h_dw_bwd_fused_res"):  # x,du,B,C,H,W,relu_in,dw_rev,dr,dW,epi,bn_mean,...
+        W = a[5]
+        best, lanes = 64, ((W + 61) // 62) * 64
+        if ((W + 29) // 30) * 32 < lanes:
+            best, lanes = 32, ((W + 29) // 30) * 32
+        if ((W + 13) // 14) * 16 < lanes:
+            best = 16
+        if name.endswith("_res"):
+            return f"dw_bwd_march_h_kernel<{best}, 2, true, true>"
+        return f"dw_bwd_march_h_kernel<{best}, {a[10]}, {'true' if a[11] is not None else 'false'}, false>"
+    if name == "orcai_h_pool_res_add":
+        return f"pool_res_add_h_kernel<{mt(a[3])}>"
+    return {"orcai_h_outer_reduce": "outer_reduce_h_kernel", "orcai_h_pool_bwd_bn": "pool_bwd_h_kernel", "orcai_h_bn_planes_apply": "bn_planes_apply_h_kernel",
+            "orcai_h_planes_sum": "planes_sums_h_kernel", "orcai_h_bn_planes_stats": "planes_sums_h_kernel", "orcai_h_conv0_affine": "conv0_h_kernel<3>",
+            "orcai_h_conv0_bn_bwd": "conv0_bn_wgrad_h_kernel<3, 8>", "orcai_h_conv0_bn_bwd_ready": "conv0_bn_wgrad_h_kernel<3, 8>"}.get(name, name)
+
+
+def _h_call_bytes(name, a):
+    """Algorithmic HBM bytes of one f16-path launcher call (2 bytes per element, each tensor once at its true channel count); None where no plane streams."""
+    if name == "orcai_h_sepconv":
+        B, Cin, H, W, Cout, layout, u_out = a[1], a[2], a[3], a[4], a[12], a[14], a[18]
+        if layout == 1:
+            return 2.0 * B * H * W * Cin + 4.0 * B * H * W * Cout + (2.0 * B * H * W * Cin if u_out else 0)
+        return 2.0 * B * H * W * (Cin + Cout + (Cin if u_out else 0))
+    if name == "orcai_h_sepconv_stats":
+        return 2.0 * a[1] * a[3] * a[4] * (2 * a[2] + a[10])
+    if name == "orcai_h_sepconv_stats_bn":
+        return 2.0 * a[1] * a[3] * a[4] * (2 * a[2] + a[14])
+    if name == "orcai_h_bn_bwd_pointwise":
+        B, C, H, W, Cin = a[2], a[3], a[4], a[5], a[18]
+        return 2.0 * B * H * W * (3 * C + Cin)
+    if name in ("orcai_h_dw_bwd_fused", "orcai_h_dw_bwd_fused_res"):
+        return 2.0 * a[2] * a[4] * a[5] * 3 * a[3]
+    if name == "orcai_h_outer_reduce":  # A,Ca,Bq,Cb,B,H,W,...
+        return 2.0 * a[4] * a[5] * a[6] * (a[1] + a[3])
+    if name == "orcai_h_pool_bwd_bn":  # dout,ybn,B,C,H,W,...: dout at the pooled resolution, v read, dy written
+        return 2.0 * a[2] * a[4] * a[5] * a[3] * 2.25
+    if name == "orcai_h_pool_res_add":  # s,prev,B,C,Cp,H,W,...: v_b read, prev at the sampled pixels, the block output
+        return 2.0 * a[2] * a[5] * a[6] * (a[3] + 0.25 * a[4] + 0.25 * a[3])
+    if name == "orcai_h_bn_planes_apply":  # v,B,C,H,W,...
+        return 2.0 * a[1] * a[3] * a[4] * 2 * a[2]
+    if name in ("orcai_h_planes_sum", "orcai_h_bn_planes_stats"):
+        return 2.0 * a[1] * a[3] * a[4] * a[2]
+    return None
+
+
 class HpsearchWorkload:
     """BASELINE configs[4]: the three CNN width variants of the reference's hyper-parameter file (lstm_units 128, kernel 3, dropout
     0.5), batch 64 per GPU, data parallel (one RCCL all-reduce of each variant's flat gradient bucket per step), on the f16 path:
@@ -597,12 +662,12 @@ class HpsearchWorkload:
 
         def dominant(name, args):  # the f16 separable convolutions of block 1 (k = 3 taps, two output tiles or the widest plane)
             # (the training forward launches it through orcai_h_sepconv_stats: BatchNorm statistics in the epilogue, a 3 us zero fill in the bracket)
-            return (name == "orcai_h_sepconv" and args[6] == 3 and args[3] >= 736) or (name == "orcai_h_sepconv_stats" and args[3] >= 736)
+            return (name == "orcai_h_sepconv" and args[6] == 3 and args[3] >= 736) or (name in ("orcai_h_sepconv_stats", "orcai_h_sepconv_stats_bn") and args[3] >= 736)
 
         for v in self.variants:
             model = ResNetLSTM((736, 171, 1), 7, HPS_FILTER_SETS[v], 3, 0.5, 128, seed=1, precision=precision)
             tr = Trainer(model, 1e-4, seed=rank)
-            tl = _TimedLib(tr.trunk.lib, dominant)
+            tl = _TimedLib(tr.trunk.lib, lambda name, args: False)  # nothing is bracketed inside the timed steps: roofline() ranks its own extra step
             tr.trunk.lib = tl
             tr.head.lib = tl
             self.trainers[v], self.timed[v] = tr, tl
@@ -632,25 +697,37 @@ class HpsearchWorkload:
         return out
 
     def roofline(self):
-        """Dominant kernel symbol of the sweep: the f16 separable-convolution kernel on block-1 planes (sepconv_h_ftile_kernel<MT, ...>):
-        HIP events around its launches inside the timed steps; algorithmic bytes = f16 tensors read / written once per launch."""
-        t, by, n = 0.0, 0.0, 0
+        """The dominant kernel SYMBOL of the sweep against HBM, ranked from this run's own table like TrainWorkload.roofline: one more sweep step after the
+        timed region with every orcai_* launcher bracketed by HIP events, the calls grouped by the template instantiation they run (_h_call_symbol: the
+        names rocprofv3 --stats prints, _Float16 symbols demangled by tools/summarize_pmc.py's rule) and priced with their algorithmic bytes (_h_call_bytes:
+        every f16 tensor read / written once at its true channel count).  `traffic`: HBM bytes per launch of that symbol from the newest PMC table
+        (section hpsearch_f16_set3: the counters were collected on the widest variant)."""
         for v in self.variants:
-            for a, b, args in (self.timed[v].events or {}).get("orcai_h_sepconv", []):
-                B, Cin, H, W, Cout, layout, u_out = args[1], args[2], args[3], args[4], args[12], args[14], args[18]
-                t += a.elapsed_time(b)
-                by += 2.0 * B * H * W * (Cin + Cout + (Cin if u_out else 0))
-                n += 1
-            for a, b, args in (self.timed[v].events or {}).get("orcai_h_sepconv_stats", []):  # in, out and the depthwise output
-                B, Cin, H, W, Cout = args[1], args[2], args[3], args[4], args[10]
-                t += a.elapsed_time(b)
-                by += 2.0 * B * H * W * (2 * Cin + Cout)
-                n += 1
-        out = {"bound": "hbm", "kernel": "sepconv_h_ftile_kernel<MT, XP, UOUT> on block-1 planes (736 x 171), all variants", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
-        if n:
-            ach = by / (t * 1e-3) / 1e9
-            out.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_ms": round(t / n, 4), "launches": n,
-                        "algorithmic_bytes_per_launch": round(by / n)})
+            self.timed[v].mode, self.timed[v].events = "all", {}
+        self.step(False)
+        torch.cuda.synchronize()
+        by_symbol = {}
+        for v in self.variants:
+            for name, calls in self.timed[v].events.items():
+                for e0, e1, args in calls:
+                    sym, by = _h_call_symbol(name, args), _h_call_bytes(name, args)
+                    d = by_symbol.setdefault(sym, {"ms": 0.0, "bytes": 0.0, "n": 0, "priced": True, "launcher": name})
+                    d["ms"] += e0.elapsed_time(e1)
+                    d["n"] += 1
+                    d["priced"] = d["priced"] and by is not None
+                    d["bytes"] += by or 0.0
+            self.timed[v].mode, self.timed[v].events = "dominant", None
+        out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "measured": "one fully bracketed sweep step after the timed region",
+               "symbol_ms_per_sweep_step_instrumented": {k: round(d["ms"], 3) for k, d in sorted(by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:10]}}
+        priced = {k: d for k, d in by_symbol.items() if d["priced"] and d["bytes"] > 0}
+        if priced:
+            top = max(priced, key=lambda k: priced[k]["ms"])
+            d = priced[top]
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            out.update({"kernel": top, "launcher": d["launcher"], "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "kernel_ms": round(d["ms"] / d["n"], 4),
+                        "launches_per_sweep_step": d["n"], "algorithmic_bytes_per_launch": round(d["bytes"] / d["n"]),
+                        "traffic": measured_traffic_symbol(top, "hpsearch_f16_set3"), "traffic_from": "PMC passes on the set3 variant alone (mean per launch of the symbol)",
+                        "top_symbol_of_full_table": max(by_symbol, key=lambda k: by_symbol[k]["ms"])})
         out["variants"] = self.per_variant()
         return out
 

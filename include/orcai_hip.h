@@ -349,6 +349,12 @@ int orcai_bn_finish_sharded(const double* shards, int B, int C, int H, int W, fl
  * taken on the f32 values before their rounding to f16). */
 int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
                           void* out, void* u_out, double* shards, void* stream);
+/* orcai_h_sepconv_stats whose input planes hold the PRE-normalisation tensor v of a BatchNorm + ReLU (the f16 twin of orcai_sepconv_planes_stats_bn):
+ * y = f16(relu(fma(v, gamma * rsqrt(var + eps), beta - mean * ...))) is formed on load -- the value orcai_h_bn_planes_apply stores, bit for bit -- and zero
+ * outside the image, so the training forward never materialises y_a (architectures.py:172-189 in training mode). */
+int orcai_h_sepconv_stats_bn(const void* v_in, int B, int Cin, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                             float in_eps, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout, void* out, void* u_out, double* shards,
+                             void* stream);
 int orcai_h_bn_finish_sharded(const double* shards, int B, int C, int H, int W, float* mean, float* var, void* stream);
 int orcai_bn_planes_apply(const float* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma, const float* beta,
                           float eps, int relu, float* y, void* stream);
@@ -470,6 +476,15 @@ int orcai_dropout_mask_dev(float* mask, int64_t n, const uint64_t* counter, uint
 int orcai_adam_step_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* lr, float b1, float b2, float eps, const uint64_t* counter, float gscale,
                         void* stream);
 int orcai_counter_advance(uint64_t* counter, void* stream);
+/* One clear per training step for every reduction scratch buffer: orcai_scratch_arena zeroes `bytes` (rounded down to 32-KiB slots, at most 1024) at `base`
+ * with ONE launch on `stream` and registers the range; until the next call, a launcher whose accumulator argument (the `scratch*` / `shards` pointers of the
+ * BatchNorm, pooling and weight-gradient entry points) lies inside a slot that no launcher has taken since skips its own zero-fill launch.  Any other pointer,
+ * a slot handed to a second launcher, or no registered arena: the launcher clears its accumulator itself, as before.  The caller hands every accumulating
+ * launcher of a step its own slot (orcai_amd/training.py: TrunkTrainer._fresh); base = NULL unregisters.  Host-side state: one stream, one step at a time.
+ * orcai_arena_take is the query the launchers use (1 = skip the fill; marks the slot taken). */
+int orcai_scratch_arena(void* base, size_t bytes, void* stream);
+int orcai_arena_take(const void* p, size_t bytes);
+
 /* A voided step (the f16 path under its static loss scale: Keras' LossScaleOptimizer skips the update when a gradient is not finite).
  *   orcai_step_ok: ok[0] = 1 if every value of g[0, ng) and stats[0, ns) (this step's BatchNorm batch statistics; ns may be 0) is
  *   finite, else 0, and skipped[0] += 1; nothing returns to the host, so the decision stays inside a captured graph.

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "orcai_sepconv_planes_epi": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orcai_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "orcai_h_sepconv_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
+    "orcai_h_sepconv_stats_bn": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
     "orcai_h_bn_finish_sharded": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3),
     "orcai_bn_planes_stats": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4),
     "orcai_bn_planes_apply": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
@@ -131,6 +132,8 @@ _SIGNATURES = {
     "orcai_adam_step_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "orcai_counter_advance": (C.c_int, [C.c_void_p, C.c_void_p]),
     "orcai_step_ok": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orcai_scratch_arena": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orcai_arena_take": (C.c_int, [C.c_void_p, C.c_size_t]),
     "orcai_poison_if_nonfinite": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "orcai_adam_step_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_ema_update_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

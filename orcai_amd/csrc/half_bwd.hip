@@ -652,10 +652,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
 // their two shifted copies in registers (packed f16), a step loads one du row and one x row, three steps ahead, and stores one dr row.
 // BNIN: x is the pre-normalisation tensor v; y = f16(relu(fma(v, s, t))) is formed on load -- the value bn_planes_apply_h_kernel stored -- so the
 // materialised y_a is not read by the backward pass at all.
-struct InBnH {
-  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;
-  float eps = 0.0f;
-};
+// (struct InBnH: half_planes.h)
 
 // acc = fma(f32(half HI ? upper : lower of d), y, acc)
 __device__ __forceinline__ void mixacc(int hi, float& acc, uint32_t d, float y) {  // hi: a constant after unrolling

@@ -463,18 +463,21 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const float* __restrict__ A
 // two slots, and every wave reads its three rows back with ds_read_b128.  One raw barrier per octet; counted vmcnt waits leave the
 // depthwise-output store of the training forward in flight.  Same arithmetic in the same order as sepconv_h_kernel.
 // =========================================================================================
-template <int MT, bool XP, bool UOUT, bool STATS = false>
+// BNIN: the input planes hold the pre-normalisation tensor of a BatchNorm (+ ReLU): normalised where a row leaves LDS, zero outside the image (the
+// planes' pads hold v = 0, but "same" padding pads y) -- y_a is never materialised by the training forward (orcai_h_sepconv_stats_bn).
+template <int MT, bool XP, bool UOUT, bool STATS = false, bool BNIN = false>
 __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restrict__ in /*[B][CO][HP][WP][8]*/, int Cin, int H, int W, int WP, int relu_in,
                                                               const h16* __restrict__ dw /*[CO][9][8]*/, const h16* __restrict__ pwf /*[KG][MT][64][8]*/,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                               void* __restrict__ out, int tasks, uint32_t magic_WP, int nchunk, h16* __restrict__ u_out,
-                                                              double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/8)][16]*/) {
+                                                              double* __restrict__ shards = nullptr /*STATS: [32][ceil(Cout/8)][16]*/, InBnH ib = InBnH{}) {
   using orcai_lds::glds16;
   using orcai_lds::wait_vm_barrier;
   constexpr int NWV = 8, KK = 9, R = 1, lo = XP ? 2 : 1, VAL = 64 - 2 * lo;
   static_assert(!(XP && UOUT), "the training forward writes planes");
   static_assert(!STATS || !XP, "statistics epilogue: plane output");
   __shared__ float stat_s[STATS ? NWV : 1][4][STATS ? 8 * MT : 1];  // STATS: per wave and 16-lane row, the row's sums and sums of squares
+  __shared__ __attribute__((aligned(16))) float inbn_s[BNIN ? 2 : 1][BNIN ? 64 : 4];  // BNIN: folded scale, shift per input channel (<= 64)
   extern __shared__ __attribute__((aligned(16))) h16x8 smem_hf[];
   const int CO = (Cin + 7) >> 3, COo = (Cout + 7) >> 3, KG = (CO + 3) >> 2;
   h16x8* rows_s = smem_hf;                    // [2][nchunk * 64] pixels
@@ -503,12 +506,25 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
   };
   issue(0);
   for (int i = threadIdx.x; i < KG * MT * 64; i += 64 * NWV) pw_s[i] = reinterpret_cast<const h16x8*>(pwf)[i];
+  if (BNIN && threadIdx.x < 64) {
+    const int ci = threadIdx.x, cc = ci < Cin ? ci : 0;
+    const float sc = ib.gamma[cc] * rsqrtf(ib.var[cc] + ib.eps);  // exactly bn_planes_apply_h_kernel's arithmetic
+    inbn_s[0][ci] = ci < Cin ? sc : 0.0f;
+    inbn_s[1][ci] = ci < Cin ? ib.beta[cc] - ib.mean[cc] * sc : 0.0f;
+  }
   __syncthreads();
 
   const int task = bx * NWV + wave;
   const bool wave_live = task < tasks;
   const int qbase = R * WP + task * VAL - lo;
   const int q = qbase + lane;
+  int bn_row = 0;
+  bool bn_colok = false;
+  if (BNIN) {  // this lane's pixel of the flat padded plane: row / column once per window
+    const int qq = q < 0 ? 0 : q;
+    bn_row = (int)__umulhi((uint32_t)qq, magic_WP);
+    bn_colok = q >= 0 && (qq - bn_row * WP) < W;
+  }
   bool u_live = false;
   if (UOUT) {
     const int urow = (int)__umulhi((uint32_t)q, magic_WP);
@@ -533,7 +549,20 @@ __global__ __launch_bounds__(512) void sepconv_h_ftile_kernel(const h16* __restr
         if (u_any && o > 0) wait_vm_barrier<1>(); else wait_vm_barrier<0>();
         if (o + 1 < CO) issue(o + 1);
         const h16x8* rs = rbase + (o & 1) * nchunk * 64;
-        const h16x8 cur[3] = {rs[0], rs[WP], rs[2 * WP]};
+        h16x8 cur[3] = {rs[0], rs[WP], rs[2 * WP]};
+        if (BNIN) {
+          const float4 s0 = reinterpret_cast<const float4*>(inbn_s[0])[2 * o], s1 = reinterpret_cast<const float4*>(inbn_s[0])[2 * o + 1];
+          const float4 t0 = reinterpret_cast<const float4*>(inbn_s[1])[2 * o], t1 = reinterpret_cast<const float4*>(inbn_s[1])[2 * o + 1];
+          const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const bool ok = bn_colok && (bn_row + dy - 1) >= R && (bn_row + dy - 1) < R + H;  // padded-plane row of this lane's pixel, one up / same / one down
+            h16x8 y;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) y[k8] = (h16)fmaxf(fmaf((float)cur[dy][k8], sv[k8], tv[k8]), 0.0f);  // f32 fma, ReLU, ONE rounding to f16: the stored y_a
+            cur[dy] = ok ? y : zero_h();
+          }
+        }
         const h16x8 dd = relu_in ? dw_octet<3, true>(cur, dw + (int64_t)o * KK * 8) : dw_octet<3, false>(cur, dw + (int64_t)o * KK * 8);
         if (UOUT) {
           if (u_live) reinterpret_cast<h16x8*>(u_out)[((int64_t)b * CO + o) * plane + q] = dd;
@@ -650,6 +679,7 @@ struct SepArgsH {
   int B, Cin, H, W, WP, RP, Cout, relu_in, relu_out, out_layout, H2, WP2;
   h16* u_out;
   double* shards = nullptr;  // flat tiles with the depthwise-output store: BatchNorm statistics of the output in the epilogue
+  InBnH ib;                  // ib.mean != nullptr: BatchNorm + ReLU of the input applied on load (with the statistics epilogue)
 };
 
 template <int KS, int MT>
@@ -670,8 +700,12 @@ int launch_sepconv_h(hipStream_t st, const SepArgsH& a) {
                      a.shift, a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out)
       if (a.out_layout == 2) ORCAI_HFTILE(true, false);
       else if (a.u_out && a.shards) {
-        hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, false, true, true>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, a.shift,
-                           a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
+        if (a.ib.mean)
+          hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, false, true, true, true>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, 0, a.dw, a.pwf, a.scale, a.shift,
+                             a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards, a.ib);
+        else
+          hipLaunchKernelGGL((sepconv_h_ftile_kernel<MT, false, true, true>), tgrid, dim3(512), lds, st, a.in, a.Cin, a.H, a.W, a.WP, a.relu_in, a.dw, a.pwf, a.scale, a.shift,
+                             a.Cout, a.relu_out, a.out, tasks, magic_for(a.WP), nchunk, a.u_out, a.shards);
       }
       else if (a.u_out) ORCAI_HFTILE(false, true);
       else ORCAI_HFTILE(false, false);
@@ -735,14 +769,14 @@ int orcai_h_sepconv(const void* in, int B, int Cin, int H, int W, int ksize_plan
   }
 }
 
-int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
-                          void* out, void* u_out, double* shards, void* stream) {
+static int h_sepconv_stats_impl(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
+                                void* out, void* u_out, double* shards, const InBnH& ib, void* stream) {
   if (!in || !dw || !pwf || !scale || !shift || !out || !u_out || !shards || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return ORCAI_E_BADARG;
   if (Cout > 64 || Cin > 64 || (((uintptr_t)in | (uintptr_t)dw | (uintptr_t)pwf | (uintptr_t)out | (uintptr_t)u_out) & 15) || B > 65535) return ORCAI_E_UNSUPPORTED;
   // the launcher's own conditions for the flat-tile kernel, checked BEFORE anything is touched
   const int WP = orcai_padded_width(W, 3), nchunk = (7 * 62 + 64 + 2 * WP + 63) / 64, KG = ((Cin + 7) / 8 + 3) / 4, MTv = (Cout + 15) / 16;
   const size_t lds = ((size_t)2 * nchunk * 64 + (size_t)KG * MTv * 64) * 16;
-  if (orcai_sepconv_tile_mode(-1) == 0 || nchunk > 24 || lds + 4096 > 64 * 1024 /*+ the kernel's static statistics slots*/ || (int64_t)((Cout + 7) / 8) * (H + 2) * WP >= (1ll << 27) ||
+  if (orcai_sepconv_tile_mode(-1) == 0 || nchunk > 24 || lds + 4096 + 512 > 64 * 1024 /*+ the kernel's static statistics slots and folded input BatchNorm*/ || (int64_t)((Cout + 7) / 8) * (H + 2) * WP >= (1ll << 27) ||
       (int64_t)(H + 2) * WP >= (1ll << 29))
     return ORCAI_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -752,7 +786,22 @@ int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu
     if (e != hipSuccess) return (int)e;
   }
   SepArgsH a{(const h16*)in, (const h16*)dw, (const h16*)pwf, scale, shift, out, B, Cin, H, W, WP, 1, Cout, relu_in, 0, 0, 0, 0, (h16*)u_out, shards};
+  a.ib = ib;
   return launch_sepconv_h_mt<3>(st, a);
+}
+
+int orcai_h_sepconv_stats(const void* in, int B, int Cin, int H, int W, int relu_in, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout,
+                          void* out, void* u_out, double* shards, void* stream) {
+  return h_sepconv_stats_impl(in, B, Cin, H, W, relu_in, dw, pwf, scale, shift, Cout, out, u_out, shards, InBnH{}, stream);
+}
+
+int orcai_h_sepconv_stats_bn(const void* v_in, int B, int Cin, int H, int W, const float* in_mean, const float* in_var, const float* in_gamma, const float* in_beta,
+                             float in_eps, const void* dw, const void* pwf, const float* scale, const float* shift, int Cout, void* out, void* u_out, double* shards,
+                             void* stream) {
+  if (!in_mean || !in_var || !in_gamma || !in_beta) return ORCAI_E_BADARG;
+  InBnH ib;
+  ib.mean = in_mean; ib.var = in_var; ib.gamma = in_gamma; ib.beta = in_beta; ib.eps = in_eps;
+  return h_sepconv_stats_impl(v_in, B, Cin, H, W, 0, dw, pwf, scale, shift, Cout, out, u_out, shards, ib, stream);
 }
 
 int orcai_h_pool_res_add(const void* s, const void* prev, int B, int C, int Cp, int H, int W, int ksize, const void* wrf, const float* br, void* out, int xpooled,

@@ -31,6 +31,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma_h(h16x8 a, h16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// BatchNorm (+ ReLU) of a kernel's INPUT applied on load (BNIN): the planes hold the pre-normalisation tensor v, y = f16(relu(fma(v, s, t))) with
+// s = gamma * rsqrt(var + eps), t = beta - mean * s is formed where a pixel is used -- the value bn_planes_apply_h_kernel would have stored.
+struct InBnH {
+  const float *mean = nullptr, *var = nullptr, *gamma = nullptr, *beta = nullptr;
+  float eps = 0.0f;
+};
+
 inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }  // __umulhi(n, magic) == n / d while n*d < 2^32
 
 // XCD-aware block order (see model_fwd.hip): every XCD gets one contiguous band of the (snippet, window) space.

@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
                                                                    const float* __restrict__ scale, const float* __restrict__ shift, int Cout, int relu_out,
                                                                    const float* __restrict__ prev, int Cp, int prev_compact, const float* __restrict__ wr /*[Cp][Cout]*/,
                                                                    const float* __restrict__ br, float* __restrict__ out /*[B][CQo][Ho+2][WPo][4]*/, int Ho, int Wo, int WPo,
-                                                                   int nstrip, int NT, int dbg /*timing experiments: bit 0 = no tail items*/) {
+                                                                   int nstrip, int NT) {
   constexpr int KK = 9, R = 1, lo = 2, VAL = 60, TR = 8, MT = 2, NPX = VAL / 2, XROW = 8 * NPX * 4;  // XROW floats per exchange row: [8 quads][NPX][4]
   constexpr int SLOT = (TR + 2) * 256;  // floats per input slot: [tile row][lane][4]
   // one array, so that every pointer below is an LDS pointer to the compiler: [2 input slots][7 exchange rows: rows 2 .. 7 of the tile, then the carry
@@ -1045,7 +1045,9 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
   __shared__ __attribute__((aligned(16))) float lds_f[2 * SLOT + 7 * XROW];
   __shared__ float pw_s[CQ * 4 * 16 * MT];
   __shared__ float sc_s[MT * 16], sh_s[MT * 16];
-  __shared__ float wr_s[16 * MT * 16], br_s[MT * 16];  // residual conv: [ci][co] (zero outside Cp x Cout), bias -- read in the tail (kept in registers they spill)
+  __shared__ float wr_s[16 * MT * 16];  // residual conv weights [ci][co] (zero outside Cp x Cout), read in the tail (kept in registers they spill)
+  // LDS: 53 760 B for 8 input quads = 42 allocation granules of 1 280 B -- a third of a compute unit's 128 granules exactly; one granule more and only
+  // TWO workgroups are resident (the first version, 54 144 B, ran 20 % slower for it)
   static_assert(2 * XROW <= (TR + 2) * 256, "two exchange rows alias one input slot");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int bx, b;
@@ -1054,8 +1056,9 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
   const int NPS = 4 * NT - 1;  // pooled rows per segment
   const int p0 = seg * NPS, pend = (p0 + NPS < Ho) ? p0 + NPS : Ho;
   const int rb = 2 * p0, c0 = strip * VAL;
-  const int need = 2 * (pend - p0) + 1, have = H - rb;  // conv rows the segment's windows touch / rows of the image below rb (H even: window Ho - 1 has two rows)
-  const int ntile = ((need < have ? need : have) + TR - 1) / TR;
+  // conv rows the segment's windows touch (H even: the image's last window has two rows; when the image ends on a tile boundary one more tile --
+  // all of its rows below the image, its results discarded -- closes that window through the carry: 1 tile in 93 for orcai-V1's block 1)
+  const int ntile = (2 * (pend - p0) + 1 + TR - 1) / TR;
   const int lk = lane >> 4, lj = lane & 15;
   const int plane = (H + 2 * R) * WP;
   const int CQo = (Cout + 3) >> 2, CQp = (Cp + 3) >> 2;
@@ -1094,12 +1097,10 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
     const bool ok = ci < Cp && co < Cout;
     const float av = wr[ok ? ci * Cout + co : 0];
     wr_s[threadIdx.x] = ok ? av : 0.0f;
-    if (threadIdx.x < MT * 16) {
-      const float bv = br[co < Cout ? co : 0];
-      br_s[threadIdx.x] = co < Cout ? bv : 0.0f;
-    }
   }
-  const int tm = wave & 1, tk = (wave >> 1) - 1;  // this wave's tail item: output tile tm of pooled row 4 t + tk
+  // this wave's tail item: output tile tm of pooled row 4 t + tk.  The carried window (tk = -1, which also refreshes the carry) goes to waves 6 and 7:
+  // waves 0 and 1 already fetch two rows per quad
+  const int tm = wave & 1, tk = (wave >> 1) == 3 ? -1 : (wave >> 1);
   __syncthreads();
   const float lo_out = relu_out ? 0.0f : -INFINITY;
   const int plane_p = prev_compact ? Ho * Wo : plane, plane_o = (Ho + 2 * R) * WPo;
@@ -1123,6 +1124,17 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
     asm volatile("" : "+s"(opaque_zero));
     plane16 = (int64_t)plane * 16 + opaque_zero;  // (and the per-quad plane bases are formed where they are used)
     const float* dwt = static_cast<const float*>(__builtin_assume_aligned(dw + opaque_zero, 16));
+    const int pr = p0 + 4 * t + tk;  // this wave's pooled row in the tail (tk = -1: the window the previous tile left open, closed by this tile's first row)
+    const bool item = (tk >= 0 || t > 0) && pr < pend;  // wave-uniform
+    // residual operand of the tail: prev at the pooled pixel (2 pr, 2 j), lane = pooled pixel of the strip (float4 index inside one quad plane);
+    // derived where it is used, from a fresh lane id each time -- one more register alive across the quad loop spills
+    auto prev_pixel = [&]() {
+      int l;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+      const int jq = (c0 >> 1) + (l < NPX ? l : NPX - 1);
+      const int jqc = jq < Wo ? jq : Wo - 1;
+      return prev_compact ? pr * Wo + jqc : (2 * pr + R) * WP + 2 * jqc;
+    };
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1138,6 +1150,7 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
         const int sl = (cq & 1) ^ par;
         if (cq + 1 < CQr) issue(t, cq + 1, sl ^ 1, lane_t);
         else if (t + 1 < ntile) issue(t + 1, 0, sl ^ 1, lane_t);  // lands during the tail
+
         float4 rows[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) rows[dy] = *reinterpret_cast<const float4*>(&lds_f[sl * SLOT + (wave + dy) * 256 + lane_t * 4]);
@@ -1156,23 +1169,34 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
           for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
       }
     }
-    // ---- the tail's operands that come from HBM are requested NOW, a barrier pair and the epilogue arithmetic ahead of their use: prev at the pooled
-    // pixel (2 pr, 2 j), lane = pooled pixel of the strip, 4 channels per load.  Everything lane-dependent of the tail is derived from an opaque copy
-    // of the lane id INSIDE the tile loop: hoisted out of it, two dozen loop-invariant registers are spilled and come back through scratch memory.
-    const int pr = p0 + 4 * t + tk;  // this wave's pooled row (tk = -1: the window the previous tile left open, closed by this tile's first row)
-    const bool item = (tk >= 0 || t > 0) && pr < pend;  // wave-uniform
-    // the segment's (= the image's) last window has two rows when the image ends with this tile: closed here, by waves 0 and 1 as a second item
-    const int pr_last = p0 + 4 * t + 3;
-    const bool item2 = tk < 0 && pr_last < pend && r0 + TR >= H;
+    // ---- the tail's operands that come from HBM: prev at the pooled pixel (2 pr, 2 j), lane = pooled pixel of the strip, 4 channels per load
+    // (always four quads: quads past Cp re-read quad 0 against zero weights)
     float4 pv[4];
-    auto request_prev = [&](int prow) {
-      const int jq = (c0 >> 1) + (lane_t < NPX ? lane_t : NPX - 1);
-      const int jqc = jq < Wo ? jq : Wo - 1;
-      const int srcpix = prev_compact ? prow * Wo + jqc : (2 * prow + R) * WP + 2 * jqc;
+    auto request_prev = [&]() {
+      const int srcpix = prev_pixel();
 #pragma unroll
       for (int cq = 0; cq < 4; ++cq) pv[cq] = prevb[(int64_t)(cq < CQp ? cq : 0) * plane_p + srcpix];
     };
-    if (item && !(dbg & 1)) request_prev(pr);
+    // residual 1x1 conv of prev at the wave's 30 pooled pixels for output tile tm: pv (lane = pixel) -> B fragments by the 4x4 lane-row transpose,
+    // the weights' A fragments from LDS, one MFMA chain per 16-pixel tile in pool_res_add_x_kernel's order
+    f32x4 racc[2];
+    auto residual = [&]() {
+      float wa[4];
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) wa[cq] = wr_s[(cq * 4 + tlk) * 32 + tm * 16 + tlj];
+      racc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      racc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cq = 0; cq < 4; ++cq) {
+        float d[4] = {pv[cq].x, pv[cq].y, pv[cq].z, pv[cq].w};
+        swap32(d[0], d[2]);
+        swap32(d[1], d[3]);
+        swap16(d[0], d[1]);
+        swap16(d[2], d[3]);
+        racc[0] = mfma16(wa[cq], d[0], racc[0]);
+        racc[1] = mfma16(wa[cq], d[1], racc[1]);
+      }
+    };
 
     // ---- folded BatchNorm (+ ReLU) and the column-pair maximum, exactly sepconv_tile_kernel<.., XP>'s epilogue; the values stay in `acc`
 #pragma unroll
@@ -1207,41 +1231,30 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
         }
       }
     }
+    if (item) {  // between the exchange writes and their barrier (the accumulators are dead): what a wave would otherwise spend waiting for the others
+      request_prev();
+      residual();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // E1: the tile's eight x-pooled rows are in LDS
 
-    // ---- tail: pooled row `prow` of output tile tm = max of the exchange rows pa, pb, pc (+ residual conv of prev, bias) -> out
+    // ---- tail: pooled row `prow` of output tile tm = max of the exchange rows pa, pb, pc, + (residual + bias) -> out
     float* carry = &lds_f[2 * SLOT + 6 * XROW];
     auto finish = [&](int prow, const float* pa, const float* pb, const float* pc) {
-      float4 mx[2];
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int px = 16 * t2 + tlj, pxc = px < NPX ? px : NPX - 1;
-        const int idx = ((tm * 4 + tlk) * NPX + pxc) * 4;
-        const float4 a = *reinterpret_cast<const float4*>(&pa[idx]), bq = *reinterpret_cast<const float4*>(&pb[idx]), c = *reinterpret_cast<const float4*>(&pc[idx]);
-        mx[t2] = make_float4(fmaxf(fmaxf(a.x, bq.x), c.x), fmaxf(fmaxf(a.y, bq.y), c.y), fmaxf(fmaxf(a.z, bq.z), c.z), fmaxf(fmaxf(a.w, bq.w), c.w));
-      }
-      f32x4 racc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int cq = 0; cq < 4; ++cq) {
-        if (cq < CQp) {
-          float d[4] = {pv[cq].x, pv[cq].y, pv[cq].z, pv[cq].w};
-          swap32(d[0], d[2]);
-          swap32(d[1], d[3]);
-          swap16(d[0], d[1]);
-          swap16(d[2], d[3]);
-          const float wa = wr_s[(cq * 4 + tlk) * 32 + tm * 16 + tlj];
-          racc[0] = mfma16(wa, d[0], racc[0]);
-          racc[1] = mfma16(wa, d[1], racc[1]);
-        }
-      }
       const int oq = tm * 4 + tlk;
-      const float4 br4 = reinterpret_cast<const float4*>(br_s)[oq];
-      const float brr[4] = {br4.x, br4.y, br4.z, br4.w};
+      float brr[4];  // residual bias of the lane's four output channels (four cached 4-byte loads: no LDS left for them)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = oq * 4 + r;
+        const float bv = br[co < Cout ? co : 0];
+        brr[r] = co < Cout ? bv : 0.0f;
+      }
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2) {
-        const int px = 16 * t2 + tlj, j = (c0 >> 1) + px;
+        const int px = 16 * t2 + tlj, pxc = px < NPX ? px : NPX - 1, j = (c0 >> 1) + px;
+        const int idx = (oq * NPX + pxc) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(&pa[idx]), bq = *reinterpret_cast<const float4*>(&pb[idx]), c = *reinterpret_cast<const float4*>(&pc[idx]);
+        const float mv[4] = {fmaxf(fmaxf(a.x, bq.x), c.x), fmaxf(fmaxf(a.y, bq.y), c.y), fmaxf(fmaxf(a.z, bq.z), c.z), fmaxf(fmaxf(a.w, bq.w), c.w)};
         if (px < NPX && j < Wo && oq < CQo) {
-          const float mv[4] = {mx[t2].x, mx[t2].y, mx[t2].z, mx[t2].w};
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < Cout) ? mv[r] + (racc[t2][r] + brr[r]) : 0.0f;
@@ -1249,17 +1262,13 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
         }
       }
     };
-    if (item && !(dbg & 1)) {
+    if (item) {
       const float* pa = tk < 0 ? carry : xrow(2 * tk);
       const float* pb = tk < 0 ? (r0 < H ? xrow(0) : pa) : xrow(2 * tk + 1);
       const float* pc = (tk >= 0 && r0 + 2 * tk + 2 < H) ? xrow(2 * tk + 2) : pa;
       finish(pr, pa, pb, pc);
     }
-    if (item2 && !(dbg & 1)) {  // rows 6 and 7 are the image's last two: their window closes here (the prev loads are exposed once per strip)
-      request_prev(pr_last);
-      finish(pr_last, xrow(6), xrow(7), xrow(6));
-    }
-    if (tk < 0 && t + 1 < ntile) {  // waves 0 and 1: the new carry, max(row 6, row 7), for their half of the channels (the old carry was read above: same wave, in order)
+    if (tk < 0 && t + 1 < ntile) {  // waves 6 and 7: the new carry, max(row 6, row 7), for their half of the channels (the old carry was read above: same wave, in order)
       const float* p6 = xrow(6);
       const float* p7 = xrow(7);
 #pragma unroll
@@ -1270,7 +1279,7 @@ __global__ __launch_bounds__(512, 6) void sepconv_pool_march_kernel(const float*
         *reinterpret_cast<float4*>(&carry[idx]) = make_float4(fmaxf(a.x, bq.x), fmaxf(a.y, bq.y), fmaxf(a.z, bq.z), fmaxf(a.w, bq.w));
       }
     }
-    vm_clean = item && !item2 && !(dbg & 1);  // this wave waited for loads younger than the next tile's first DMA: that DMA has landed, only stores are in flight
+    vm_clean = item;  // this wave waited for loads younger than the next tile's first DMA: that DMA has landed, only stores are in flight
   }
 }
 
@@ -2624,10 +2633,9 @@ int orcai_sepconv_pool_res(const float* in, const float* prev, int B, int Cin, i
   const int NT = g_pool_fused_nt, nseg = (Ho + 4 * NT - 2) / (4 * NT - 1);
   dim3 grid(nstrip * nseg, B);
   hipStream_t st = (hipStream_t)stream;
-  static const int exp_dbg = getenv("ORCAI_EXP_PM_DBG") ? atoi(getenv("ORCAI_EXP_PM_DBG")) : 0;  // EXPERIMENT: timing-only variants of the marching kernel (wrong results)
 #define ORCAI_PM_LAUNCH(CQT, RELU)                                                                                                                          \
   hipLaunchKernelGGL((sepconv_pool_march_kernel<CQT, RELU>), grid, dim3(512), 0, st, in, Cin, H, W, WP, dw, pw, scale, shift, C, relu_out, prev, Cp, prev_compact ? 1 : 0, \
-                     wr, br, out, Ho, Wo, WPo, nstrip, NT, exp_dbg)
+                     wr, br, out, Ho, Wo, WPo, nstrip, NT)
   switch (CQ) {  // C in 17 .. 32 and Cin = C for a block's second conv: 5 .. 8 input quads
     case 5: if (relu_in) ORCAI_PM_LAUNCH(5, true); else ORCAI_PM_LAUNCH(5, false); break;
     case 6: if (relu_in) ORCAI_PM_LAUNCH(6, true); else ORCAI_PM_LAUNCH(6, false); break;

@@ -8,6 +8,8 @@
 #include <cstddef>
 #include <cstdint>
 
+extern "C" int orcai_arena_take(const void* p, size_t bytes);  // capi.hip: 1 = [p, p + bytes) is a fresh slot of the step's pre-cleared accumulator arena
+
 namespace orcai_zero {
 
 __global__ __launch_bounds__(256) static void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
@@ -18,6 +20,7 @@ __global__ __launch_bounds__(256) static void zero_words_kernel(uint32_t* __rest
 inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
   const size_t n = bytes / 4;
   if (n == 0) return hipSuccess;
+  if (orcai_arena_take(p, bytes)) return hipSuccess;  // cleared with the whole arena at the start of the step (orcai_scratch_arena)
   const size_t want = (n + 255) / 256;
   hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
   return hipGetLastError();

@@ -112,7 +112,9 @@ def hyperparameter_search(data_dir: Path | str, output_dir: Path | str, orcai_pa
             trainer.load_state_dict(resume)
         hist = model.fit(train_ds, validation_data=val_ds, epochs=max(1, epochs - initial_epoch),
                          callbacks=[EarlyStopping(monitor=monitor, patience=5, mode="max", restore_best_weights=True), checkpoint])
-        return float(max(hist.history[monitor])), trainer.state_dict()
+        end_state = trainer.state_dict()
+        trainer.release_graph()  # the trial's captured step and its memory pool go now, not whenever the collector finds the trainer
+        return float(max(hist.history[monitor])), end_state
 
     for n, rungs in hyperband_brackets(max_epochs, FACTOR):
         configs = [(_draw(rng, hps_parameter, orcai_parameter), None) for _ in range(n)]  # (hyper-parameters, state after the previous rung)

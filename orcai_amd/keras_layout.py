@@ -92,6 +92,13 @@ def from_keras3_paths(arrays: dict, n_blocks: int, architecture: str = "ResNetLS
     return out
 
 
+def expected_keras3_paths(arrays: dict, n_blocks: int, architecture: str = "ResNetLSTM") -> list[str]:
+    """The dataset paths from_keras3_paths reads from this file (layer names resolved against the file's own layer list)."""
+    layer_names = [p.split("/")[1] for p in arrays if p.startswith("layers/") and p.count("/") >= 3]
+    by_cls = _layers_by_class(layer_names)
+    return ["/".join(["layers", by_cls[cls][k], *sub, "vars", str(i)]) for cls, k, sub, i, _ in variable_map(n_blocks, architecture) if k < len(by_cls[cls])]
+
+
 def to_keras3_paths(weights: dict, n_blocks: int, architecture: str = "ResNetLSTM") -> dict:
     """Inverse of from_keras3_paths for a model built in a fresh session (layer names without offset): used by the round-trip test
     and to document the layout."""

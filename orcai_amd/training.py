@@ -378,11 +378,20 @@ class TrunkTrainer:
         self.adt = torch.float16 if self.half else torch.float32
         if self.half and getattr(model, "architecture", "") != "ResNetLSTM":
             raise NotImplementedError("the f16 path implements ResNetLSTM only")
-        self.scratch = torch.zeros(8 * 16 * 32, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad (<= 64 channels) x the 32 accumulator copies of orcai_bn_planes_stats
+        self._own_scratch = torch.zeros(8 * 16 * 32, dtype=torch.float64, device=self.dev)  # 8 doubles per channel quad (<= 64 channels) x the 32 accumulator copies of orcai_bn_planes_stats
+        self.scratch = self._own_scratch
+        # One clear per step instead of one 5-us zero-fill launch per reduction (~30 per step): every launcher that accumulates gets its own 32-KiB slot of
+        # an arena that Trainer.forward_backward clears with ONE launch (orcai_scratch_arena); the launchers skip their own fill for a slot nobody has taken
+        # since (include/orcai_hip.h).  self.scratch / self.res_scratch always name the slot of the most recent producer: its consumers read it there.
+        self.arena_slots = 96
+        self.arena = torch.empty(self.arena_slots * 4096, dtype=torch.float64, device=self.dev)
+        self._slot = self.arena_slots  # no step in flight: _fresh() hands out the private buffers
+        self.use_arena = True  # A/B: tools/ab_flags.py
         # ResNet1DConv drops out the output of every residual block (architectures.py:97); ResNetLSTM has no Dropout in the trunk
         self.block_rate = float(model.dropout_rate) if getattr(model, "architecture", "") == "ResNet1DConv" else 0.0
         self.block_masks = None  # list of 0/1 plane tensors (one per block) for the current step, or None
-        self.res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
+        self._own_res_scratch = torch.zeros(8 * 16, dtype=torch.float64, device=self.dev)  # planes_sum of the residual bias gradient: pool_bwd_bn's sums stay in self.scratch
+        self.res_scratch = self._own_res_scratch
         self.stats_in_epilogue = True  # block-1-shaped separable convs reduce their BatchNorm statistics in the epilogue (A/B: tools/ab_train_order.py)
         self.dgrad_first = True  # order of a separable conv's backward kernels (A/B: tools/ab_train_order.py)
         self.bias_in_pool = True  # residual bias gradients reduced inside the pooling backward (no planes_sum pass over dout)
@@ -399,6 +408,33 @@ class TrunkTrainer:
         self.partials = torch.empty(512 * 64 * 64, dtype=torch.float32, device=self.dev)  # per-workgroup partial weight gradients (outer_reduce)
 
     # ------------------------------------------------------------- helpers
+    def begin_step(self) -> None:
+        """Clear the accumulator arena (one launch) and start handing out its slots."""
+        if self.use_arena:
+            N.check(self.lib.orcai_scratch_arena(self.arena.data_ptr(), self.arena.numel() * 8, N.stream_ptr()), "scratch_arena")
+            self._slot = 0
+
+    def end_step(self) -> None:
+        """No launcher may skip its zero fill outside a step (the arena's memory may be anybody's by then)."""
+        N.lib().orcai_scratch_arena(None, 0, None)
+        self._slot = self.arena_slots
+        self.scratch, self.res_scratch = self._own_scratch, self._own_res_scratch
+
+    def _slot_view(self, own):
+        if self._slot < self.arena_slots:
+            v = self.arena[self._slot * 4096 : (self._slot + 1) * 4096]
+            self._slot += 1
+            return v
+        return own
+
+    def _fresh(self):
+        """A cleared accumulator for the NEXT producer launch (self.scratch); call it in front of every launcher that accumulates into self.scratch, never
+        in front of one that reads sums an earlier launcher left there."""
+        self.scratch = self._slot_view(self._own_scratch)
+
+    def _fresh_res(self):
+        self.res_scratch = self._slot_view(self._own_res_scratch)
+
     def _planes(self, B, c, h, w):
         G = self.G
         return torch.zeros((B, (c + G - 1) // G, h + 2 * self.R, self.model.padded_width(w), G), dtype=self.adt, device=self.dev)
@@ -450,6 +486,7 @@ class TrunkTrainer:
         self.scratch); False when the shape is not one of the strip-tile kernel's: the caller then runs the two separate launches."""
         if not self.fused_stats_under_capture and torch.cuda.is_current_stream_capturing():
             return False  # A/B switch of tools/debug_graph_divergence.py
+        self._fresh()
         rc = (self.lib.orcai_h_sepconv_stats if self.half else self.lib.orcai_sepconv_planes_stats)(x.data_ptr(), self.B, Cin, H, W, relu_in, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
                                                  out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
@@ -464,6 +501,7 @@ class TrunkTrainer:
         if sums_in_shards:  # the producing kernel left the sums in self.scratch (orcai_sepconv_planes_stats)
             N.check((lib.orcai_h_bn_finish_sharded if self.half else lib.orcai_bn_finish_sharded)(self.scratch.data_ptr(), self.B, C, H, W, mean.data_ptr(), var.data_ptr(), st), "bn_finish_sharded")
         else:
+            self._fresh()
             N.check(self._fn("bn_planes_stats")(v.data_ptr(), self.B, C, H, W, self.k, self.scratch.data_ptr(), mean.data_ptr(), var.data_ptr(), st), "bn_planes_stats")
         self.stats[bn] = (mean, var)
         if y is None:
@@ -483,7 +521,8 @@ class TrunkTrainer:
         """_sep_stats whose input is the PRE-normalisation tensor of BatchNorm `bn_in` (+ ReLU): normalised on load, never materialised."""
         P = self.P
         mean, var = self.stats[bn_in]
-        rc = self.lib.orcai_sepconv_planes_stats_bn(v_in.data_ptr(), self.B, Cin, H, W, mean.data_ptr(), var.data_ptr(), P.W(bn_in + "/gamma").data_ptr(),
+        self._fresh()
+        rc = (self.lib.orcai_h_sepconv_stats_bn if self.half else self.lib.orcai_sepconv_planes_stats_bn)(v_in.data_ptr(), self.B, Cin, H, W, mean.data_ptr(), var.data_ptr(), P.W(bn_in + "/gamma").data_ptr(),
                                                     P.W(bn_in + "/beta").data_ptr(), BN_EPS, dw.data_ptr(), pw.data_ptr(), self._ones(64).data_ptr(), shift.data_ptr(), Cout,
                                                     out.data_ptr(), u_out.data_ptr(), self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
@@ -494,6 +533,7 @@ class TrunkTrainer:
     def _bn_bwd(self, dy, v, bn, C, H, W, relu, dv):
         lib, P, st = self.lib, self.P, N.stream_ptr()
         mean, var = self.stats[bn]
+        self._fresh()
         N.check(lib.orcai_bn_planes_bwd(dy.data_ptr(), v.data_ptr(), self.B, C, H, W, self.k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                         P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), P.G(bn + "/beta").data_ptr(),
                                         P.G(bn + "/gamma").data_ptr(), dv.data_ptr(), st), "bn_planes_bwd")
@@ -598,6 +638,7 @@ class TrunkTrainer:
             # is never written (the backward pass rebuilds it from the input taps: orcai_conv0_bn_bwd_x)
             w0, b0, ones = P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(), self._ones(16).data_ptr()
             mean0, var0 = P.B("bn0/mean"), P.B("bn0/var")
+            self._fresh()
             if self.conv0_march and k == 3:  # the marching form: no tiles, LDS or barriers (csrc/train_trunk.hip conv0_march_kernel)
                 N.check(lib.orcai_conv0_stats_march(src.data_ptr(), snippet_stride, B, H, W, w0, ones, b0, self.scratch.data_ptr(), st), "conv0_stats_march")
             else:
@@ -616,14 +657,14 @@ class TrunkTrainer:
             self.block_in[i] = (prev, res_in)  # (input of sep_a, input of the residual conv): the same tensor without block dropout
             # sep_a -> bn_a (+ ReLU) -> sep_b -> bn_b.  bn_b feeds only the pooling, which applies it on the fly to the maximum (monotone per channel):
             # y_b is never written.  bn_a + ReLU: applied where sep_b (and, in the backward pass, its depthwise weight gradient) load their
-            # input -- y_a is not materialised either -- when sep_b runs on the LDS-tile kernels with the statistics epilogue (k = 3, f32).
+            # input -- y_a is not materialised either -- when sep_b runs on the LDS-tile kernels with the statistics epilogue (k = 3).
             na, nb = f"b{i}/sep_a", f"b{i}/sep_b"
             self.dwl[na], self.dwl[nb] = self._w_dw(na), self._w_dw(nb)
             va, ya, vb = b[f"va{i}"], b[f"ya{i}"], b[f"vb{i}"]
             fused = self.stats_in_epilogue and k == 3 and self._sep_stats(prev, c, h, w, 1, self.dwl[na], self._w_pw(na + "/pointwise"), P.W(na + "/bias"), f, va, b[f"u_a{i}"])
             if not fused:
                 self._sep(prev, c, h, w, k, 1, self.dwl[na], self._w_pw(na + "/pointwise"), P.W(na + "/bias"), f, va, u_out=b[f"u_a{i}"])
-            on_load = self.apply_on_load and self.stats_in_epilogue and k == 3 and not self.half
+            on_load = self.apply_on_load and self.stats_in_epilogue and k == 3
             self._bn_fwd(va, f"b{i}/bn_a", f, h, w, 1, None if on_load else ya, sums_in_shards=fused)
             if on_load:
                 on_load = self._sep_stats_bn(va, f"b{i}/bn_a", f, h, w, self.dwl[nb], self._w_pw(nb + "/pointwise"), P.W(nb + "/bias"), f, vb, b[f"u_b{i}"])
@@ -669,6 +710,8 @@ class TrunkTrainer:
         lib, P, st, k = self.lib, self.P, N.stream_ptr(), self.k
         mean, var = self.stats[bn]
         wt = self._w_pwT(name + "/pointwise", Cin, Cout)  # pointwise^T [Cout][Cin]
+        if not sums_ready:  # the launcher reduces the BatchNorm backward sums itself (otherwise it READS them from self.scratch)
+            self._fresh()
         if self.fused_pw_wgrad and not self.half:
             # one pass: dv formed per pixel, du = Wpw dv, AND the pointwise weight gradient u (x) dv -- dv is never written or re-read
             rc = lib.orcai_bn_bwd_pointwise_wgrad(dy.data_ptr(), v.data_ptr(), u.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
@@ -695,6 +738,7 @@ class TrunkTrainer:
             if epi[0] == "bsums":
                 _, ref, bn, relu = epi
                 mean, var = self.stats[bn]
+                self._fresh()
                 rc = self.lib.orcai_sepconv_planes_epi(du.data_ptr(), self.B, Cin, H, W, dw.data_ptr(), eye.data_ptr(), self._ones(64).data_ptr(), zeros.data_ptr(), Cin, dr.data_ptr(), 2,
                                                        ref.data_ptr(), mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(), P.W(bn + "/beta").data_ptr(), BN_EPS, relu,
                                                        self.scratch.data_ptr(), N.stream_ptr())
@@ -725,6 +769,7 @@ class TrunkTrainer:
             # f16 path: the entry conv's stored v0 is the pass's x (y0 formed from it on load), bn0's backward sums over the total gradient in its
             # epilogue, the residual branch's even-pixel gradient added inside (orcai_h_dw_bwd_fused_res + orcai_h_conv0_bn_bwd_ready)
             mean0, var0 = self.stats["bn0"]
+            self._fresh()
             rc = self.lib.orcai_h_dw_bwd_fused_res(self.buf["v0"].data_ptr(), du.data_ptr(), self.B, Cin, H, W, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
                                                    P.G(name + "/depthwise").data_ptr(), mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(),
                                                    BN_EPS, 1, self.scratch.data_ptr(), self._resq.data_ptr(), N.stream_ptr())
@@ -735,6 +780,7 @@ class TrunkTrainer:
         if name == "b1/sep_a" and epi is None and x_bn is None and self._conv0_dgrad_ok(x):
             # block 1's first conv: y0 rebuilt from the snippet's taps instead of read, bn0's backward sums left in self.scratch for orcai_conv0_bn_bwd_x_ready
             mean0, var0 = self.stats["bn0"]
+            self._fresh()
             rc = self.lib.orcai_dw_bwd_fused_conv0(self.src.data_ptr(), self.snippet_stride, du.data_ptr(), self.B, H, W, P.W("conv0/kernel").data_ptr(), P.W("conv0/bias").data_ptr(),
                                                    self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(), P.G(name + "/depthwise").data_ptr(), mean0.data_ptr(), var0.data_ptr(),
                                                    P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, self.scratch.data_ptr(),
@@ -764,6 +810,8 @@ class TrunkTrainer:
         if bn is not None:
             mean, var = self.stats[bn]
             bnp = [mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(), P.W(bn + "/beta").data_ptr()]
+        if mode == 2:
+            self._fresh()
         rc = self._fn("dw_bwd_fused")(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, relu_in, self._w_dw(name, reverse=True).data_ptr(), dr.data_ptr(),
                                          P.G(name + "/depthwise").data_ptr(), mode, *bnp, BN_EPS, bn_relu, self.scratch.data_ptr(), N.stream_ptr())
         if rc == N.E_UNSUPPORTED:
@@ -799,7 +847,13 @@ class TrunkTrainer:
             N.check(self._fn("outer_reduce")(u.data_ptr(), Cin, dv.data_ptr(), Cout, self.B, H, W, k, 0, 0, 0, P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                              self.partials.numel(), st), "outer_reduce")
         # depthwise weight gradient, accumulated straight into the (zeroed) flat gradient buffer in the Keras layout
-        if x_bn is not None:  # x is the pre-normalisation tensor of BatchNorm x_bn (+ ReLU): normalised on load, as the forward conv did
+        if x_bn is not None and self.half:
+            # f16 path, a shape the marching pass refused: its plain depthwise weight gradient reads the MATERIALISED y_a -- form it now (the value the
+            # forward conv formed on load) in the block's y_a planes
+            ya = self.buf["ya" + name[1:name.index("/")]]
+            self._bn_apply(x, x_bn, Cin, H, W, 1, ya)
+            N.check(self._fn("dw_wgrad")(ya.data_ptr(), du.data_ptr(), self.B, Cin, H, W, k, k, 0, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad")
+        elif x_bn is not None:  # x is the pre-normalisation tensor of BatchNorm x_bn (+ ReLU): normalised on load, as the forward conv did
             mean, var = self.stats[x_bn]
             N.check(lib.orcai_dw_wgrad_bn(x.data_ptr(), du.data_ptr(), self.B, Cin, H, W, mean.data_ptr(), var.data_ptr(), P.W(x_bn + "/gamma").data_ptr(),
                                           P.W(x_bn + "/beta").data_ptr(), BN_EPS, P.G(name + "/depthwise").data_ptr(), st), "dw_wgrad_bn")
@@ -833,6 +887,7 @@ class TrunkTrainer:
                 N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
                                                  self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
                 if not bias_in_pool:
+                    self._fresh_res()
                     N.check(self._fn("planes_sum")(dout.data_ptr(), B, f, ho, wo, k, self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), 0, st), "planes_sum")
 
             if not self.dgrad_first:
@@ -840,7 +895,9 @@ class TrunkTrainer:
             # max-pool branch
             dyb = b[f"dyb{i}"]
             bmean, bvar = self.stats[f"b{i}/bn_b"]  # the pooling backward also accumulates bn_b's backward reductions (sum dy, sum dy*xhat)
+            self._fresh()
             if bias_in_pool:  # the residual conv's bias gradient (sum of dout) reduced where the pooling backward reads dout anyway
+                self._fresh_res()
                 N.check(lib.orcai_pool_bwd_bn_bias(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
                                                    bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), st),
                         "pool_bwd_bn_bias")
@@ -877,6 +934,8 @@ class TrunkTrainer:
             dprev = dr
         H, W = m.input_hw
         mean0, var0 = self.stats["bn0"]  # bn0 (+ReLU) backward fused into the entry conv's weight gradient: dv0 is never written
+        if not self.bn0_sums_ready:
+            self._fresh()
         if self.v0_stored:
             c0bwd = self.lib.orcai_h_conv0_bn_bwd_ready if (self.half and self.bn0_sums_ready) else self._fn("conv0_bn_bwd")
             N.check(c0bwd(self.src.data_ptr(), self.snippet_stride, dprev.data_ptr(), b["v0"].data_ptr(), B, H, W, k, mean0.data_ptr(), var0.data_ptr(),
@@ -981,10 +1040,14 @@ class Trainer:
         if isinstance(masks, str):
             masks = self._masks(B, self.model.out_steps)
         self.trunk.block_masks = [masks[f"block{i}"] for i in range(1, len(self.model.filters) + 1)] if (self.conv1d and masks is not None) else None
-        featv = self.trunk.forward(src, snippet_stride, B)
-        probs = self.head.forward(featv, masks, self.model.dropout_rate)
-        out = self.head.loss_and_backward(labels, loss_weight)
-        self.trunk.backward(out["dfeatv"])
+        self.trunk.begin_step()  # one clear for every reduction scratch of the step
+        try:
+            featv = self.trunk.forward(src, snippet_stride, B)
+            probs = self.head.forward(featv, masks, self.model.dropout_rate)
+            out = self.head.loss_and_backward(labels, loss_weight)
+            self.trunk.backward(out["dfeatv"])
+        finally:
+            self.trunk.end_step()
         return {"acc": out["acc"], "probs": probs}
 
     def apply(self, world_size: int = 1) -> None:
@@ -1040,6 +1103,13 @@ class Trainer:
         out = self.forward_backward(src, snippet_stride, B, labels, loss_weight=loss_weight)
         self.apply(world_size)
         return out
+
+    def release_graph(self) -> None:
+        """Drop the captured step and its private memory pool (a hyper-parameter search builds one trainer per trial: hpsearch.py:110-257).  Not
+        inside another capture: destroying a graph is a runtime call."""
+        if self._graph is not None:
+            torch.cuda.synchronize()
+            self._graph = None
 
     def train_step_graphed(self, src: torch.Tensor, snippet_stride: int, B: int, labels: torch.Tensor) -> dict:
         """The whole single-GPU step -- dropout masks, forward, loss, backward, Adam, moving statistics, step counter -- as ONE

@@ -69,7 +69,7 @@ def test_bench_kernel_symbols_are_in_the_newest_pmc_traffic_table():
     f = bp.traffic_file()
     assert f is not None
     kernels = json.loads(f.read_text())["predict"]["kernels"]
-    for label in ("conv0+b1/sep_a", "b1/sep_b", "b2/sep_a", "b2/sep_b", "b1/pool_res"):  # labels the inference step launches (b1/sep_a alone only without the entry fusion)
+    for label in ("conv0+b1/sep_a", "b1/sep_b+pool_res", "b2/sep_a", "b2/sep_b", "b2/pool_res", "lstm1/rec", "lstm1/gemm"):  # labels the inference step launches
         sym = bp.PredictWorkload.kernel_symbol(label)
         assert sym in kernels, (label, sym, f.name, sorted(k for k in kernels if "sepconv" in k or "conv0" in k))
     fe = json.loads(f.read_text())["frontend"]["kernels"]

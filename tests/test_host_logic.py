@@ -296,6 +296,36 @@ def test_keras_weight_file_name_map_round_trips():
     assert (ROOT / "tools" / "keras_to_npz.py").exists()  # the file load_orcai_model's error message names
 
 
+def test_keras_converter_fails_loudly_on_files_that_do_not_match():
+    """tools/keras_to_npz.py (B8, io.py:386-404): a variable the architecture needs and the file lacks, a layers/... dataset nothing maps to and a
+    wrong shape each stop the conversion with the offending path / name in the message; a matching file passes.  (No h5py needed: the checks work
+    on the {dataset path: array} dict the HDF5 reader hands over.)"""
+    import importlib.util
+
+    from orcai_amd import keras_layout as K
+    from orcai_amd.architectures import ResNetLSTM
+
+    spec = importlib.util.spec_from_file_location("keras_to_npz", ROOT / "tools" / "keras_to_npz.py")
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    model = ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.3, 64, seed=6)
+    paths = K.to_keras3_paths(model.weights, 2, "ResNetLSTM")
+    paths["optimizer/vars/0"] = np.zeros(1)
+    good = conv._mapped_keras3(dict(paths), 2, "ResNetLSTM", "x.keras")
+    conv.check_against_spec(good, model)
+    lacking = {p: a for p, a in paths.items() if p != "layers/dense_1/vars/1"}
+    with pytest.raises(SystemExit, match="layers/dense_1/vars/1"):
+        conv._mapped_keras3(lacking, 2, "ResNetLSTM", "x.keras")
+    extra = dict(paths)
+    extra["layers/conv2d_9/vars/0"] = np.zeros((1, 1, 4, 4))
+    with pytest.raises(SystemExit, match="no variable of the ResNetLSTM architecture maps to"):
+        conv._mapped_keras3(extra, 2, "ResNetLSTM", "x.keras")
+    bad = dict(good)
+    bad["b1/sep_a/pointwise"] = np.zeros((1, 1, 16, 11), dtype=np.float32)
+    with pytest.raises(SystemExit, match="shape of b1/sep_a/pointwise"):
+        conv.check_against_spec(bad, model)
+
+
 def test_wav_prefetcher_drops_recordings_the_caller_skips(tmp_path):
     """Table mode skips recordings (output exists, bad rows) without reading them: their decoded audio must not pile up."""
     from orcai_amd import wavio

@@ -437,3 +437,44 @@ def test_class_weight_scales_the_loss_like_keras():
     hist = model.fit(DS([(x, y)]), epochs=1, class_weight=cw)
     assert abs(hist.history["loss"][0] - (factor * out["plain"][0] + hist.history["loss"][0] - factor * out["plain"][0])) < 1e-9  # runs end to end
     assert np.isfinite(hist.history["loss"][0])
+
+
+def test_fit_loop_on_a_replayed_graph_follows_the_callbacks(tmp_path):
+    """FitLoop with graph_step=True (the step replayed as one hipGraph) against graph_step=False through the host-side events that touch the
+    trainer between replays: ReduceLROnPlateau halving the learning rate (patience 0: every epoch without improvement), EarlyStopping stopping and
+    restoring the best weights with load_state_dict, then a SECOND fit on the same trainer (the graph is reused after the restore).  Same seeds,
+    dropout off: both loops must produce the same history and end state up to float-atomic reordering (reference train.py:165-184, 201-219)."""
+    from orcai_amd.architectures import ResNetLSTM
+    from orcai_amd.datasets import SnippetDataset
+    from orcai_amd.fit import EarlyStopping, FitLoop, ReduceLROnPlateau
+    from orcai_amd.training import Trainer
+
+    d = _data(tmp_path, n_train=48, n_val=24)
+    runs = {}
+    for graph in (False, True):
+        model = ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=3)
+        tr = Trainer(model, learning_rate=3e-3, seed=1)
+        loop = FitLoop(model, tr, graph_step=graph)
+        assert loop.graph_step == graph
+        train = SnippetDataset(d / "train_dataset", 8, seed=[1, 2], shuffle=True)
+        val = SnippetDataset(d / "val_dataset", 8, seed=[3, 4], shuffle=False)
+        # an unreachable monitor target makes every epoch after the first "no improvement": the learning rate halves each epoch and
+        # EarlyStopping (patience 2) stops at epoch 3 and restores the weights of epoch 1
+        cbs = [ReduceLROnPlateau(monitor="val_loss", factor=0.5, patience=0, mode="max", min_delta=0.0), EarlyStopping(monitor="val_loss", patience=2, mode="max", restore_best_weights=True)]
+        h1 = loop.fit(train, validation_data=val, epochs=6, callbacks=cbs).history
+        lr_after, w_restored = tr.lr, tr.P.w.clone()
+        loop.stop_training = False
+        h2 = loop.fit(train, validation_data=val, epochs=2, callbacks=[]).history  # keeps training from the restored state, graph reused
+        runs[graph] = (h1, h2, lr_after, w_restored, tr.P.w.clone(), int(tr.counter.item()), tr._graph is not None)
+        tr.release_graph()
+        assert tr._graph is None
+    (e1, e2, elr, ew0, ew1, ec, eg), (g1, g2, glr, gw0, gw1, gc_, gg) = runs[False], runs[True]
+    assert not eg and gg  # the second loop really replayed a graph
+    assert len(e1["loss"]) == len(g1["loss"]) and len(e1["loss"]) >= 2  # stopped at the same epoch
+    assert e1["learning_rate"] == g1["learning_rate"] and elr == glr and len(set(e1["learning_rate"])) > 1  # the plateau callback changed the rate
+    for k in ("loss", "val_loss", "MBA", "val_MBA"):
+        assert np.allclose(e1[k], g1[k], rtol=0, atol=2e-3), (k, e1[k], g1[k])
+        assert np.allclose(e2[k], g2[k], rtol=0, atol=2e-3), (k, e2[k], g2[k])
+    assert ec == gc_
+    assert float((ew0 - gw0).abs().max()) <= 2e-3 and float((ew1 - gw1).abs().max()) <= 2e-3
+    assert float((ew1 - ew0).abs().max()) > 0  # the second fit moved the restored weights

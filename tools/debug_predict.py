@@ -8,6 +8,9 @@ from orcai_amd.predict import aggregate_predictions_device
 log = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "debug_predict.log"), "a")
 def P(*a):
     print(*a, file=log, flush=True); print(*a, flush=True)
+if os.environ.get("ORCAI_POOL_FUSED"):  # A/B of the fused block tail under a profiler (0 = the two launches)
+    from orcai_amd import _native as N
+    N.lib().orcai_pool_fused(int(os.environ["ORCAI_POOL_FUSED"]))
 dev = torch.device("cuda", 0)
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 64

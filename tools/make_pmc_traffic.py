@@ -1,4 +1,4 @@
-"""profiles/rNN_pmc_traffic.json from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/evidence_r03_b.sh.
+"""profiles/rNN_pmc_traffic.json from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/evidence_rNN_b.sh.
 
 usage: python tools/make_pmc_traffic.py gpurun_out/ev3 profiles/r03_pmc_traffic.json
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies the

@@ -30,7 +30,32 @@ def demangle(name: str) -> str:
     return _DEMANGLED[name]
 
 
+def parse_itanium_kernel(name: str):
+    """`_ZN12_GLOBAL__N_1<len><kernel>I<literal template arguments>E...` -> `kernel<2, false, true>`: the demanglers of this image give up on
+    symbols with _Float16 parameters (DF16_), which is every kernel of the f16 path.  Only integer / bool literal arguments are understood."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return None
+    n, i = int(m.group(1)), m.end()
+    kernel, rest = name[i : i + n], name[i + n :]
+    if not rest.startswith("I"):
+        return kernel
+    args, j = [], 1
+    while j < len(rest) and rest[j] != "E":
+        a = re.match(r"L([ibjlm])(n?)(\d+)E", rest[j:])
+        if not a:
+            return kernel
+        v = int(a.group(3)) * (-1 if a.group(2) else 1)
+        args.append(("true" if v else "false") if a.group(1) == "b" else str(v))
+        j += a.end()
+    return f"{kernel}<{', '.join(args)}>"
+
+
 def short(name: str) -> str:
+    if name.startswith("_Z"):
+        p = parse_itanium_kernel(name)
+        if p and demangle(name) == name:  # the demangler could not read it
+            return p
     name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
