@@ -589,6 +589,8 @@ def _h_call_symbol(name, a):
         return f"sepconv_h_ftile_kernel<{mt(a[14])}, false, true, true, true>"
     if name == "orcai_h_bn_bwd_pointwise":  # dy,v,B,C,H,W,ksize,mean,var,gamma,beta,eps,relu,scratch,sums_ready,dbeta,dgamma,wt,Cin,dv,du,stream
         return f"bn_bwd_pw_h_kernel<{mt(a[18])}>"
+    if name == "orcai_h_bn_bwd_pointwise_wgrad":  # dy,v,u,B,C,H,W,ksize,...,wt,Cin,du,...: <conv-input tiles, conv-output tiles>
+        return f"bn_bwd_pw_wgrad_h_kernel<{mt(a[19])}, {mt(a[4])}>"
     if name in ("orcai_h_dw_bwd_fused", "orcai_h_dw_bwd_fused_res"):  # x,du,B,C,H,W,relu_in,dw_rev,dr,dW,epi,bn_mean,...
         W = a[5]
         best, lanes = 64, ((W + 61) // 62) * 64
@@ -601,7 +603,7 @@ def _h_call_symbol(name, a):
         return f"dw_bwd_march_h_kernel<{best}, {a[10]}, {'true' if a[11] is not None else 'false'}, false>"
     if name == "orcai_h_pool_res_add":
         return f"pool_res_add_h_kernel<{mt(a[3])}>"
-    return {"orcai_h_outer_reduce": "outer_reduce_h_kernel", "orcai_h_pool_bwd_bn": "pool_bwd_h_kernel", "orcai_h_bn_planes_apply": "bn_planes_apply_h_kernel",
+    return {"orcai_h_outer_reduce": "outer_reduce_h_kernel", "orcai_h_pool_bwd_bn": "pool_bwd_h_kernel", "orcai_h_pool_bwd_bn_bias": "pool_bwd_h_kernel", "orcai_h_bn_planes_apply": "bn_planes_apply_h_kernel",
             "orcai_h_planes_sum": "planes_sums_h_kernel", "orcai_h_bn_planes_stats": "planes_sums_h_kernel", "orcai_h_conv0_affine": "conv0_h_kernel<3>",
             "orcai_h_conv0_bn_bwd": "conv0_bn_wgrad_h_kernel<3, 8>", "orcai_h_conv0_bn_bwd_ready": "conv0_bn_wgrad_h_kernel<3, 8>"}.get(name, name)
 
@@ -620,11 +622,13 @@ def _h_call_bytes(name, a):
     if name == "orcai_h_bn_bwd_pointwise":
         B, C, H, W, Cin = a[2], a[3], a[4], a[5], a[18]
         return 2.0 * B * H * W * (3 * C + Cin)
+    if name == "orcai_h_bn_bwd_pointwise_wgrad":  # dy, v (C channels) read, u read and du written (Cin channels); dv is never moved
+        return 2.0 * a[3] * a[5] * a[6] * (2 * a[4] + 2 * a[19])
     if name in ("orcai_h_dw_bwd_fused", "orcai_h_dw_bwd_fused_res"):
         return 2.0 * a[2] * a[4] * a[5] * 3 * a[3]
     if name == "orcai_h_outer_reduce":  # A,Ca,Bq,Cb,B,H,W,...
         return 2.0 * a[4] * a[5] * a[6] * (a[1] + a[3])
-    if name == "orcai_h_pool_bwd_bn":  # dout,ybn,B,C,H,W,...: dout at the pooled resolution, v read, dy written
+    if name in ("orcai_h_pool_bwd_bn", "orcai_h_pool_bwd_bn_bias"):  # dout,ybn,B,C,H,W,...: dout at the pooled resolution, v read, dy written
         return 2.0 * a[2] * a[4] * a[5] * a[3] * 2.25
     if name == "orcai_h_pool_res_add":  # s,prev,B,C,Cp,H,W,...: v_b read, prev at the sampled pixels, the block output
         return 2.0 * a[2] * a[5] * a[6] * (a[3] + 0.25 * a[4] + 0.25 * a[3])

@@ -562,8 +562,19 @@ int orcai_h_bn_planes_apply(const void* v, int B, int C, int H, int W, int ksize
 int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H, int W, int ksize, const float* mean, const float* var, const float* gamma,
                              const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma, const void* wtf, int Cin,
                              void* dv, void* du, void* stream);
+/* orcai_h_bn_bwd_pointwise + orcai_h_outer_reduce(u, dv) in one pass (f16 twin of orcai_bn_bwd_pointwise_wgrad; train.py:201-219): dv is formed per pixel,
+ * rounded to f16 as the two-launch path stores it, used for du = Wpw dv AND for the pointwise weight gradient dWpw[Cin][C] += sum_pixels u (x) dv, and never
+ * written.  u: the conv's stored depthwise output (octet planes of Cin channels); workspace: per-workgroup partial products (>= Cin * C floats; more = more
+ * workgroups, up to 1024).  ORCAI_E_UNSUPPORTED (nothing touched) beyond 32 channels on either side: the caller runs the two launches. */
+int orcai_h_bn_bwd_pointwise_wgrad(const void* dy, const void* v, const void* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
+                                   const void* wtf, int Cin, void* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream);
 int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
                         const float* bn_var, float bn_eps, double* bn_sums, void* stream);
+/* orcai_h_pool_bwd_bn that also reduces sum(dout) per channel -- the bias gradient of the block's residual conv, dout being the gradient of the block output
+ * (f16 twin of orcai_pool_bwd_bn_bias): dout_sums f64[8 * ceil(C/8)] scratch, dbias f32[C] (overwritten; it carries dout's loss scale). */
+int orcai_h_pool_bwd_bn_bias(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                             const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream);
 int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, float* workspace,
                          int64_t workspace_floats, void* stream);
 int orcai_h_dw_wgrad(const void* x, const void* du, int B, int C, int H, int W, int ksize_planes, int ktap, int relu_in, float* dW, void* stream);

@@ -69,9 +69,11 @@ _SIGNATURES = {
     "orcai_bn_bwd_pointwise": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3),
     "orcai_pw_wgrad_tiles": (C.c_int, [C.c_int]),
     "orcai_bn_bwd_pointwise_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [c_i64, C.c_void_p]),
+    "orcai_h_bn_bwd_pointwise_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [c_i64, C.c_void_p]),
     "orcai_pool_res_add_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]),
     "orcai_pool_bwd_bn": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_pool_bwd_bn_bias": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4),
+    "orcai_h_pool_bwd_bn_bias": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4),
     "orcai_conv0_bn_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 5),
     "orcai_conv0_stats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_int] * 4 + [C.c_void_p] * 5),
     "orcai_conv0_affine_bn": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),

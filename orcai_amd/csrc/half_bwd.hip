@@ -299,7 +299,8 @@ __device__ __forceinline__ O8 o8_fill(float x) {
 __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__ dout, const h16* __restrict__ ybn, int C, int H, int W, int WP, int R, int Ho, int Wo,
                                                           int WPo, int pad_top, int pad_left, h16* __restrict__ dy, const float* __restrict__ bn_gamma,
                                                           const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float bn_eps,
-                                                          double* __restrict__ bn_sums /*[2][8*CO]*/) {
+                                                          double* __restrict__ bn_sums /*[2][8*CO]*/,
+                                                          double* __restrict__ dout_sums = nullptr /*[8*CO]: sum of dout per channel (the residual conv's bias gradient)*/) {
   const int CO = (C + 7) >> 3;
   const int nchunk = (Ho + PB_ROWS - 1) / PB_ROWS;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -309,10 +310,11 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
   const int64_t bq = blockIdx.y;
   const int co = (int)(bq % CO);
   float bs[8], bqs[8], bmu[8], binv[8], sgn[8];
+  float ds[8];  // dout_sums: every pooled pixel belongs to exactly one thread's OWN windows (i0 <= i < i1)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = co * 8 + k, cc = c < C ? c : 0;
-    bs[k] = 0.f; bqs[k] = 0.f;
+    bs[k] = 0.f; bqs[k] = 0.f; ds[k] = 0.f;
     bmu[k] = bn_sums ? bn_mean[cc] : 0.f;
     binv[k] = bn_sums ? rsqrtf(bn_var[cc] + bn_eps) : 0.f;
     sgn[k] = (bn_gamma && bn_gamma[cc] < 0.f) ? -1.f : 1.f;
@@ -400,6 +402,10 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
       }
     }
     if (i >= i0) {
+      if (dout_sums) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ds[k] += d.v[k];
+      }
       if (r0 >= 0) {
         if (cx0) emit((int64_t)(r0 + R) * WP + x0, add8(c0, g6[0]), t0);
         if (cx1) emit((int64_t)(r0 + R) * WP + x1, add8(c1, g6[1]), t1);
@@ -431,6 +437,13 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
     for (int k = 0; k < 8; ++k) a[k] = (double)bqs[k];
     block_reduce8(red, a);
     if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&bn_sums[8 * CO + co * 8 + threadIdx.x], red[0][threadIdx.x]);
+    if (dout_sums) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] = (double)ds[k];
+      block_reduce8(red, a);
+      if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&dout_sums[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+    }
   }
 }
 
@@ -527,6 +540,142 @@ __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restri
         const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
         if (ca < Ca && cb < Cb) mine[ca * Cb + cb] = acc[ti][r];
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BN backward apply + du = Wpw dv + POINTWISE WEIGHT GRADIENT u (x) dv in one pass
+// The f16 twin of bn_bwd_pw_wgrad_kernel (train_trunk.hip): bn_bwd_pw_h_kernel's arithmetic for dv and du, and outer_reduce_h_kernel's contraction
+// over pixels for dW[ci][co] += sum_p u[ci][p] dv[co][p] -- dv is formed per pixel, rounded to f16 exactly as the two-launch path stores it, used for
+// both products and NEVER written: one write and one read of the widest gradient tensor of the conv are gone, and the separate orcai_h_outer_reduce
+// launch with them.  A workgroup of 4 waves owns 256 consecutive flat pixels per pass (lane = pixel for the BatchNorm arithmetic and the du MFMAs, as
+// bn_bwd_pw_h_kernel); the pass's u and dv octets go through one LDS image [pixel][channel] and come back through the transposing read
+// ds_read_b64_tr_b16 as MFMA operands with k = pixel, wave w taking output tile w (<= 2 x 2 tiles of 16 channels: orcai-V1's block 1 in all three
+// hyper-parameter-search widths); the next pass's 16-byte loads are in flight in registers during the MFMA phase.  Per-workgroup partial products +
+// add_partials_h_kernel.
+template <int MT /*conv-INPUT tiles: rows of du and of dW*/, int NT /*conv-OUTPUT tiles: columns of dW*/>
+__global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_h_kernel(const h16* __restrict__ dy, const h16* __restrict__ v, const h16* __restrict__ u, int C, int H, int W, int WP, int R,
+                                                                 int B, const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int relu, const double* __restrict__ dbeta,
+                                                                 const double* __restrict__ dgamma, float inv_count, const h16* __restrict__ wtf, int Cin,
+                                                                 h16* __restrict__ du, float* __restrict__ part, uint32_t magic_WP) {
+  static_assert(MT <= 2 && NT <= 2, "one output tile per wave");
+  constexpr int pa_h = MT * 16 + 8, pb_h = NT * 16 + 8;  // row pitches in halves (16-byte multiples; the extra 16 bytes spread the rows over the banks)
+  constexpr int COA = MT * 2, COB = NT * 2;             // octets per operand (channels past Cin / C are zero)
+  __shared__ __attribute__((aligned(16))) h16 As[256 * pa_h];  // u  [pixel][conv-input channel]
+  __shared__ __attribute__((aligned(16))) h16 Bs[256 * pb_h];  // dv [pixel][conv-output channel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lk = lane >> 4, lj = lane & 15;
+  const int CO = (C + 7) >> 3, COi = (Cin + 7) >> 3;
+  const int plane = (H + 2 * R) * WP;
+  for (int i = tid; i < 256 * pa_h / 2; i += 256) reinterpret_cast<uint32_t*>(As)[i] = 0u;
+  for (int i = tid; i < 256 * pb_h / 2; i += 256) reinterpret_cast<uint32_t*>(Bs)[i] = 0u;
+  // BatchNorm constants of this lane's 8 * COB output channels stay in registers? no: they are wave-uniform per channel -> scalar loads inside the pass
+  const int chunks_per_plane = (H * WP + 255) >> 8;  // 256-pixel chunks covering the H image rows of a plane (start at row R)
+  const int64_t nchunks = (int64_t)B * chunks_per_plane;
+  f32x4 wacc = (f32x4){0.f, 0.f, 0.f, 0.f};  // this wave's tile of dW: tile index = wave (< MT * NT)
+  h16x8 rdy[COB], rv[COB], ru[COA];
+  auto fetch = [&](int64_t ch) {
+    const int64_t b = ch / chunks_per_plane;
+    const int q = R * WP + (int)(ch - b * chunks_per_plane) * 256 + tid;
+    const bool pin = ch < nchunks && q < plane;
+    const int qc = pin ? q : 0;
+#pragma unroll
+    for (int o = 0; o < COB; ++o) {
+      rdy[o] = (o < CO && pin) ? reinterpret_cast<const h16x8*>(dy)[((int64_t)b * CO + o) * plane + qc] : zero_h();
+      rv[o] = (o < CO && pin) ? reinterpret_cast<const h16x8*>(v)[((int64_t)b * CO + o) * plane + qc] : zero_h();
+    }
+#pragma unroll
+    for (int o = 0; o < COA; ++o) ru[o] = (o < COi && pin) ? reinterpret_cast<const h16x8*>(u)[((int64_t)b * COi + o) * plane + qc] : zero_h();
+  };
+  fetch(blockIdx.x);
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t b = ch / chunks_per_plane;
+    const int qbase = R * WP + (int)(ch - b * chunks_per_plane) * 256 + wave * 64;  // this wave's 64-pixel window
+    const int q = qbase + lane;
+    const int row = (int)__umulhi((uint32_t)q, magic_WP);
+    const bool live = q < plane && (q - row * WP) < W && row < R + H;
+    // ---- dv per pixel (bn_bwd_pw_h_kernel's arithmetic, rounded to f16 as the two-launch path stores it)
+    u32x4 d[4];
+    h16x8 dvo[COB];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o < COB && o < CO) {
+        float dd[8], vv[8], r[8];
+        unpack8(rdy[o], dd);
+        unpack8(rv[o], vv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = o * 8 + k;
+          if (c < C) {
+            const float inv = rsqrtf(var[c] + eps);
+            const float xh = (vv[k] - mean[c]) * inv;
+            float de = dd[k];
+            if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
+            r[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
+          } else {
+            r[k] = 0.0f;
+          }
+        }
+        dvo[o < COB ? o : 0] = pack8(r);
+        d[o] = as_u(dvo[o < COB ? o : 0]);
+      } else {
+        if (o < COB) dvo[o] = zero_h();
+        d[o] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();  // the previous pass's transposing reads are done (and, first pass, the zero fill is visible)
+#pragma unroll
+    for (int o = 0; o < COB; ++o) *reinterpret_cast<h16x8*>(Bs + tid * pb_h + 8 * o) = dvo[o];
+#pragma unroll
+    for (int o = 0; o < COA; ++o) *reinterpret_cast<h16x8*>(As + tid * pa_h + 8 * o) = ru[o];
+    __syncthreads();
+    fetch(ch + gridDim.x);  // the next pass's loads: in flight during both MFMA phases
+    // ---- du = Wpw dv: one K group of 4 octets (C <= 32)
+    {
+      f32x4 acc[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      octets_to_fragments(d);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const h16x8 a = reinterpret_cast<const h16x8*>(wtf)[m * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = mfma_h(a, as_h(d[t]), acc[m][t]);
+      }
+#pragma unroll
+      for (int tp = 0; tp < 4; tp += 2) {
+        const int flat = qbase + 16 * (tp + (lk & 1)) + lj;
+        const int r2 = (int)__umulhi((uint32_t)flat, magic_WP);
+        const bool ok = flat < plane && (flat - r2 * WP) < W && r2 < R + H;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          float a[4], bq[4], o8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { a[r] = acc[m][tp][r]; bq[r] = acc[m][tp + 1][r]; }
+          tiles_to_octet(a, bq, o8);
+          const int oq = 2 * m + (lk >> 1);
+          if (ok && oq < COi) reinterpret_cast<h16x8*>(du)[((int64_t)b * COi + oq) * plane + flat] = pack8(o8);
+        }
+      }
+    }
+    // ---- dW tile of this wave over the pass's 256 pixels: A[row = ci][k = pixel], B[k = pixel][col = co]
+    if (wave < MT * NT) {  // wave-uniform: EXEC stays all ones inside, as the transposing read requires
+      const int mt = wave / NT, nt = wave - mt * NT;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+        wacc = mfma_h(tr_fragment(As, pa_h, 32 * s8 + 8 * lk, 16 * mt, lj), tr_fragment(Bs, pb_h, 32 * s8 + 8 * lk, 16 * nt, lj), wacc);
+    }
+  }
+  if (wave < MT * NT) {
+    float* mine = part + (int64_t)blockIdx.x * Cin * C;
+    const int mt = wave / NT, nt = wave - mt * NT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ca = mt * 16 + lk * 4 + r, cb = nt * 16 + lj;
+      if (ca < Cin && cb < C) mine[ca * C + cb] = wacc[r];
     }
   }
 }
@@ -1084,10 +1233,48 @@ int orcai_h_bn_bwd_pointwise(const void* dy, const void* v, int B, int C, int H,
   return (int)hipGetLastError();
 }
 
-int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
-                        const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
+int orcai_h_bn_bwd_pointwise_wgrad(const void* dy, const void* v, const void* u, int B, int C, int H, int W, int ksize, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, float eps, int relu, double* scratch2C, int sums_ready, float* dbeta, float* dgamma,
+                                   const void* wtf, int Cin, void* du, float* dWpw, float* workspace, int64_t workspace_floats, void* stream) {
+  if (!dy || !v || !u || !du || !wtf || !scratch2C || !dbeta || !dgamma || !dWpw || !workspace || B <= 0 || C <= 0 || Cin <= 0) return ORCAI_E_BADARG;
+  // one output tile of dW per wave: at most 2 x 2 tiles of 16 channels (block 1 of every hyper-parameter-search width); wider layers keep the two launches
+  const int MT = (Cin + 15) / 16, NT = (C + 15) / 16;
+  if (MT > 2 || NT > 2 || workspace_floats < (int64_t)Cin * C) return ORCAI_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int CO = (C + 7) / 8, R = ksize / 2, WP = orcai_padded_width(W, ksize);
+  const int64_t plane = (int64_t)(H + 2 * R) * WP;
+  if (plane >= (1ll << 29) || (((uintptr_t)dy | (uintptr_t)v | (uintptr_t)u | (uintptr_t)du | (uintptr_t)wtf) & 15)) return ORCAI_E_UNSUPPORTED;
+  double* db = scratch2C;
+  double* dg = scratch2C + 8 * CO;
+  if (!sums_ready) {
+    hipError_t e = orcai_zero::zero_async(scratch2C, sizeof(double) * 16 * CO, st);
+    if (e != hipSuccess) return (int)e;
+    int gx = (int)((B * plane + 255) / 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(bn_planes_bwd_sums_h_kernel, dim3(gx, CO), dim3(256), 0, st, (const h16*)dy, (const h16*)v, C, plane, B, mean, var, gamma, beta, eps, relu, db, dg);
+  }
+  const int64_t nchunks = (int64_t)B * ((H * WP + 255) / 256);
+  int64_t grid = nchunks < 1024 ? nchunks : 1024;  // four workgroups per compute unit
+  if (grid * Cin * C > workspace_floats) grid = workspace_floats / ((int64_t)Cin * C);
+  const float inv_count = (float)(1.0 / ((double)B * H * W));
+#define ORCAI_HBBPW(MT_, NT_)                                                                                                                                       \
+  hipLaunchKernelGGL((bn_bwd_pw_wgrad_h_kernel<MT_, NT_>), dim3((unsigned)grid), dim3(256), 0, st, (const h16*)dy, (const h16*)v, (const h16*)u, C, H, W, WP, R, B, mean, var, \
+                     gamma, beta, eps, relu, db, dg, inv_count, (const h16*)wtf, Cin, (h16*)du, workspace, magic_for(WP))
+  if (MT == 1 && NT == 1) ORCAI_HBBPW(1, 1);
+  else if (MT == 1) ORCAI_HBBPW(1, 2);
+  else if (NT == 1) ORCAI_HBBPW(2, 1);
+  else ORCAI_HBBPW(2, 2);
+#undef ORCAI_HBBPW
+  hipLaunchKernelGGL(add_partials_h_kernel, dim3(blocks_for((int64_t)Cin * C), 8), dim3(256), 0, st, workspace, (int)grid, Cin * C, dWpw);
+  hipLaunchKernelGGL(f64_to_f32_pair_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
+  return (int)hipGetLastError();
+}
+
+static int h_pool_bwd_bn_impl(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                              const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream) {
   if (!dout || !ybn || !dy || B <= 0 || C <= 0 || H <= 0 || W <= 0 || C > 64) return ORCAI_E_BADARG;
   if (bn_sums && (!bn_gamma || !bn_mean || !bn_var)) return ORCAI_E_BADARG;
+  if (dout_sums && (!bn_sums || !dbias)) return ORCAI_E_BADARG;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   int tot_h = (Ho - 1) * 2 + 3 - H, tot_w = (Wo - 1) * 2 + 2 - W;
   if (tot_h < 0) tot_h = 0;
@@ -1099,11 +1286,27 @@ int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, 
     hipError_t e = orcai_zero::zero_async(bn_sums, sizeof(double) * 16 * CO, st);
     if (e != hipSuccess) return (int)e;
   }
+  if (dout_sums) {
+    hipError_t e = orcai_zero::zero_async(dout_sums, sizeof(double) * 8 * CO, st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int per_bq = ((Ho + PB_ROWS - 1) / PB_ROWS) * Wo;
   dim3 grid((per_bq + 255) / 256, (unsigned)(B * CO));
   hipLaunchKernelGGL(pool_bwd_h_kernel, grid, dim3(256), 0, st, (const h16*)dout, (const h16*)ybn, C, H, W, orcai_padded_width(W, ksize), ksize / 2, Ho, Wo,
-                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, (h16*)dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums);
+                     orcai_padded_width(Wo, ksize), tot_h / 2, tot_w / 2, (h16*)dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, dout_sums);
+  if (dout_sums) hipLaunchKernelGGL(f64_to_f32_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, dout_sums, dbias, C, 0);
   return (int)hipGetLastError();
+}
+
+int orcai_h_pool_bwd_bn(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                        const float* bn_var, float bn_eps, double* bn_sums, void* stream) {
+  return h_pool_bwd_bn_impl(dout, ybn, B, C, H, W, ksize, dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, nullptr, nullptr, stream);
+}
+
+int orcai_h_pool_bwd_bn_bias(const void* dout, const void* ybn, int B, int C, int H, int W, int ksize, void* dy, const float* bn_gamma, const float* bn_mean,
+                             const float* bn_var, float bn_eps, double* bn_sums, double* dout_sums, float* dbias, void* stream) {
+  if (!dout_sums || !dbias) return ORCAI_E_BADARG;
+  return h_pool_bwd_bn_impl(dout, ybn, B, C, H, W, ksize, dy, bn_gamma, bn_mean, bn_var, bn_eps, bn_sums, dout_sums, dbias, stream);
 }
 
 int orcai_h_outer_reduce(const void* A, int Ca, const void* Bq, int Cb, int B, int H, int W, int ksize, int a_stride2, int Ha, int Wa, float* D, float* workspace,

@@ -16,7 +16,6 @@
 #include <type_traits>
 
 #include <cstdint>
-#include <cstdlib>
 
 #include "lds_dma.h"
 #include "orcai_hip.h"
@@ -2238,9 +2237,8 @@ template <int MT, int CQ>
 int launch_sepconv_tile(hipStream_t st, const SepArgs& a, int nstrip) {
   constexpr int TR = 8;
   dim3 grid(nstrip * ((a.H + TR - 1) / TR), a.B);
-  static const int exp_pad = getenv("ORCAI_EXP_LDS_PAD") ? atoi(getenv("ORCAI_EXP_LDS_PAD")) : 0;  // EXPERIMENT (occupancy sensitivity): unused dynamic LDS
 #define ORCAI_TILE_LAUNCH(XP, RELU, UOUT)                                                                                                       \
-  hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), exp_pad, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
+  hipLaunchKernelGGL((sepconv_tile_kernel<MT, CQ, XP, RELU, TR, UOUT>), grid, dim3(64 * TR), 0, st, a.in, a.Cin, a.H, a.W, a.WP, a.dw, a.pw, a.scale, \
                      a.shift, a.Cout, a.relu_out, a.out, nstrip, a.u_out)
   if (a.epi == 2) {  // input-gradient pass with the BatchNorm backward sums of its output (no ReLU on load, no depthwise-output store)
     if constexpr (MT == 2)

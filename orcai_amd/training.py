@@ -712,9 +712,9 @@ class TrunkTrainer:
         wt = self._w_pwT(name + "/pointwise", Cin, Cout)  # pointwise^T [Cout][Cin]
         if not sums_ready:  # the launcher reduces the BatchNorm backward sums itself (otherwise it READS them from self.scratch)
             self._fresh()
-        if self.fused_pw_wgrad and not self.half:
+        if self.fused_pw_wgrad:
             # one pass: dv formed per pixel, du = Wpw dv, AND the pointwise weight gradient u (x) dv -- dv is never written or re-read
-            rc = lib.orcai_bn_bwd_pointwise_wgrad(dy.data_ptr(), v.data_ptr(), u.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
+            rc = (lib.orcai_h_bn_bwd_pointwise_wgrad if self.half else lib.orcai_bn_bwd_pointwise_wgrad)(dy.data_ptr(), v.data_ptr(), u.data_ptr(), self.B, Cout, H, W, k, mean.data_ptr(), var.data_ptr(), P.W(bn + "/gamma").data_ptr(),
                                                   P.W(bn + "/beta").data_ptr(), BN_EPS, relu, self.scratch.data_ptr(), sums_ready, P.G(bn + "/beta").data_ptr(),
                                                   P.G(bn + "/gamma").data_ptr(), wt.data_ptr(), Cin, du.data_ptr(), P.G(name + "/pointwise").data_ptr(), self.partials.data_ptr(),
                                                   self.partials.numel(), st)
@@ -882,7 +882,7 @@ class TrunkTrainer:
                 N.check(lib.orcai_mask_scale(dprev.data_ptr(), self.block_masks[i - 1].data_ptr(), 1.0 / (1.0 - self.block_rate), dprev.numel(), dprev.data_ptr(), st),
                         "mask_scale")
             dout = dprev  # gradient w.r.t. prev_i (planes of f channels, ho x wo)
-            bias_in_pool = self.bias_in_pool and not self.half
+            bias_in_pool = self.bias_in_pool
             def residual_wgrad():  # residual 1x1 stride-2 conv: weight / bias gradients (read-only passes over prev and dout)
                 N.check(self._fn("outer_reduce")(prev.data_ptr(), cprev, dout.data_ptr(), f, B, ho, wo, k, 1, h, w, P.G(f"b{i}/res/kernel").data_ptr(),
                                                  self.partials.data_ptr(), self.partials.numel(), st), "outer_reduce")
@@ -898,7 +898,7 @@ class TrunkTrainer:
             self._fresh()
             if bias_in_pool:  # the residual conv's bias gradient (sum of dout) reduced where the pooling backward reads dout anyway
                 self._fresh_res()
-                N.check(lib.orcai_pool_bwd_bn_bias(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
+                N.check((lib.orcai_h_pool_bwd_bn_bias if self.half else lib.orcai_pool_bwd_bn_bias)(dout.data_ptr(), b[f"vb{i}"].data_ptr(), B, f, h, w, k, dyb.data_ptr(), P.W(f"b{i}/bn_b/gamma").data_ptr(), bmean.data_ptr(),
                                                    bvar.data_ptr(), BN_EPS, self.scratch.data_ptr(), self.res_scratch.data_ptr(), P.G(f"b{i}/res/bias").data_ptr(), st),
                         "pool_bwd_bn_bias")
             else:

@@ -430,6 +430,10 @@ def test_half_training_step_at_the_benchmarked_shapes(filters):
     assert rec.rcs("orcai_h_sepconv_stats") == [0] * 4 and rec.rcs("orcai_h_sepconv_stats_bn") == [0] * 4 and not rec.rcs("orcai_h_bn_planes_apply")[1:]
     assert rec.rcs("orcai_h_dw_bwd_fused") == [0] * 8 and rec.rcs("orcai_h_dw_bwd_fused_res") == [0] and rec.rcs("orcai_h_conv0_bn_bwd_ready") == [0]
     assert not rec.rcs("orcai_h_dw_wgrad") and not rec.rcs("orcai_h_planes_relu_bwd")
+    # block 1: BatchNorm backward + du + pointwise weight gradient in one pass (dv never written); the residual bias gradients inside the pooling backward
+    blk1 = [rc for n, rc, a in rec.calls if n == "orcai_h_bn_bwd_pointwise_wgrad" and (a[5], a[6]) == (736, 171)]
+    assert blk1 == [0, 0], blk1
+    assert rec.rcs("orcai_h_pool_bwd_bn_bias") == [0] * 4 and not rec.rcs("orcai_h_planes_sum")
 
 
 def _branch_matched_reference(cfg, B, tr, seed, rate):
@@ -609,6 +613,64 @@ def test_bn_bwd_pointwise_h_vs_f32_twin(C, Cin, H, W, relu, ready):
         assert np.abs(a - b).max() <= 3e-3 * max(1.0, np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
 
 
+@pytest.mark.parametrize("C,Cin,H,W,relu,ready", [(30, 30, 40, 171, 0, 1), (30, 16, 23, 171, 1, 0), (10, 10, 9, 86, 0, 1), (20, 16, 12, 21, 1, 1), (32, 32, 3, 300, 0, 0), (17, 9, 1, 64, 1, 0)])
+def test_bn_bwd_pointwise_wgrad_h_vs_two_launches(C, Cin, H, W, relu, ready):
+    """orcai_h_bn_bwd_pointwise_wgrad (BatchNorm backward apply + du = Wpw dv + the pointwise weight gradient u (x) dv in ONE pass, dv never written) against
+    the two launches it replaces: du, dbeta, dgamma bit-identical to orcai_h_bn_bwd_pointwise; dWpw against the float64 contraction of the SAME f16
+    operands (the u planes and the dv the two-launch path stores) and against orcai_h_outer_reduce; chunks that straddle snippets and plane ends,
+    one- and two-tile operands, BatchNorm sums taken by the launcher or handed in; more than 32 channels: ORCAI_E_UNSUPPORTED with nothing touched."""
+    from orcai_amd import _native as N
+    from orcai_amd.half import pack_pointwise_fragments
+
+    lib = N.lib()
+    rng = np.random.default_rng(C * 7 + Cin + W)
+    B, k = 3, 3
+    dy, v, u = _rand_planes(rng, B, C, H, W, k), _rand_planes(rng, B, C, H, W, k, 2.0), _rand_planes(rng, B, Cin, H, W, k)
+    mean, var = (0.3 * rng.standard_normal(C)).astype(np.float32), (0.5 + rng.random(C)).astype(np.float32)
+    gamma, beta = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+    wt = (rng.standard_normal((C, Cin)) / 4).astype(np.float16)  # pointwise^T [Cout][Cin]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    md, vd, gd, bd = dev(mean), dev(var), dev(gamma), dev(beta)
+    w = dev(pack_pointwise_fragments(wt.astype(np.float32)))
+    dyd, vdv, ud = dev(to_octet_planes(dy, k)), dev(to_octet_planes(v, k)), dev(to_octet_planes(u, k))
+    st = N.stream_ptr()
+    part = torch.zeros(1 << 21, device="cuda")
+
+    def sums():  # ready: the BatchNorm backward sums as an earlier launcher left them (here: taken by the two-launch kernel itself on a first call)
+        sc = torch.zeros(128, dtype=torch.float64, device="cuda")
+        return sc
+
+    # the two launches
+    dv = torch.zeros_like(dyd)
+    du_ref = torch.zeros((B, (Cin + 7) // 8) + tuple(dyd.shape[2:]), dtype=torch.float16, device="cuda")
+    sc_ref = sums()
+    dbeta_r, dgamma_r = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    N.check(lib.orcai_h_bn_bwd_pointwise(N.ptr(dyd), N.ptr(vdv), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(sc_ref), 0, N.ptr(dbeta_r),
+                                         N.ptr(dgamma_r), N.ptr(w), Cin, N.ptr(dv), N.ptr(du_ref), st), "h_bn_bwd_pointwise")
+    dW_ref = torch.zeros((Cin, C), device="cuda")
+    N.check(lib.orcai_h_outer_reduce(N.ptr(ud), Cin, N.ptr(dv), C, B, H, W, k, 0, 0, 0, N.ptr(dW_ref), N.ptr(part), part.numel(), st), "h_outer_reduce")
+    torch.cuda.synchronize()
+    # the fused launch (sums handed in when `ready`: sc_ref holds them)
+    du = torch.full_like(du_ref, 0.0)
+    sc = sc_ref.clone() if ready else sums()
+    dbeta, dgamma, dW = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros((Cin, C), device="cuda")
+    rc = lib.orcai_h_bn_bwd_pointwise_wgrad(N.ptr(dyd), N.ptr(vdv), N.ptr(ud), B, C, H, W, k, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, relu, N.ptr(sc), ready,
+                                            N.ptr(dbeta), N.ptr(dgamma), N.ptr(w), Cin, N.ptr(du), N.ptr(dW), N.ptr(part), part.numel(), st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.equal(du, du_ref)
+    assert torch.equal(dbeta, dbeta_r) and torch.equal(dgamma, dgamma_r)
+    dv_np = from_octet_planes(dv.float().cpu().numpy(), C, H, W, k)[0].astype(np.float64)
+    want = np.einsum("bihw,bohw->io", u.astype(np.float64), dv_np)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(dW.cpu().numpy() - want).max() <= 2e-5 * scale, (np.abs(dW.cpu().numpy() - want).max(), scale)  # f32 accumulation of exact f16 products
+    assert np.abs(dW.cpu().numpy() - dW_ref.cpu().numpy()).max() <= 4e-5 * scale
+    # beyond two tiles on either side: refused before anything is touched
+    big = torch.zeros(1 << 16, dtype=torch.float16, device="cuda")
+    assert lib.orcai_h_bn_bwd_pointwise_wgrad(N.ptr(big), N.ptr(big), N.ptr(big), 1, 40, 4, 8, 3, N.ptr(md), N.ptr(vd), N.ptr(gd), N.ptr(bd), 1e-3, 0, N.ptr(sc), 1, N.ptr(dbeta),
+                                              N.ptr(dgamma), N.ptr(w), 30, N.ptr(big), N.ptr(dW), N.ptr(part), part.numel(), st) == N.E_UNSUPPORTED
+
+
 @pytest.mark.parametrize("C,H,W", [(30, 12, 21), (12, 9, 14), (64, 7, 9), (20, 16, 6)])
 def test_pool_bwd_h_vs_f32_twin(C, H, W):
     from orcai_amd import _native as N
@@ -638,6 +700,21 @@ def test_pool_bwd_h_vs_f32_twin(C, H, W):
     for i, name in enumerate(("dy", "sum dy", "sum dy*xhat")):
         a, b = out[True][i], out[False][i]
         assert np.abs(a - b).max() <= 3e-3 * max(1.0, np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
+    # the same launch with the residual conv's bias gradient reduced where dout is read (orcai_h_pool_bwd_bn_bias): dy and the BatchNorm sums unchanged,
+    # dbias = the float64 sum of the f16 dout values, exactly what the separate orcai_h_planes_sum pass gives
+    dd, vv = dev(to_octet_planes(dout, k)), dev(to_octet_planes(v, k))
+    dy2 = torch.zeros_like(vv)
+    sums2, dsum = torch.zeros(128, dtype=torch.float64, device="cuda"), torch.full((64,), 5.0, dtype=torch.float64, device="cuda")
+    dbias, want = torch.full((64,), 9.0, device="cuda"), torch.zeros(64, device="cuda")
+    N.check(lib.orcai_h_pool_bwd_bn_bias(N.ptr(dd), N.ptr(vv), B, C, H, W, k, N.ptr(dy2), N.ptr(gd), N.ptr(md), N.ptr(vd), 1e-3, N.ptr(sums2), N.ptr(dsum), N.ptr(dbias),
+                                         N.stream_ptr()), "h_pool_bwd_bn_bias")
+    N.check(lib.orcai_h_planes_sum(N.ptr(dd), B, C, Ho, Wo, k, N.ptr(torch.zeros(64, dtype=torch.float64, device="cuda")), N.ptr(want), 0, N.stream_ptr()), "h_planes_sum")
+    torch.cuda.synchronize()
+    assert np.array_equal(from_octet_planes(dy2.float().cpu().numpy(), C, H, W, k)[0], out[True][0])
+    assert np.abs(sums2.cpu().numpy()[:C] - out[True][1]).max() <= 1e-9 * max(1.0, np.abs(out[True][1]).max())
+    ref64 = dout.astype(np.float64).sum(axis=(0, 2, 3))
+    assert np.abs(dbias[:C].cpu().numpy() - ref64).max() <= 1e-5 * max(1.0, np.abs(ref64).max())
+    assert np.abs(dbias[:C].cpu().numpy() - want[:C].cpu().numpy()).max() <= 1e-5 * max(1.0, np.abs(ref64).max())
 
 
 @pytest.mark.parametrize("C,H,W", [(12, 12, 21), (30, 9, 14), (8, 16, 6)])
