@@ -550,3 +550,92 @@ def test_depthwise_backward_rebuilds_the_entry_activation(H, W, B, res):
     n = B * H * W
     tol = 3e-6 * np.sqrt(n) * max(1.0, np.abs(dr_ref).max() * 3) + 2e-3  # + a gate decision or two within f32 rounding of zero
     assert np.abs(s[:16] - g.sum(axis=(0, 2, 3))).max() <= tol and np.abs(s[16:32] - (g * xh).sum(axis=(0, 2, 3))).max() <= tol, (np.abs(s[:16] - g.sum(axis=(0, 2, 3))).max(), np.abs(s[16:32] - (g * xh).sum(axis=(0, 2, 3))).max(), tol)
+
+
+def test_accumulator_arena_skips_only_fresh_slots():
+    """orcai_scratch_arena (one clear per step for every reduction scratch): a launcher's own zero fill is skipped for a 32-KiB slot nobody has taken since the
+    arena was cleared, and ONLY then -- a slot used a second time, a pointer outside the arena, a range that straddles two slots and an unregistered arena all get
+    the fill.  Seen from outside through orcai_planes_sum, which clears its scratch and then accumulates into it: a stale scratch would double the sum."""
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    B, C, H, W, k = 2, 8, 6, 10, 3
+    WP = lib.orcai_padded_width(W, k)
+    x = torch.zeros((B, 2, H + 2, WP, 4), device="cuda")
+    x[:, :, 1:H + 1, :W] = torch.rand((B, 2, H, W, 4), device="cuda")
+    want = x.double().sum(dim=(0, 2, 3)).reshape(-1).float()
+    arena = torch.full((4 * 4096,), 123.0, dtype=torch.float64, device="cuda")  # four slots of 32 KiB, full of garbage
+    out = torch.zeros(C, device="cuda")
+
+    def run(scratch):
+        N.check(lib.orcai_planes_sum(N.ptr(x), B, C, H, W, k, scratch.data_ptr(), N.ptr(out), 0, st), "planes_sum")
+        torch.cuda.synchronize()
+        return out.clone()
+
+    try:
+        assert lib.orcai_arena_take(arena.data_ptr(), 64) == 0  # nothing registered
+        N.check(lib.orcai_scratch_arena(arena.data_ptr(), arena.numel() * 8, st), "scratch_arena")
+        torch.cuda.synchronize()
+        assert float(arena.abs().max()) == 0.0  # ONE launch cleared all of it
+        assert torch.allclose(run(arena[:4096]), want, rtol=1e-6)  # fresh slot: fill skipped, the arena's zeros are the accumulator's start
+        assert float(arena[:32].abs().max()) > 0  # ... and the sums were left in the slot
+        assert torch.allclose(run(arena[:4096]), want, rtol=1e-6)  # the same slot again: NOT fresh any more -> cleared by the launcher -> still right
+        arena[4096:8192] = 5.0  # a slot somebody scribbled on without the library knowing: still "fresh" to the library ...
+        assert lib.orcai_arena_take(arena[4096:].data_ptr(), 32768 + 8) == 0  # ... but a range that straddles two slots is never skipped
+        assert lib.orcai_arena_take(arena[2 * 4096:].data_ptr(), 64) == 1 and lib.orcai_arena_take(arena[2 * 4096:].data_ptr(), 64) == 0  # take once
+        other = torch.full((4096,), 9.0, dtype=torch.float64, device="cuda")
+        assert torch.allclose(run(other), want, rtol=1e-6)  # outside the arena: cleared as ever
+    finally:
+        lib.orcai_scratch_arena(None, 0, None)
+    assert lib.orcai_arena_take(arena[3 * 4096:].data_ptr(), 64) == 0  # unregistered: nothing is skipped
+    garbage = torch.full((4096,), 7.0, dtype=torch.float64, device="cuda")
+    assert torch.allclose(run(garbage), want, rtol=1e-6)
+
+
+def test_poison_if_nonfinite_marks_the_gradient_bucket():
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    g = torch.ones(1000, device="cuda")
+    stats = torch.rand(300, device="cuda")
+    N.check(lib.orcai_poison_if_nonfinite(N.ptr(stats), 300, N.ptr(g), st), "poison")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all()) and float(g.sum()) == 1000.0  # finite statistics: nothing written
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        stats[177] = bad
+        g.fill_(1.0)
+        N.check(lib.orcai_poison_if_nonfinite(N.ptr(stats), 300, N.ptr(g), st), "poison")
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(g[0])) and bool(torch.isfinite(g[1:]).all())
+
+
+def test_lstm_backward_split_saturates_instead_of_overflowing():
+    """the split-f16 backward recurrence scales dz by the power of two taken from max|dH| of the INCOMING gradient; with large recurrent weights the
+    recurrent term grows past 2^16 times that maximum within a few steps, f16(dz S) would be inf and NaN would reach dxz and the weights.  dz S is saturated
+    at 2^15: dxz stays finite (the f32-MFMA kernel's behaviour); with ordinary weights the split kernel still agrees with the f32-MFMA one."""
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    Bn, T, u = 16, 46, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    gates = torch.rand((Bn, T, 2, 4 * u), generator=g).cuda() * 0.9 + 0.05
+    cs = (torch.rand((Bn, T, 2, u), generator=g).cuda() - 0.5)
+    dH = torch.randn((Bn, T, 2 * u), generator=g).cuda() * 1e-3
+    before = lib.orcai_lstm_split(-1)
+    try:
+        for scale, explode in ((0.05, False), (1.0, True)):
+            U = (torch.randn((2, u, 4 * u), generator=g) * scale).cuda()
+            outs = {}
+            for split in (1, 0):
+                lib.orcai_lstm_split(split)
+                dxz = torch.zeros((Bn, T, 2, 4 * u), device="cuda")
+                N.check(lib.orcai_lstm_bwd(N.ptr(dH), N.ptr(gates), N.ptr(cs), N.ptr(U), Bn, T, u, N.ptr(dxz), st), "lstm_bwd")
+                torch.cuda.synchronize()
+                outs[split] = dxz
+            if explode:
+                assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].abs().max()) > 65504.0 * float(dH.abs().max()) * 4  # the recurrence really left the f16 range of the scaled operand (and f32 holds it)
+                assert bool(torch.isfinite(outs[1]).all())  # no inf / NaN from the split operand
+            else:
+                assert float((outs[1] - outs[0]).abs().max()) <= 5e-6 * float(outs[0].abs().max())
+    finally:
+        lib.orcai_lstm_split(before)

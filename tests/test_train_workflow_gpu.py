@@ -280,6 +280,24 @@ def _dp_worker(rank, world, port, backend, mode, q):
             dist.barrier()
             dist.destroy_process_group()
         return
+    if mode == "verdict":  # f16 path: rank 1's SECOND batch holds an inf (its batch statistics become non-finite; rank 0's stay finite)
+        from orcai_amd.architectures import ResNetLSTM
+        from orcai_amd.training import Trainer
+
+        tr = Trainer(ResNetLSTM((32, 12, 1), 3, [10, 20], 3, 0.0, 64, seed=21, precision="f16"), learning_rate=3e-3)
+        w0 = tr.P.w.clone()
+        seen = []
+        for step in range(3):
+            xb = x.clone()
+            if step == 1 and rank == 1:
+                xb[5] = float("inf")
+            tr.train_step(xb, 32 * 12, 8, y, world_size=world)
+            seen.append((int(tr.skipped.item()), int(tr.counter.item()), float((tr.P.w - w0).abs().max())))
+        q.put((rank, w_before, tr.P.w.cpu().numpy(), {k: v.cpu().numpy() for k, v in tr.P.stats.items()}, seen))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     losses = []
     for _ in range(4):
         out = tr.train_step(x, 32 * 12, 8, y, world_size=world)
@@ -337,6 +355,19 @@ def test_loss_trajectory_is_world_size_invariant(backend):
         for r in res:
             assert np.abs(np.array(r[4]) - np.array(base)).max() <= 1e-5, (w, r[4], base)
             assert np.array_equal(r[2], res[0][2])
+
+
+def test_f16_step_verdict_is_global_across_replicas():
+    """orcai_step_ok sees the all-reduced gradient (the same on every rank) AND the rank-local batch statistics; a rank whose statistics alone are
+    non-finite must not void its step while the others apply theirs.  Rank 1's second batch holds an inf: both ranks skip exactly that step (skipped 0, 1, 1; the
+    device step counter 1, 1, 2), their weights stay bit-identical and finite, and the third step trains again (reference hpsearch.py:186-205: MirroredStrategy
+    applies or skips an update on all replicas together)."""
+    res = _run_dp(2, "gloo", "verdict")
+    for r in res:
+        assert [s[0] for s in r[4]] == [0, 1, 1] and [s[1] for s in r[4]] == [1, 1, 2], r[4]
+        assert r[4][0][2] > 0 and r[4][1][2] == r[4][0][2] and r[4][2][2] != r[4][1][2]  # step 2 moved nothing, step 3 moved the weights again
+        assert np.isfinite(r[2]).all()
+    assert np.array_equal(res[0][2], res[1][2])
 
 
 def test_split_batch_is_the_mirrored_strategy_contract():
