@@ -61,6 +61,27 @@ def traffic_file():
     return found[-1] if found else None
 
 
+def measured_issue(symbol: str):
+    """SIMD occupancy / busy shares of `symbol` from the newest committed counter pass at the benchmark's launch size (tools/pmc_occupancy.sh ->
+    profiles/rNN_pmc_occupancy_fused_tail.json): resident waves per SIMD, share of SIMD cycles the vector ALU / the matrix pipe was occupied (SQ_* count
+    quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs).  None when there is no such file or it does not know the symbol."""
+    import json
+    from pathlib import Path
+
+    found = sorted((Path(__file__).resolve().parent / "profiles").glob("r*_pmc_occupancy_fused_tail.json"))
+    if not found:
+        return None
+    d = json.loads(found[-1].read_text())
+    try:
+        g = lambda c: d[c][symbol]["mean_per_launch"]  # noqa: E731
+        dur = g("GRBM_GUI_ACTIVE") / 8
+        return {"waves_per_simd": round(g("SQ_WAVE_CYCLES") * 4 / 1024 / dur, 2), "valu_busy": round(g("SQ_ACTIVE_INST_VALU") * 4 / 1024 / dur, 3),
+                "mfma_busy": round(g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / dur, 3), "wait_share_of_wave_life": round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 2),
+                "source": "profiles/" + found[-1].name}
+    except KeyError:
+        return None
+
+
 def measured_traffic(symbol: str, workload: str = "predict"):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE
     in separate runs; gfx950: FETCH_SIZE counts wide reads at half, MI355X_MICROARCH.md HBM section).  None only when no table has been
@@ -210,6 +231,9 @@ class PredictWorkload:
                         "kernel_tflops": round(d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12, 2)})
             if out["traffic"]:  # PMC bytes (2*FETCH_SIZE + WRITE_SIZE of the committed passes) over the algorithmic bytes: > 1 = padding / re-reads
                 out["traffic_ratio"] = round(out["traffic"] / out["algorithmic_bytes_per_launch"], 3)
+            issue = measured_issue(dominant)
+            if issue:  # what the kernel is bound by when it is not its bytes: vector ALU and f32 MFMA share one datapath
+                out["simd_issue"] = issue
         else:
             out.update({"bound": "mfma", "achieved": None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None})
         by_symbol = {}
