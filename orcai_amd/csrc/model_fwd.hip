@@ -769,173 +769,6 @@ __global__ __launch_bounds__(64 * TRW) void conv0_sep_tile_kernel(const float* _
 }
 
 // =========================================================================================
-// conv0_sep_march: conv0_sep_tile with the workgroup MARCHING down its column strip.  The tile kernel spends 10 waves on 8 output rows: ten entry rows are
-// computed per tile (the two halo rows again by the neighbouring tile) and two of the ten waves retire after phase 1.  Here 8 waves walk NT tiles of 8 output
-// rows; the 16-channel entry activation lives in an LDS RING of 10 rows -- a tile's first two entry rows are the previous tile's last two -- so every entry row
-// is computed ONCE (wave w: row y0 + 1 + w), no wave idles, the pointwise weights / folded BatchNorms are staged once per workgroup, and the nine input
-// dwords of the next tile's entry row are requested during the current tile's separable-conv phase.  Two barriers per tile (ring written | ring read).
-// Everything loop-invariant that the compiler would hoist out of the tile loop and spill -- ~300 scalar weights, per-lane addresses -- is re-derived per tile
-// (opaque zero offset, v_mbcnt lane id: sepconv_pool_march_kernel's rule).  Same fma / MFMA chains as conv0_sep_tile_kernel: bit-identical.
-// =========================================================================================
-template <int MT>
-__global__ __launch_bounds__(512) void conv0_sep_march_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
-                                                              const float* __restrict__ w0_ /*[9][16]*/, const float* __restrict__ sc0_,
-                                                              const float* __restrict__ sh0_, const float* __restrict__ dw_ /*[4][9][4]*/,
-                                                              const float* __restrict__ pw /*[16][Cout]*/, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int Cout, int relu_out, float* __restrict__ out,
-                                                              float* __restrict__ prev_sub, int nstrip, int NT) {
-  constexpr int R = 1, lo = 1, VAL = 62, C0 = 16, TR = 8, NR = TR + 2;
-  __shared__ __attribute__((aligned(16))) float act_s[NR][C0 / 4][256];  // ring: entry row e lives in slot (e + 1) mod NR, [quad][lane][4]
-  __shared__ float pw_s[C0 * 16 * MT];                                    // [(ci * 16 + lj)][m]
-  __shared__ float sc_s[MT * 16], sh_s[MT * 16];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int bx, b;
-  xcd_remap(bx, b);
-  const int seg = bx / nstrip, strip = bx - seg * nstrip;
-  const int yb = seg * NT * TR, c0 = strip * VAL;  // first output row of the segment
-  const int rows_left = H - yb;
-  const int ntile = (rows_left < NT * TR ? rows_left + TR - 1 : NT * TR) / TR;
-  const int y_end = yb + NT * TR;  // entry rows this segment OWNS (writes the residual subsample of): [yb, y_end)
-  const int plane = (H + 2 * R) * WP;
-  const int CQo = (Cout + 3) >> 2;
-  const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
-  const float lo_out = relu_out ? 0.0f : -INFINITY;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (int64_t)b * snippet_stride), 0, H * W * 4, 0x00020000);
-  constexpr uint32_t OOB = 0x80000000u;  // stays out of range after adding a row pitch
-
-  for (int i = threadIdx.x; i < C0 * 16 * MT; i += 64 * TR) {
-    const int m = i % MT, lj_ = (i / MT) % 16, ci = i / (16 * MT), co = m * 16 + lj_;
-    pw_s[i] = co < Cout ? pw[ci * Cout + co] : 0.0f;
-  }
-  if (threadIdx.x < MT * 16) {
-    const int co = threadIdx.x;
-    sc_s[co] = co < Cout ? scale[co] : 0.0f;
-    sh_s[co] = co < Cout ? shift[co] : 0.0f;
-  }
-
-  // the nine input dwords of entry row e at this lane's column (rows outside the snippet / columns outside the image read as 0 through the range check)
-  auto request = [&](int e, int lane, f32x2 (&inp)[5]) {
-    const int x = c0 - lo + lane;
-    const uint32_t center = (uint32_t)((e * W + x) * 4);
-    const bool e_ok = e >= -1 && e <= H;
-    const uint32_t off[3] = {(e_ok && x >= 1 && x <= W) ? center - 4u : OOB, (e_ok && x >= 0 && x < W) ? center : OOB, (e_ok && x >= -1 && x + 1 < W) ? center + 4u : OOB};
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        inp[(3 * d + j) >> 1][(3 * d + j) & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off[j] + (uint32_t)((d - 1) * W * 4), 0, 0));
-    inp[4][1] = 0.0f;
-  };
-  // entry activation of row e from its nine inputs -> ring slot (conv0_kernel's fma chain, folded BatchNorm, ReLU, zero outside the image) and, for rows this
-  // segment owns, the residual branch's (2i, 2j) subsample
-  auto entry_row = [&](int e, int lane, const f32x2 (&inp)[5], int oz) {
-    const int x = c0 - lo + lane;
-    const float hi = (x >= 0 && x < W && e >= 0 && e < H) ? INFINITY : 0.0f;
-    const bool sub_lane = prev_sub && e >= yb && e < y_end && lane >= lo && lane < 64 - lo && x < W && e < H && ((x | e) & 1) == 0;
-    float4* sub = reinterpret_cast<float4*>(prev_sub) + (int64_t)b * (C0 / 4) * Ho * Wo + (e >> 1) * Wo + (x >> 1);
-    const float* w0 = static_cast<const float*>(__builtin_assume_aligned(w0_ + oz, 16));
-    const float* sc0 = static_cast<const float*>(__builtin_assume_aligned(sc0_ + oz, 16));
-    const float* sh0 = static_cast<const float*>(__builtin_assume_aligned(sh0_ + oz, 16));
-    const int slot = (e + 1) % NR;
-#pragma unroll
-    for (int cq = 0; cq < C0 / 4; ++cq) {
-      const f32x2 s01 = {sc0[cq * 4 + 0], sc0[cq * 4 + 1]}, s23 = {sc0[cq * 4 + 2], sc0[cq * 4 + 3]};
-      const f32x2 h01 = {sh0[cq * 4 + 0], sh0[cq * 4 + 1]}, h23 = {sh0[cq * 4 + 2], sh0[cq * 4 + 3]};
-      f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float* wt = w0 + (dy * 3 + dx) * C0 + cq * 4;
-          const f32x2 w01 = {wt[0], wt[1]}, w23 = {wt[2], wt[3]};
-          const int ii = 3 * dy + dx;
-          a01 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w01, a01) : pk_fma_bcast<0>(inp[ii >> 1], w01, a01));
-          a23 = ((ii & 1) ? pk_fma_bcast<1>(inp[ii >> 1], w23, a23) : pk_fma_bcast<0>(inp[ii >> 1], w23, a23));
-        }
-      a01 = a01 * s01 + h01;
-      a23 = a23 * s23 + h23;
-      const float4 c = make_float4(relu_mask(a01.x, hi), relu_mask(a01.y, hi), relu_mask(a23.x, hi), relu_mask(a23.y, hi));
-      *reinterpret_cast<float4*>(&act_s[slot][cq][lane * 4]) = c;
-      if (sub_lane) sub[(int64_t)cq * Ho * Wo] = c;
-    }
-  };
-  auto lane_id = []() {
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-  };
-
-  f32x2 inp[5];
-  // prologue: the segment's first two entry rows (yb - 1, yb) by waves 0 and 1; then every wave requests its row of tile 0
-  if (wave < 2) {
-    const int l = lane_id();
-    request(yb - 1 + wave, l, inp);
-    entry_row(yb - 1 + wave, l, inp, 0);
-  }
-  request(yb + 1 + wave, lane_id(), inp);
-
-  for (int t = 0; t < ntile; ++t) {
-    const int y0 = yb + t * TR;
-    int oz = 0;
-    asm volatile("" : "+s"(oz));
-    const int lane = lane_id();
-    const int lk = lane >> 4, lj = lane & 15;
-    // ---- phase 1: entry row y0 + 1 + wave into the ring (its slot held a row the previous tile's phase 2 has finished with: barrier B below)
-    entry_row(y0 + 1 + wave, lane, inp, oz);
-    __syncthreads();  // A: the ring holds rows y0 - 1 .. y0 + 8 (and, first tile, the staged weights)
-    if (t + 1 < ntile) request(y0 + TR + 1 + wave, lane, inp);  // next tile's inputs: in flight during phase 2
-    // ---- phase 2: output row y0 + wave: depthwise 3x3 over entry rows y - 1 .. y + 1, pointwise on the MFMA
-    const int y = y0 + wave;
-    if (y < H) {
-      f32x4 acc[MT][4];
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[m][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* dw = static_cast<const float*>(__builtin_assume_aligned(dw_ + oz, 16));
-      int sl[3];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) sl[dy] = (y + dy) % NR;  // entry row y - 1 + dy -> slot (y + dy) mod NR
-#pragma unroll
-      for (int cq = 0; cq < C0 / 4; ++cq) {
-        float4 c0r[3];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) c0r[dy] = *reinterpret_cast<const float4*>(&act_s[sl[dy]][cq][lane * 4]);
-        float afrag[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) afrag[m] = pw_s[((cq * 4 + lk) * 16 + lj) * MT + m];
-        float d[4];
-        dw_quad_impl<3, false>(c0r, dw + cq * 36, d);
-        swap32(d[0], d[2]);
-        swap32(d[1], d[3]);
-        swap16(d[0], d[1]);
-        swap16(d[2], d[3]);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][tt] = mfma16(afrag[m], d[tt], acc[m][tt]);
-      }
-      float4* outb = reinterpret_cast<float4*>(out) + (int64_t)b * CQo * plane + (R + y) * WP;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int wl = 16 * tt + lj;
-        const int xx = c0 - lo + wl;
-        const bool live = wl >= lo && wl < 64 - lo && xx < W;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float4 sc = reinterpret_cast<const float4*>(sc_s)[m * 4 + lk], sh = reinterpret_cast<const float4*>(sh_s)[m * 4 + lk];
-          const int oq = m * 4 + lk;
-          if (live && oq < CQo)
-            outb[(int64_t)oq * plane + xx] = make_float4(max2(fmaf(acc[m][tt][0], sc.x, sh.x), lo_out), max2(fmaf(acc[m][tt][1], sc.y, sh.y), lo_out),
-                                                        max2(fmaf(acc[m][tt][2], sc.z, sh.z), lo_out), max2(fmaf(acc[m][tt][3], sc.w, sh.w), lo_out));
-        }
-      }
-    }
-    __syncthreads();  // B: every wave has read the ring; the next tile's phase 1 may overwrite the eight oldest rows
-  }
-}
-
-// =========================================================================================
 // sepconv_tile: the arithmetic of sepconv_kernel<3, MT> with the window rows shared through LDS, for planes
 // several windows wide (block 1).  A workgroup of TR waves owns a 2-D tile of TR image rows x 64 columns (one row per wave); per
 // input quad the tile's TR + 2 rows are fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
@@ -2539,7 +2372,7 @@ int orcai_padded_width(int W, int ksize) { return (W + ksize / 2 + 3) & ~3; }
 
 int orcai_entry_tile(int waves) {
   const int prev = g_entry_tile;
-  if (waves == 0 || waves == 10 || waves == 16 || (waves > 100 && waves <= 192)) g_entry_tile = waves;  // 100 + NT: the marching kernel over NT tiles
+  if (waves == 0 || waves == 10 || waves == 16) g_entry_tile = waves;
   return prev;
 }
 
@@ -2618,12 +2451,7 @@ int orcai_conv0_sepconv(const float* in, int64_t snippet_stride, int B, int H, i
   hipStream_t st = (hipStream_t)stream;
   const int nstrip = (W + 61) / 62;
   if (g_entry_tile && Cout > 16 && Cout <= 32 && nstrip >= 2 && W * 100 >= nstrip * 62 * 85) {  // wide planes: entry rows shared through LDS
-    if (g_entry_tile >= 100) {  // marching: a workgroup walks g_entry_tile - 100 tiles of 8 output rows down its strip, entry rows in an LDS ring
-      const int NT = g_entry_tile - 100;
-      dim3 grid(nstrip * ((H + NT * 8 - 1) / (NT * 8)), B);
-      hipLaunchKernelGGL((conv0_sep_march_kernel<2>), grid, dim3(512), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, Cout, relu_out, out,
-                         prev_sub, nstrip, NT);
-    } else if (g_entry_tile == 16) {
+    if (g_entry_tile == 16) {
       dim3 grid(nstrip * ((H + 13) / 14), B);
       hipLaunchKernelGGL((conv0_sep_tile_kernel<2, 16>), grid, dim3(1024), 0, st, in, snippet_stride, H, W, WP, w0, scale0, shift0, dw, pw, scale, shift, Cout,
                          relu_out, out, prev_sub, nstrip);

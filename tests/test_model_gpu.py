@@ -402,7 +402,7 @@ def test_fused_entry_random_shapes():
         a_ref = torch.zeros((B, CQo, H + 2, WP, 4), device=dev)
         assert lib.orcai_conv0_bn_relu(N.ptr(src), stride, B, H, W, 3, N.ptr(w0), N.ptr(sc0), N.ptr(sh0), N.ptr(prev0), st) == 0
         assert lib.orcai_sepconv_bn(N.ptr(prev0), B, 16, H, W, 3, 1, N.ptr(dw), N.ptr(pw), N.ptr(sc), N.ptr(sh), Cout, relu_out, 0, N.ptr(a_ref), st) == 0
-        for nw, tile in ((1, 0), (2, 0), (5, 0), (4, 10), (4, 16), (4, 101), (4, 102), (4, 108)):  # 100 + NT: the marching kernel over NT tiles per workgroup
+        for nw, tile in ((1, 0), (2, 0), (5, 0), (4, 10), (4, 16)):
             prev = lib.orcai_entry_windows(nw)
             prev_tile = lib.orcai_entry_tile(tile)
             try:
