@@ -475,7 +475,7 @@ class TrainWorkload:
     data parallel over RCCL (one flat 3.98 MB gradient all-reduce per step).  One step = forward (training mode) +
     masked BCE + backward + all-reduce + Adam; metric snippets/s."""
 
-    name = "orcai-V1 train step, batch 64 per GPU, synthetic snippets"
+    name = "orcai-V1 train step, synthetic snippets (64 per GPU, or the global batch of 64 split over the ranks with --dp-batch split)"
     metric = "snippets_per_s"
     unit = "snippets/s"
     dtype = "f32"
@@ -732,7 +732,11 @@ class HpsearchWorkload:
         (section hpsearch_f16_set3: the counters were collected on the widest variant)."""
         for v in self.variants:
             self.timed[v].mode, self.timed[v].events = "all", {}
-        self.step(False)
+        world, self.world = self.world, 1  # rank-local: only rank 0 calls roofline(), so NO collective may run here
+        try:
+            self.step(False)
+        finally:
+            self.world = world
         torch.cuda.synchronize()
         by_symbol = {}
         for v in self.variants:
