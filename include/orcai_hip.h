@@ -508,6 +508,18 @@ int orcai_counter_advance_guarded(uint64_t* counter, const int32_t* ok, void* st
  * orcai_ema_update: moving = moving*momentum + batch*(1 - momentum)  (BatchNormalization moving statistics, one flat buffer). */
 int orcai_pack_lstm(const float* w, const int* desc, int n_desc, float* out32, void* out16, void* stream);
 int orcai_unpack_lstm_grad(const float* src, int ld_src, int col_off, int rows, int units, float* G, const float* W, float l2g, void* stream);
+/* The same for up to 16 (source, destination) pairs in ONE launch -- the 12 of both BiLSTM layers of a training step -- and the value of the L2 penalty over up
+ * to 8 slices of the flat weight buffer in one launch (train.py:201-219: kernel_regularizer=l2(0.001) on the LSTM input kernels and Dense-128).  `descs_host`,
+ * `off_host`, `n_host` are HOST arrays, read during the call (the descriptors travel by value in the kernel arguments: nothing to keep alive, capturable). */
+typedef struct {
+  const float* src; /* kernel-order gradient [rows][ld_src] */
+  int ld_src, col_off, rows;
+  float* G;         /* Keras-layout destination [rows][4 * units] */
+  const float* W;   /* Keras-layout weights for the L2 term, or NULL */
+  float l2g;
+} orcai_unpack_desc;
+int orcai_unpack_lstm_grads(const orcai_unpack_desc* descs_host, int n, int units, void* stream);
+int orcai_l2_values(const float* base, const int64_t* off_host, const int64_t* n_host, int count, float lambda, double* out, void* stream);
 int orcai_ema_update(float* moving, const float* batch, int n, float momentum, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -17,6 +17,12 @@ _lib = None
 c_i64 = C.c_int64
 c_f32p = C.c_void_p  # device pointers travel as void*
 
+class UnpackDesc(C.Structure):
+    """orcai_unpack_desc of include/orcai_hip.h."""
+
+    _fields_ = [("src", C.c_void_p), ("ld_src", C.c_int), ("col_off", C.c_int), ("rows", C.c_int), ("G", C.c_void_p), ("W", C.c_void_p), ("l2g", C.c_float)]
+
+
 _SIGNATURES = {
     "orcai_version": (C.c_char_p, []),
     "orcai_frontend_workspace_bytes": (C.c_size_t, []),
@@ -142,6 +148,8 @@ _SIGNATURES = {
     "orcai_counter_advance_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_pack_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_unpack_lstm_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "orcai_unpack_lstm_grads": (C.c_int, [C.POINTER(UnpackDesc), C.c_int, C.c_int, C.c_void_p]),
+    "orcai_l2_values": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "orcai_make_spectrogram": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_int, c_i64, C.c_int, c_i64, c_i64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -183,7 +191,8 @@ def lib() -> C.CDLL:
     return _lib
 
 
-E_UNSUPPORTED = -2  # ORCAI_E_UNSUPPORTED (include/orcai_hip.h)
+E_BADARG = -1  # ORCAI_E_BADARG (include/orcai_hip.h)
+E_UNSUPPORTED = -2  # ORCAI_E_UNSUPPORTED
 
 
 def check(code: int, what: str) -> None:

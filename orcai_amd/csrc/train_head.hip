@@ -1197,6 +1197,41 @@ __global__ __launch_bounds__(256) void unpack_lstm_grad_kernel(const float* __re
   G[k] = v;
 }
 
+// the same for up to 16 (source, destination) pairs in ONE launch (both BiLSTM layers of a step: 12 pairs), descriptors by value in the kernel arguments
+struct UnpackBatch {
+  orcai_unpack_desc d[16];
+};
+__global__ __launch_bounds__(256) void unpack_lstm_grads_kernel(UnpackBatch b, int u) {
+  const orcai_unpack_desc d = b.d[blockIdx.y];
+  const int64_t n = (int64_t)d.rows * 4 * u;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (4 * u)), p = (int)(i - (int64_t)r * 4 * u);
+    const int64_t k = (int64_t)r * 4 * u + lstm_perm(p, u);
+    float v = d.src[(int64_t)r * d.ld_src + d.col_off + p];
+    if (d.W) v = fmaf(d.l2g, d.W[k], v);
+    d.G[k] = v;
+  }
+}
+
+// out += lambda * sum w^2 over up to 8 slices of one buffer in ONE launch (blockIdx.y = slice)
+struct L2Batch {
+  int64_t off[8], n[8];
+};
+__global__ __launch_bounds__(256) void l2_values_kernel(const float* __restrict__ base, L2Batch b, float lambda, double* __restrict__ out) {
+  __shared__ double s[256];
+  const float* w = base + b.off[blockIdx.y];
+  const int64_t n = b.n[blockIdx.y];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)w[i] * (double)w[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, (double)lambda * s[0]);
+}
+
 // moving = moving * momentum + batch * (1 - momentum) over one flat buffer of all BatchNorm statistics
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ moving, const float* __restrict__ batch, int n, float momentum, const int32_t* __restrict__ ok = nullptr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1476,6 +1511,35 @@ int orcai_pack_lstm(const float* w, const int* desc, int n_desc, float* out32, v
 int orcai_unpack_lstm_grad(const float* src, int ld_src, int col_off, int rows, int units, float* G, const float* W, float l2g, void* stream) {
   if (!src || !G || rows <= 0 || units <= 0 || (units & 7) || col_off < 0 || ld_src < col_off + 4 * units) return ORCAI_E_BADARG;
   hipLaunchKernelGGL(unpack_lstm_grad_kernel, dim3(blocks_for((int64_t)rows * 4 * units)), dim3(256), 0, (hipStream_t)stream, src, ld_src, col_off, rows, units, G, W, l2g);
+  return (int)hipGetLastError();
+}
+
+int orcai_unpack_lstm_grads(const orcai_unpack_desc* descs_host, int n, int units, void* stream) {
+  if (!descs_host || n <= 0 || n > 16 || units <= 0 || (units & 7)) return ORCAI_E_BADARG;
+  UnpackBatch b;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    const orcai_unpack_desc& d = descs_host[i];
+    if (!d.src || !d.G || d.rows <= 0 || d.col_off < 0 || d.ld_src < d.col_off + 4 * units) return ORCAI_E_BADARG;
+    b.d[i] = d;
+    const int64_t e = (int64_t)d.rows * 4 * units;
+    most = e > most ? e : most;
+  }
+  unsigned gx = blocks_for(most);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(unpack_lstm_grads_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, b, units);
+  return (int)hipGetLastError();
+}
+
+int orcai_l2_values(const float* base, const int64_t* off_host, const int64_t* n_host, int count, float lambda, double* out, void* stream) {
+  if (!base || !off_host || !n_host || !out || count <= 0 || count > 8) return ORCAI_E_BADARG;
+  L2Batch b;
+  for (int i = 0; i < count; ++i) {
+    if (off_host[i] < 0 || n_host[i] <= 0) return ORCAI_E_BADARG;
+    b.off[i] = off_host[i];
+    b.n[i] = n_host[i];
+  }
+  hipLaunchKernelGGL(l2_values_kernel, dim3(64, count), dim3(256), 0, (hipStream_t)stream, base, b, lambda, out);
   return (int)hipGetLastError();
 }
 

@@ -247,7 +247,12 @@ class HeadTrainer:
         # Dense-128: dW1 = h2d^T dpre + 2 lambda W1, db1, dh2d = dpre W1^T
         _gemm(lib, c["h2d"], 1, 2 * u, dpre, DENSE_UNITS, 1, P.G("dense1/kernel"), 2 * u, DENSE_UNITS, M, wreg=P.W("dense1/kernel"), beta_w=l2g)
         N.check(lib.orcai_colsum(dpre.data_ptr(), M, DENSE_UNITS, P.G("dense1/bias").data_ptr(), 0, st), "colsum")
-        N.check(lib.orcai_l2_value(P.W("dense1/kernel").data_ptr(), P.W("dense1/kernel").numel(), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_value")
+        # the value of the L2 penalty over the five regularised kernels: one launch over their slices of the flat weight buffer
+        l2_names = ["dense1/kernel"] + [f"lstm{layer}/{name}/kernel" for layer in (1, 2) for name in ("fwd", "bwd")]
+        offs = (N.c_i64 * len(l2_names))(*[P.offsets[n][0] for n in l2_names])
+        cnts = (N.c_i64 * len(l2_names))(*[P.offsets[n][1] for n in l2_names])
+        N.check(lib.orcai_l2_values(P.w.data_ptr(), offs, cnts, len(l2_names), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_values")
+        unpack, alive = [], []  # kernel-order LSTM gradients -> the Keras-layout gradient buffer: ONE launch for both layers at the end (sources kept alive until then)
         dh = torch.empty((M, 2 * u), **f32)
         _gemm(lib, dpre, DENSE_UNITS, 1, P.W("dense1/kernel"), 1, DENSE_UNITS, dh, M, 2 * u, DENSE_UNITS)
         for layer in (2, 1):
@@ -269,14 +274,16 @@ class HeadTrainer:
                 dU = torch.empty((u, 4 * u), **f32)
                 _gemm(lib, hp.view(-1)[d * u :], 1, 2 * u, dxz.view(-1)[d * 4 * u :], 8 * u, 1, dU, u, 4 * u, M)
                 Wk = P.W(f"lstm{layer}/{name}/kernel")
-                # kernel-order gradients back into the Keras-layout gradient buffer (+ the L2 term of the input kernel), one launch each
-                N.check(lib.orcai_unpack_lstm_grad(dU.data_ptr(), 4 * u, 0, u, u, P.G(f"lstm{layer}/{name}/recurrent").data_ptr(), None, 0.0, st), "unpack")
-                N.check(lib.orcai_unpack_lstm_grad(dWc.data_ptr(), 8 * u, d * 4 * u, fin, u, P.G(f"lstm{layer}/{name}/kernel").data_ptr(), Wk.data_ptr(), l2g, st), "unpack")
-                N.check(lib.orcai_unpack_lstm_grad(dbc.data_ptr(), 8 * u, d * 4 * u, 1, u, P.G(f"lstm{layer}/{name}/bias").data_ptr(), None, 0.0, st), "unpack")
-                N.check(lib.orcai_l2_value(Wk.data_ptr(), Wk.numel(), L2_LAMBDA, acc[3:].data_ptr(), st), "l2_value")
+                # kernel-order gradients back into the Keras-layout gradient buffer (+ the L2 term of the input kernel)
+                unpack.append(N.UnpackDesc(dU.data_ptr(), 4 * u, 0, u, P.G(f"lstm{layer}/{name}/recurrent").data_ptr(), None, 0.0))
+                unpack.append(N.UnpackDesc(dWc.data_ptr(), 8 * u, d * 4 * u, fin, P.G(f"lstm{layer}/{name}/kernel").data_ptr(), Wk.data_ptr(), l2g))
+                unpack.append(N.UnpackDesc(dbc.data_ptr(), 8 * u, d * 4 * u, 1, P.G(f"lstm{layer}/{name}/bias").data_ptr(), None, 0.0))
+                alive += [dU, dWc, dbc]
             dx = torch.empty((M, fin), **f32)
             _gemm(lib, dxz, 8 * u, 1, lc["Wc"], 1, 8 * u, dx, M, fin, 8 * u)
             dh = dx
+        N.check(lib.orcai_unpack_lstm_grads((N.UnpackDesc * len(unpack))(*unpack), len(unpack), u, st), "unpack_lstm_grads")
+        del alive
         # BN_f + ReLU backward on the Keras-Reshape layout
         dfeatv = torch.empty_like(c["featv"])
         cols = c["featv"].shape[2]

@@ -29,7 +29,7 @@ def test_default_line_with_two_ranks_and_split_batches():
     assert "error" not in s and s["n_gpus"] == 2 and s["scaling"] == "strong" and s["config"]["per_rank_batch"] == 32 and s["config"]["global_batch"] == 64
     assert s["allreduce_us"] > 0 and s["allreduce_bytes"] == 4 * 994959
     assert "error" not in s2 and s2["scaling"] == "strong" and s2["roofline"]["kernel"]  # rank 0's own fully bracketed sweep step ran without a collective
-    assert d["roofline"]["kernel"].startswith("sepconv_pool_march_kernel")
+    assert d["roofline"]["kernel"].split("<")[0] in ("sepconv_pool_march_kernel", "conv0_sep_tile_kernel")  # (two ranks time-share the one card here: either of the two largest may top)
 
 
 def test_training_workloads_with_two_ranks():

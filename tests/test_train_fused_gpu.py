@@ -639,3 +639,46 @@ def test_lstm_backward_split_saturates_instead_of_overflowing():
                 assert float((outs[1] - outs[0]).abs().max()) <= 5e-6 * float(outs[0].abs().max())
     finally:
         lib.orcai_lstm_split(before)
+
+
+def test_batched_lstm_gradient_unpack_and_l2_values_match_the_single_launches():
+    """Round 4: orcai_unpack_lstm_grads (12 (source, destination) pairs of a step in one launch) and orcai_l2_values (the five regularised kernels in one
+    launch) against one orcai_unpack_lstm_grad / orcai_l2_value launch each: bit-identical gradients, the same penalty to double rounding of the sum."""
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    u = 64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    cases = []  # (src, ld, col_off, rows, W or None, l2g)
+    for fin in (256, 2 * u):
+        dWc = torch.randn((fin, 8 * u), generator=g).cuda()
+        dbc = torch.randn((8 * u,), generator=g).cuda()
+        for d in (0, 1):
+            dU = torch.randn((u, 4 * u), generator=g).cuda()
+            Wk = torch.randn((fin, 4 * u), generator=g).cuda()
+            cases += [(dU, 4 * u, 0, u, None, 0.0), (dWc, 8 * u, d * 4 * u, fin, Wk, 2e-3), (dbc, 8 * u, d * 4 * u, 1, None, 0.0)]
+    one = [torch.full((rows, 4 * u), 7.0, device="cuda") for _, _, _, rows, _, _ in cases]
+    many = [torch.full((rows, 4 * u), -7.0, device="cuda") for _, _, _, rows, _, _ in cases]
+    descs = []
+    for (src, ld, off, rows, W, l2g), a, b in zip(cases, one, many):
+        N.check(lib.orcai_unpack_lstm_grad(N.ptr(src), ld, off, rows, u, N.ptr(a), N.ptr(W) if W is not None else None, l2g, st), "unpack")
+        descs.append(N.UnpackDesc(src.data_ptr(), ld, off, rows, b.data_ptr(), W.data_ptr() if W is not None else None, l2g))
+    N.check(lib.orcai_unpack_lstm_grads((N.UnpackDesc * len(descs))(*descs), len(descs), u, st), "unpack_lstm_grads")
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    assert lib.orcai_unpack_lstm_grads((N.UnpackDesc * 17)(), 17, u, st) == N.E_BADARG
+    bad = N.UnpackDesc(cases[0][0].data_ptr(), 4 * u - 1, 0, u, many[0].data_ptr(), None, 0.0)  # a row shorter than the 4 u columns read from it
+    assert lib.orcai_unpack_lstm_grads((N.UnpackDesc * 1)(bad), 1, u, st) == N.E_BADARG
+
+    flat = torch.randn((300_000,), generator=g).cuda()
+    slices = [(0, 32768), (40_000, 131072), (171_072, 1), (200_000, 99_999)]
+    acc = torch.zeros(2, dtype=torch.float64, device="cuda")
+    for o, n in slices:
+        N.check(lib.orcai_l2_value(flat[o:].data_ptr(), n, 1e-3, acc[0:].data_ptr(), st), "l2_value")
+    offs, cnts = (N.c_i64 * len(slices))(*[o for o, _ in slices]), (N.c_i64 * len(slices))(*[n for _, n in slices])
+    N.check(lib.orcai_l2_values(N.ptr(flat), offs, cnts, len(slices), 1e-3, acc[1:].data_ptr(), st), "l2_values")
+    torch.cuda.synchronize()
+    want = float(np.float32(1e-3)) * sum(float((flat[o : o + n].double() ** 2).sum()) for o, n in slices)  # (lambda crosses the C ABI as a float)
+    assert abs(float(acc[1]) - want) <= 1e-12 * want and abs(float(acc[0]) - float(acc[1])) <= 1e-12 * want
+    assert lib.orcai_l2_values(N.ptr(flat), offs, cnts, 9, 1e-3, acc[1:].data_ptr(), st) == N.E_BADARG
