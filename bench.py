@@ -136,6 +136,10 @@ except ImportError:
     pass
 
 
+def _dp_label(dist, world, what="one flat fp32 gradient bucket") -> str:
+    return f"dp{world} ({_backend_name(dist)} all-reduce of {what})" if dist else "dp1 (single rank: no collective)"
+
+
 def _backend_name(dist) -> str:
     """What carries the collectives: RCCL (torch's "nccl" backend on ROCm) or, in the one-device rehearsal, gloo; "no" for a single rank."""
     if not dist:
@@ -209,7 +213,7 @@ def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
     out = {"metric": tw.metric, "value": round(tw.units_per_step * steps * world / elapsed, 1), "unit": tw.unit, "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": dp_scaling(), "dtype": tw.dtype, "data": "synthetic",
            "config": {"workload": tw.name, "units_per_step_per_gpu": tw.units_per_step, "dp_batch": dp_batch_mode(), "per_rank_batch": tw.B, "global_batch": tw.B * world,
-                      "parallelism": f"dp{world} ({_backend_name(dist)} all-reduce of one flat fp32 gradient bucket)"}}
+                      "parallelism": _dp_label(dist, world)}}
     if dist:
         out.update(allreduce_probe(dist, tw))
     if rank == 0:  # both halves of BASELINE's metric carry a roofline: the step against the f32 MFMA peak, its dominant kernel against HBM
@@ -258,7 +262,7 @@ def measure_sweep(device, rank, world, dist, steps=5, warmup=2):
         elapsed = float(t.item())
     out = {"metric": hw.metric, "value": round(hw.units_per_step * steps * world / elapsed, 1), "unit": hw.unit, "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": dp_scaling(), "dtype": hw.dtype, "data": "synthetic",
-           "config": {"workload": hw.name, "units_per_step_per_gpu": hw.units_per_step, "dp_batch": dp_batch_mode(), "per_rank_batch": hw.B, "global_batch": hw.B * world, "parallelism": f"dp{world} ({_backend_name(dist)} all-reduce of one flat fp32 gradient bucket per variant)"}}
+           "config": {"workload": hw.name, "units_per_step_per_gpu": hw.units_per_step, "dp_batch": dp_batch_mode(), "per_rank_batch": hw.B, "global_batch": hw.B * world, "parallelism": _dp_label(dist, world, "one flat fp32 gradient bucket per variant")}}
     if rank == 0:
         out["roofline"] = hw.roofline()
     return out
@@ -394,7 +398,7 @@ def main():
         if args.workload in ("train", "hpsearch"):
             line["scaling"] = dp_scaling()
             line["config"].update({"dp_batch": dp_batch_mode(), "per_rank_batch": wl.B, "global_batch": wl.B * world})
-            line["config"]["parallelism"] = f"dp{world} ({_backend_name(dist)} all-reduce of one flat fp32 gradient bucket)"
+            line["config"]["parallelism"] = _dp_label(dist, world)
             line.update(ar_probe)
         if args.workload == "hpsearch" and world == 1 and not args.no_loss_curves:
             line["loss_curves_f16_vs_f32"] = wl.loss_curves(args.curve_steps)

@@ -76,3 +76,25 @@ def test_bench_kernel_symbols_are_in_the_newest_pmc_traffic_table():
     import bench
 
     assert bench.FrontendWorkload.kernel_symbol in fe, (bench.FrontendWorkload.kernel_symbol, sorted(fe))
+
+
+def test_training_bench_symbols_are_in_the_newest_pmc_traffic_table():
+    """The same for the two training workloads: every kernel symbol the newest committed bench lines rank (bench_predict's call -> symbol maps, written
+    into `symbol_ms_per_*_instrumented`; launcher names stand for calls with more than one kernel and are skipped) is a key of the table's section the
+    line's `traffic` is read from, and the top symbol's traffic is what the table holds."""
+    import json
+    from pathlib import Path
+
+    import bench_predict as bp
+
+    f = bp.traffic_file()
+    table = json.loads(f.read_text())
+    prof = Path(f).parent
+    rnd = f.name.split("_")[0]
+    for workload, key, section in (("train", "symbol_ms_per_step_instrumented", "train"), ("hpsearch", "symbol_ms_per_sweep_step_instrumented", "hpsearch_f16_set3")):
+        line = json.loads((prof / f"{rnd}_bench_{workload}.json").read_text())
+        roof, kernels = line["roofline"], table[section]["kernels"]
+        ranked = [s for s in roof[key] if not s.startswith("orcai_")]
+        assert len(ranked) >= 6 and all(s in kernels for s in ranked), (workload, [s for s in ranked if s not in kernels])
+        assert roof["kernel"] == ranked[0]
+        assert bp.measured_traffic_symbol(roof["kernel"], section) == kernels[roof["kernel"]]["hbm_bytes_per_launch"]
