@@ -227,7 +227,10 @@ int orcai_gemm_strided(const float* A, int64_t sam, int64_t sak, const float* B,
 int orcai_colsum(const float* x, int M, int C, float* out, int accumulate, void* stream);
 
 /* BatchNormalization in training mode on a row tensor whose channel is (column % C): batch mean / biased variance,
- * y = [relu]((x - mean) * gamma * rsqrt(var + eps) + beta), and its backward (dbeta, dgamma, dx) with the optional ReLU folded in. */
+ * y = [relu]((x - mean) * gamma * rsqrt(var + eps) + beta), and its backward (dbeta, dgamma, dx) with the optional ReLU folded in.
+ * Up to 2 048 columns / 512 channels the two reductions (orcai_bn_rows_stats, orcai_bn_rows_bwd) read row slabs with coalesced loads and fold the slabs'
+ * partial sums in a fixed order through one device array inside the library: bit-reproducible, but at most ONE of these two launchers may be in flight per
+ * device (calls on one stream are ordered and fine) -- the restriction orcai_lstm_bwd has. */
 int orcai_bn_rows_stats(const float* x, int M, int cols, int C, float* mean, float* var, void* stream);
 int orcai_bn_rows_apply(const float* x, int M, int cols, int C, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                         int relu, float* y, void* stream);

@@ -2135,6 +2135,39 @@ __global__ __launch_bounds__(256) void dense_sigmoid_kernel(const float* __restr
     if (n < N) out[m * N + n] = 1.0f / (1.0f + expf(-(acc[n] + bias[n])));
 }
 
+// The same with eight lanes per row (K a multiple of 4): lane j of a row reads the row's float4 number j, j + 8, ... -- a row's 128-byte segments,
+// coalesced -- and its 4 N weights for them; the eight partial sums meet by three lane exchanges.  (One thread per row reads 4 bytes a row apart and
+// walks K dependent steps: 59 us for the 2 944 x 128 input of a training step, 12 workgroups.)
+__global__ __launch_bounds__(256) void dense_sigmoid_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  int64_t M, int K, int N, float* __restrict__ out) {
+  const int j = threadIdx.x & 7;
+  const int64_t m = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool live = m < M;
+  float acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = 0.0f;
+  const float4* xr = reinterpret_cast<const float4*>(x + (live ? m : 0) * K);
+  for (int q = j; q < (K >> 2); q += 8) {
+    const float4 v = xr[q];
+    const float* wq = w + (int64_t)q * 4 * N;
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+      if (n < N) acc[n] = fmaf(v.w, wq[3 * N + n], fmaf(v.z, wq[2 * N + n], fmaf(v.y, wq[N + n], fmaf(v.x, wq[n], acc[n]))));
+  }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    acc[n] += __shfl_xor(acc[n], 1);
+    acc[n] += __shfl_xor(acc[n], 2);
+    acc[n] += __shfl_xor(acc[n], 4);
+  }
+  if (live && j < N) {
+    float a = acc[0];
+#pragma unroll
+    for (int n = 1; n < 8; ++n) a = j == n ? acc[n] : a;
+    out[m * N + j] = 1.0f / (1.0f + expf(-(a + bias[j])));
+  }
+}
+
 // =========================================================================================
 // overlap_average: predict.py:276-293.  Output step s is covered by snippets i with step*i <= s < step*i + P.
 // float64 accumulate in snippet order, then divide by the count (bit-exact with the numpy loop).
@@ -2694,7 +2727,10 @@ int orcai_lstm_recurrent(const float* xz, const float* Uw, int B, int T, int uni
 int orcai_dense_sigmoid(const float* x, const float* w, const float* bias, int64_t M, int K, int N, float* out, void* stream) {
   if (!x || !w || !bias || !out || M <= 0 || K <= 0 || N <= 0) return ORCAI_E_BADARG;
   if (N > 8) return ORCAI_E_UNSUPPORTED;
-  hipLaunchKernelGGL(dense_sigmoid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, M, K, N, out);
+  if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(dense_sigmoid_rows_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, w, bias, M, K, N, out);
+  else
+    hipLaunchKernelGGL(dense_sigmoid_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias, M, K, N, out);
   return (int)hipGetLastError();
 }
 

@@ -210,18 +210,32 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const float* __restrict
 }
 
 // column sums of a row tensor: out[c] (=|+=) sum_m x[m][c]      (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out, int accumulate) {
-  __shared__ float part[256];
-  const int c = blockIdx.x;
+// One workgroup per 16 columns: 64 row groups x 16 consecutive columns (a wave reads four 64-byte row segments per step), eight loads in flight per
+// thread.  (The first version -- one workgroup per column, 4-byte reads a row apart, one load in flight -- took 24 us for the 12 MB of an LSTM bias gradient.)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ out, int accumulate) {
+  __shared__ float part[64][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   float s = 0.0f;
-  for (int m = threadIdx.x; m < M; m += 256) s += x[(int64_t)m * C + c];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-    __syncthreads();
+  if (c < C) {
+    const float* xc = x + c;
+    int m = rg;
+    for (; m + 7 * 64 < M; m += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = xc[(int64_t)(m + 64 * k) * C];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; m < M; m += 64) s += xc[(int64_t)m * C];
   }
-  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + part[0] : part[0];
+  part[rg][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) t += part[r][threadIdx.x];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // =========================================================================================
@@ -229,24 +243,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // column % C: Dense-128 output (C = 128 = columns) and the final separable conv in Keras Reshape layout (C = 36).
 // stats[c] = {mean, biased var}; one workgroup per channel, float64 accumulation.
 // =========================================================================================
-__global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int cols, int C, float* __restrict__ mean,
-                                                             float* __restrict__ var) {
-  __shared__ double s1[256], s2[256];
+// (1 024 threads over the flattened (row, position) index, the row recovered by a multiply-high with the launcher's reciprocal of per_row, eight loads in
+// flight per thread: the first version divided a 64-bit element index per load, one load in flight, and took 59 us for the 4.6 MB of the final conv's output)
+__device__ __forceinline__ int64_t rows_index(uint32_t i, int per_row, uint32_t magic, int cols, int C) {
+  const uint32_t m = per_row == 1 ? i : __umulhi(i, magic);
+  const uint32_t p = i - m * (uint32_t)per_row;
+  return (int64_t)m * cols + (int64_t)p * C;
+}
+
+__global__ __launch_bounds__(1024) void bn_rows_stats_kernel(const float* __restrict__ x, int M, int cols, int C, uint32_t magic, float* __restrict__ mean,
+                                                              float* __restrict__ var) {
+  __shared__ double s1[1024], s2[1024];
   const int c = blockIdx.x;
   const int per_row = cols / C;
   double a = 0.0, b = 0.0;
-  const int64_t total = (int64_t)M * per_row;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t m = i / per_row;
-    const int p = (int)(i - m * per_row);
-    const double v = (double)x[m * cols + (int64_t)p * C + c];
+  const uint32_t total = (uint32_t)M * (uint32_t)per_row;
+  const float* xc = x + c;
+  uint32_t i = threadIdx.x;
+  for (; i + 7 * 1024 < total; i += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = xc[rows_index(i + 1024 * k, per_row, magic, cols, C)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a += (double)v[k];
+      b += (double)v[k] * (double)v[k];
+    }
+  }
+  for (; i < total; i += 1024) {
+    const double v = (double)xc[rows_index(i, per_row, magic, cols, C)];
     a += v;
     b += v * v;
   }
   s1[threadIdx.x] = a;
   s2[threadIdx.x] = b;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
     __syncthreads();
   }
@@ -259,44 +291,60 @@ __global__ __launch_bounds__(256) void bn_rows_stats_kernel(const float* __restr
 }
 
 // y = [relu]( (x - mean) * gamma * rsqrt(var + eps) + beta )
-__global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, int64_t n, int C, const float* __restrict__ mean,
+// (grid: column blocks x rows -- the channel is a 32-bit column % C)
+__global__ __launch_bounds__(256) void bn_rows_apply_kernel(const float* __restrict__ x, int M, int cols, int C, const float* __restrict__ mean,
                                                              const float* __restrict__ var, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = (int)(i % C);
-  const float inv = gamma[c] * rsqrtf(var[c] + eps);
-  float v = fmaf(x[i], inv, beta[c] - mean[c] * inv);
-  if (relu) v = fmaxf(v, 0.0f);
-  y[i] = v;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int c = col % C;
+  const float inv = gamma[c] * rsqrtf(var[c] + eps), sh = beta[c] - mean[c] * inv;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) {
+    const int64_t i = (int64_t)m * cols + col;
+    float v = fmaf(x[i], inv, sh);
+    if (relu) v = fmaxf(v, 0.0f);
+    y[i] = v;
+  }
 }
 
 // BN backward, reduction part: with dy_eff = relu ? dy * (y > 0) : dy  (y = BN output),
 //   sums[c] = {sum dy_eff, sum dy_eff * xhat};  also dgamma = sums[1], dbeta = sums[0].
-__global__ __launch_bounds__(256) void bn_rows_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int cols, int C,
-                                                                 const float* __restrict__ mean, const float* __restrict__ var,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
-                                                                 float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  __shared__ double s1[256], s2[256];
+__global__ __launch_bounds__(1024) void bn_rows_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int cols, int C, uint32_t magic,
+                                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
+                                                                  float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  __shared__ double s1[1024], s2[1024];
   const int c = blockIdx.x;
   const int per_row = cols / C;
   const float inv = rsqrtf(var[c] + eps), mu = mean[c], g = gamma[c], bt = beta[c];
   double a = 0.0, b = 0.0;
-  const int64_t total = (int64_t)M * per_row;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t m = i / per_row;
-    const int p = (int)(i - m * per_row);
-    const int64_t idx = m * cols + (int64_t)p * C + c;
-    const float xh = (x[idx] - mu) * inv;
-    float d = dy[idx];
+  const uint32_t total = (uint32_t)M * (uint32_t)per_row;
+  auto take = [&](float xv, float d) {
+    const float xh = (xv - mu) * inv;
     if (relu && !(fmaf(xh, g, bt) > 0.0f)) d = 0.0f;
     a += (double)d;
     b += (double)d * (double)xh;
+  };
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * 1024 < total; i += 4 * 1024) {
+    float xv[4], dv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t idx = rows_index(i + 1024 * k, per_row, magic, cols, C) + c;
+      xv[k] = x[idx];
+      dv[k] = dy[idx];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) take(xv[k], dv[k]);
+  }
+  for (; i < total; i += 1024) {
+    const int64_t idx = rows_index(i, per_row, magic, cols, C) + c;
+    take(x[idx], dy[idx]);
   }
   s1[threadIdx.x] = a;
   s2[threadIdx.x] = b;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
     __syncthreads();
   }
@@ -304,19 +352,118 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_stats_kernel(const float* __r
 }
 
 // dx = gamma * inv * (dy_eff - dbeta/N - xhat * dgamma/N)
-__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t n, int C, float count,
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int cols, int C, float count,
                                                                  const float* __restrict__ mean, const float* __restrict__ var,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu,
                                                                  const float* __restrict__ dbeta, const float* __restrict__ dgamma,
                                                                  float* __restrict__ dx) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = (int)(i % C);
-  const float inv = rsqrtf(var[c] + eps);
-  const float xh = (x[i] - mean[c]) * inv;
-  float d = dy[i];
-  if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) d = 0.0f;
-  dx[i] = gamma[c] * inv * (d - dbeta[c] / count - xh * dgamma[c] / count);
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const int c = col % C;
+  const float inv = rsqrtf(var[c] + eps), mu = mean[c], g = gamma[c], bt = beta[c], db = dbeta[c] / count, dg = dgamma[c] / count;
+  for (int m = blockIdx.y; m < M; m += gridDim.y) {
+    const int64_t i = (int64_t)m * cols + col;
+    const float xh = (x[i] - mu) * inv;
+    float d = dy[i];
+    if (relu && !(fmaf(xh, g, bt) > 0.0f)) d = 0.0f;
+    dx[i] = g * inv * (d - db - xh * dg);
+  }
+}
+
+// ---------------------------------------------------------------- the same reductions with COALESCED reads (the kernels the launchers use up to 2 048 columns)
+// One workgroup per channel reads 4 bytes out of every 4 C-byte group of the tensor: 64 cache lines per wave load, 39 us for 4.6 MB.  Here a workgroup owns a
+// slab of rows and a thread a column (consecutive lanes read consecutive floats); the columns of a channel meet in LDS, the slabs in a library-internal
+// device array (ROWS_SLABS x 2 x ROWS_MAXC doubles) that a second launch folds in slab order -- no atomics, the same bits every run.  That array makes the
+// row-BatchNorm launchers one-stream-at-a-time per device, like orcai_lstm_bwd (include/orcai_hip.h).
+constexpr int ROWS_SLABS = 64, ROWS_MAXC = 512, ROWS_MAXCOLS = 2048;
+__device__ double g_rows_partials[ROWS_SLABS * 2 * ROWS_MAXC];
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void bn_rows_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M, int cols, int C, int rows_per_slab,
+                                                               const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int relu, double* __restrict__ part) {
+  __shared__ double ca[ROWS_MAXCOLS], cb[ROWS_MAXCOLS];
+  const int m0 = blockIdx.x * rows_per_slab, m1 = (m0 + rows_per_slab < M) ? m0 + rows_per_slab : M;
+  for (int col = threadIdx.x; col < cols; col += 512) {
+    const int c = col % C;
+    float inv = 0.f, mu = 0.f, g = 0.f, bt = 0.f;
+    if (BWD) {
+      inv = rsqrtf(var[c] + eps);
+      mu = mean[c];
+      g = gamma[c];
+      bt = beta[c];
+    }
+    double a = 0.0, b = 0.0;
+    auto take = [&](float xv, float d) {
+      if (BWD) {
+        const float xh = (xv - mu) * inv;
+        if (relu && !(fmaf(xh, g, bt) > 0.0f)) d = 0.0f;
+        a += (double)d;
+        b += (double)d * (double)xh;
+      } else {
+        a += (double)xv;
+        b += (double)xv * (double)xv;
+      }
+    };
+    int m = m0;
+    for (; m + 7 < m1; m += 8) {
+      float xv[8], dv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        xv[k] = x[(int64_t)(m + k) * cols + col];
+        dv[k] = BWD ? dy[(int64_t)(m + k) * cols + col] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) take(xv[k], dv[k]);
+    }
+    for (; m < m1; ++m) take(x[(int64_t)m * cols + col], BWD ? dy[(int64_t)m * cols + col] : 0.0f);
+    ca[col] = a;
+    cb[col] = b;
+  }
+  __syncthreads();
+  const int per_row = cols / C;
+  for (int c = threadIdx.x; c < C; c += 512) {
+    double a = 0.0, b = 0.0;
+    for (int p = 0; p < per_row; ++p) {
+      a += ca[p * C + c];
+      b += cb[p * C + c];
+    }
+    part[(blockIdx.x * 2 + 0) * ROWS_MAXC + c] = a;
+    part[(blockIdx.x * 2 + 1) * ROWS_MAXC + c] = b;
+  }
+}
+
+// the slabs' partials folded in slab order, 16 loads in flight per thread (one load at a time is 64 dependent L2 round trips: 30 us); thread = channel.
+// bwd == 0: mean / biased variance;  bwd != 0: out0 = d beta, out1 = d gamma
+__global__ __launch_bounds__(512) void bn_rows_finish_kernel(const double* __restrict__ part, int C, int slabs, double total, int bwd, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int s0 = 0; s0 < slabs; s0 += 16) {
+    double va[16], vb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int sl = s0 + k < slabs ? s0 + k : slabs - 1;
+      va[k] = part[(sl * 2 + 0) * ROWS_MAXC + c];
+      vb[k] = part[(sl * 2 + 1) * ROWS_MAXC + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (s0 + k < slabs) {
+        a += va[k];
+        b += vb[k];
+      }
+  }
+  if (bwd) {
+    out0[c] = (float)a;
+    out1[c] = (float)b;
+    return;
+  }
+  const double mu = a / total;
+  out0[c] = (float)mu;
+  const double vv = b / total - mu * mu;
+  out1[c] = (float)(vv < 0.0 ? 0.0 : vv);
 }
 
 // y = x * mask * scale (Dropout forward and backward; mask holds 0/1)
@@ -1157,6 +1304,9 @@ __global__ __launch_bounds__(256) void conv1d_dgrad_kernel(const float* __restri
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+// floor(i / d) == __umulhi(i, rows_magic(d)) while i * d < 2^32 (magic = ceil(2^32 / d): the excess i * (magic d - 2^32) / (d 2^32) stays below 1 / d); the launchers check it
+double* rows_partials();
+inline uint32_t rows_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 // ---------------------------------------------------------------- LSTM weights: Keras layout <-> the recurrence kernels' gate-column order
 // Kernel column p = 32 w + 16 nt + j holds Keras column (2 nt + (j >> 3)) u + 8 w + (j & 7)   (architectures.lstm_column_permutation):
@@ -1239,6 +1389,16 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ moving, co
   if (i < n) moving[i] = moving[i] * momentum + batch[i] * (1.0f - momentum);
 }
 
+// address of the row-BatchNorm slab partials on the current device (looked up once per device; no allocation)
+double* rows_partials() {
+  constexpr int MAXDEV = 64;
+  static double* addr[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  if (!addr[dev] && hipGetSymbolAddress((void**)&addr[dev], HIP_SYMBOL(g_rows_partials)) != hipSuccess) return nullptr;
+  return addr[dev];
+}
+
 }  // namespace
 
 extern "C" {
@@ -1295,13 +1455,23 @@ int orcai_conv1d_bwd(const float* x, const float* w, const float* dz, int B, int
 
 int orcai_colsum(const float* x, int M, int C, float* out, int accumulate, void* stream) {
   if (!x || !out || M <= 0 || C <= 0) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, M, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 15) / 16), dim3(1024), 0, (hipStream_t)stream, x, M, C, out, accumulate);
   return (int)hipGetLastError();
 }
 
 int orcai_bn_rows_stats(const float* x, int M, int cols, int C, float* mean, float* var, void* stream) {
   if (!x || !mean || !var || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, M, cols, C, mean, var);
+  if (C <= ROWS_MAXC && cols <= ROWS_MAXCOLS && cols > C) {  // (one position per row -- Dense-128's BatchNorm -- is two launches of 8 us: the channel kernel's one is faster)  // coalesced row slabs + an ordered fold
+    double* part = rows_partials();
+    if (!part) return (int)hipErrorInvalidDevice;
+    const int rps = (M + ROWS_SLABS - 1) / ROWS_SLABS, slabs = (M + rps - 1) / rps;
+    hipLaunchKernelGGL(bn_rows_partial_kernel<false>, dim3(slabs), dim3(512), 0, (hipStream_t)stream, (const float*)nullptr, x, M, cols, C, rps, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, 0, part);
+    hipLaunchKernelGGL(bn_rows_finish_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, part, C, slabs, (double)M * (double)(cols / C), 0, mean, var);
+    return (int)hipGetLastError();
+  }
+  if ((int64_t)M * (cols / C) * (cols / C) >= (1ll << 32) || (int64_t)M * (cols / C) >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_rows_stats_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, M, cols, C, rows_magic(cols / C), mean, var);
   return (int)hipGetLastError();
 }
 
@@ -1309,7 +1479,7 @@ int orcai_bn_rows_apply(const float* x, int M, int cols, int C, const float* mea
                         int relu, float* y, void* stream) {
   if (!x || !y || !mean || !var || !gamma || !beta || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
   const int64_t n = (int64_t)M * cols;
-  hipLaunchKernelGGL(bn_rows_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, C, mean, var, gamma, beta, eps, relu, y);
+  hipLaunchKernelGGL(bn_rows_apply_kernel, dim3((cols + 255) / 256, M < 65535 ? M : 65535), dim3(256), 0, (hipStream_t)stream, x, M, cols, C, mean, var, gamma, beta, eps, relu, y);
   return (int)hipGetLastError();
 }
 
@@ -1317,10 +1487,20 @@ int orcai_bn_rows_bwd(const float* dy, const float* x, int M, int cols, int C, c
                       float eps, int relu, float* dbeta, float* dgamma, float* dx, void* stream) {
   if (!dy || !x || !dx || !dbeta || !dgamma || M <= 0 || C <= 0 || cols % C) return ORCAI_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_rows_bwd_stats_kernel, dim3(C), dim3(256), 0, st, dy, x, M, cols, C, mean, var, gamma, beta, eps, relu, dbeta, dgamma);
-  const int64_t n = (int64_t)M * cols;
+  if (C <= ROWS_MAXC && cols <= ROWS_MAXCOLS && cols > C) {  // (one position per row -- Dense-128's BatchNorm -- is two launches of 8 us: the channel kernel's one is faster)
+    double* part = rows_partials();
+    if (!part) return (int)hipErrorInvalidDevice;
+    const int rps = (M + ROWS_SLABS - 1) / ROWS_SLABS, slabs = (M + rps - 1) / rps;
+    hipLaunchKernelGGL(bn_rows_partial_kernel<true>, dim3(slabs), dim3(512), 0, st, dy, x, M, cols, C, rps, mean, var, gamma, beta, eps, relu, part);
+    hipLaunchKernelGGL(bn_rows_finish_kernel, dim3(1), dim3(512), 0, st, part, C, slabs, 0.0, 1, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((cols + 255) / 256, M < 65535 ? M : 65535), dim3(256), 0, st, dy, x, M, cols, C, (float)((int64_t)M * (cols / C)), mean, var,
+                       gamma, beta, eps, relu, dbeta, dgamma, dx);
+    return (int)hipGetLastError();
+  }
+  if ((int64_t)M * (cols / C) * (cols / C) >= (1ll << 32) || (int64_t)M * (cols / C) >= (1ll << 31)) return ORCAI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_rows_bwd_stats_kernel, dim3(C), dim3(1024), 0, st, dy, x, M, cols, C, rows_magic(cols / C), mean, var, gamma, beta, eps, relu, dbeta, dgamma);
   const float count = (float)((int64_t)M * (cols / C));
-  hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3(blocks_for(n)), dim3(256), 0, st, dy, x, n, C, count, mean, var, gamma, beta, eps, relu, dbeta, dgamma, dx);
+  hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((cols + 255) / 256, M < 65535 ? M : 65535), dim3(256), 0, st, dy, x, M, cols, C, count, mean, var, gamma, beta, eps, relu, dbeta, dgamma, dx);
   return (int)hipGetLastError();
 }
 

@@ -405,6 +405,7 @@ class TrunkTrainer:
         self.conv0_two_pass = True  # entry conv: statistics pass + conv/bn0/ReLU pass, v0 never stored, rebuilt in the backward pass (A/B: tools/ab_flags.py)
         self.apply_on_load = True  # bn_a + ReLU applied where sep_b / its depthwise weight gradient load their input: y_a is never written (A/B: tools/ab_flags.py)
         self.dgrad_epilogues = True  # BatchNorm backward sums / ReLU backward in the epilogue of the input-gradient passes (A/B: tools/ab_flags.py)
+        self.conv0_stats_from_input = True  # f16 path: bn0's statistics from the snippet (orcai_conv0_stats_march) instead of a pass over the stored v0 (A/B: tools/ab_sweep_flags.py)
         self.conv0_march = True  # entry conv statistics on the marching kernel (A/B: tools/ab_flags.py; its backward twin: orcai_conv0_march)
         self.conv0_in_dgrad = True  # block 1's first conv: y0 rebuilt from the snippet inside the marching depthwise backward, bn0's sums in its epilogue (A/B: tools/ab_flags.py)
         self.bn0_sums_ready = False
@@ -639,7 +640,19 @@ class TrunkTrainer:
         if self.v0_stored:
             N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
                                              0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
-            self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+            if self.half and self.conv0_stats_from_input and self.conv0_march and k == 3:
+                # bn0's batch statistics from the 1-channel snippet (the f32 path's marching statistics pass: 4 bytes per pixel read) instead of a pass over
+                # the stored 16-channel v0 (32 bytes per pixel).  They are the statistics of the conv BEFORE its rounding to f16: the mean moves by < 2^-12 of
+                # a standard deviation, the variance by 2^-24 relative -- below what the f16 storage of v0 itself does to the normalised values
+                mean0, var0 = P.B("bn0/mean"), P.B("bn0/var")
+                self._fresh()
+                N.check(lib.orcai_conv0_stats_march(src.data_ptr(), snippet_stride, B, H, W, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                                    self.scratch.data_ptr(), st), "conv0_stats_march")
+                N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), B, 16, H, W, mean0.data_ptr(), var0.data_ptr(), st), "bn_finish_sharded")
+                self.stats["bn0"] = (mean0, var0)
+                self._bn_apply(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+            else:
+                self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
         else:
             # two passes over the 1-channel input instead of three over the 16-channel v0: statistics only, then conv + bn0 + ReLU -> y0; v0 itself
             # is never written (the backward pass rebuilds it from the input taps: orcai_conv0_bn_bwd_x)

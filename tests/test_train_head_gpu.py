@@ -127,3 +127,65 @@ def test_dropout_mask_statistics():
     assert torch.equal(mask, mask2)  # counter based: reproducible
     N.check(N.lib().orcai_dropout_mask(mask2.data_ptr(), n, 1235, 0.7, N.stream_ptr()), "dropout_mask")
     assert abs(mask2.mean().item() - 0.7) < 5e-3 and not torch.equal(mask, mask2)
+
+
+@pytest.mark.parametrize("M_,cols,C", [(2944, 396, 36), (77, 128, 128), (600, 1100, 50), (33, 36, 36), (40, 2304, 36)])
+def test_row_batchnorm_and_column_sum_kernels_vs_float64(M_, cols, C):
+    """The row-tensor kernels of the head on their own (round 4: re-parallelised -- rows over threads without index division, 2-D apply grids, 32-column
+    workgroups for the column sums, row slabs with an ordered fold up to 2 048 columns and the one-workgroup-per-channel kernels beyond): statistics, apply, backward sums + apply and column sums against float64 numpy on shapes with ragged column blocks."""
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    rng = np.random.default_rng(M_ + cols)
+    x = (rng.standard_normal((M_, cols)) * 1.5 + 0.3).astype(np.float32)
+    dy = rng.standard_normal((M_, cols)).astype(np.float32)
+    gamma, beta = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32), (0.2 * rng.standard_normal(C)).astype(np.float32)
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    xd, dyd, gd, bd = dev(x), dev(dy), dev(gamma), dev(beta)
+    mean, var = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    N.check(lib.orcai_bn_rows_stats(N.ptr(xd), M_, cols, C, N.ptr(mean), N.ptr(var), st), "bn_rows_stats")
+    xr = x.astype(np.float64).reshape(M_, cols // C, C)
+    mu, vv = xr.mean(axis=(0, 1)), xr.var(axis=(0, 1))
+    torch.cuda.synchronize()
+    assert np.abs(mean.cpu().numpy() - mu).max() <= 2e-6 and np.abs(var.cpu().numpy() - vv).max() <= 5e-6
+    eps = 1e-3
+    for relu in (0, 1):
+        y = torch.empty_like(xd)
+        N.check(lib.orcai_bn_rows_apply(N.ptr(xd), M_, cols, C, N.ptr(mean), N.ptr(var), N.ptr(gd), N.ptr(bd), eps, relu, N.ptr(y), st), "bn_rows_apply")
+        m32, v32 = mean.cpu().numpy().astype(np.float64), var.cpu().numpy().astype(np.float64)
+        inv = 1.0 / np.sqrt(v32 + eps)
+        xh = (xr - m32) * inv
+        yr = xh * gamma + beta
+        want = np.maximum(yr, 0) if relu else yr
+        assert np.abs(y.cpu().numpy().reshape(xr.shape) - want).max() <= 5e-6 * max(1.0, np.abs(want).max())
+        dbeta, dgamma, dx = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(xd)
+        N.check(lib.orcai_bn_rows_bwd(N.ptr(dyd), N.ptr(xd), M_, cols, C, N.ptr(mean), N.ptr(var), N.ptr(gd), N.ptr(bd), eps, relu, N.ptr(dbeta), N.ptr(dgamma), N.ptr(dx), st), "bn_rows_bwd")
+        got_y = y.cpu().numpy().reshape(xr.shape)
+        de = dy.astype(np.float64).reshape(xr.shape) * ((got_y > 0) if relu else 1.0)  # the mask the kernel's own forward value gives
+        cnt = M_ * (cols // C)
+        db, dg = de.sum(axis=(0, 1)), (de * xh).sum(axis=(0, 1))
+        dxr = gamma * inv * (de - db / cnt - xh * dg / cnt)
+        torch.cuda.synchronize()
+        assert np.abs(dbeta.cpu().numpy() - db).max() <= 2e-5 * max(1.0, np.abs(db).max()) and np.abs(dgamma.cpu().numpy() - dg).max() <= 2e-5 * max(1.0, np.abs(dg).max())
+        assert np.abs(dx.cpu().numpy().reshape(xr.shape) - dxr).max() <= 2e-5 * max(1.0, np.abs(dxr).max())
+    out = torch.full((cols,), 2.0, device="cuda")
+    N.check(lib.orcai_colsum(N.ptr(dyd), M_, cols, N.ptr(out), 0, st), "colsum")
+    N.check(lib.orcai_colsum(N.ptr(dyd), M_, cols, N.ptr(out), 1, st), "colsum")
+    want = 2 * dy.astype(np.float64).sum(axis=0)
+    assert np.abs(out.cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("M_,K,N_", [(2944, 128, 7), (33, 128, 3), (100, 6, 8), (7, 36, 1)])
+def test_dense_sigmoid_rows_vs_float64(M_, K, N_):
+    """orcai_dense_sigmoid: the eight-lanes-per-row kernel (K a multiple of 4) and the one-thread-per-row kernel it falls back to, against float64."""
+    from orcai_amd import _native as N
+
+    lib, st = N.lib(), N.stream_ptr()
+    rng = np.random.default_rng(K + N_)
+    x, w, b = rng.standard_normal((M_, K)).astype(np.float32), (rng.standard_normal((K, N_)) / np.sqrt(K)).astype(np.float32), rng.standard_normal(N_).astype(np.float32)
+    xd, wd, bd = (torch.from_numpy(a).cuda() for a in (x, w, b))
+    out = torch.full((M_ + 1, N_), -1.0, device="cuda")
+    N.check(lib.orcai_dense_sigmoid(N.ptr(xd), N.ptr(wd), N.ptr(bd), M_, K, N_, N.ptr(out), st), "dense_sigmoid")
+    want = 1.0 / (1.0 + np.exp(-(x.astype(np.float64) @ w.astype(np.float64) + b)))
+    got = out.cpu().numpy()
+    assert np.abs(got[:M_] - want).max() <= 1e-6 and (got[M_] == -1.0).all()  # nothing written past the last row
