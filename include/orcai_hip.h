@@ -61,13 +61,14 @@ int orcai_resample_polyphase(const float* x, int64_t n_in, float* out, int64_t n
  * Also accumulates into the workspace: max |X|^2 over ALL 257 bins and all frames, and the
  * level-1 selection histogram of the values written.
  *   pcm        f32[n_samples], mono, already at the target sampling rate
- *   n_frames   must equal 1 + n_samples / hop
+ *   n_frames   must equal 1 + (n_samples - (n_fft & 1)) / hop  (librosa's centred frame count; 1 + n_samples / hop for even n_fft)
  *   k_crop     1..1 + n_fft/2 leading rFFT bins to keep (171 for orcai-V1: first bin with f >= 16 kHz)
  *   out_db     f32[n_frames * k_crop], layout [frame][bin]  (the transposed layout
  *              preprocess_spectrogram returns, spectrogram.py:86)
  * n_fft = 512 (every shipped parameter file) runs the tuned kernel; any other power of two from 32 to 4096 a plain
- * one-workgroup-per-frame radix-2 kernel followed by a separate level-1 histogram pass (same outputs); anything else is
- * ORCAI_E_UNSUPPORTED.  With n_fft != 512 "ALL 257 bins" reads "all 1 + n_fft/2 bins". */
+ * one-workgroup-per-frame radix-2 kernel, every other size from 2 to 4096 (odd ones too) a direct float64 transform, O(n_fft^2)
+ * per frame -- both followed by a separate level-1 histogram pass (same outputs); n_fft > 4096 is ORCAI_E_UNSUPPORTED.
+ * With n_fft != 512 "ALL 257 bins" reads "all 1 + n_fft/2 bins". */
 int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop,
                   float* out_db, void* workspace, void* stream);
 

@@ -23,9 +23,10 @@ def hann_window(n_fft: int) -> np.ndarray:
     return scipy.signal.get_window("hann", n_fft, fftbins=True)
 
 
-def num_frames(n_samples: int, hop: int) -> int:
-    """Centred STFT frame count: ``1 + N // hop`` (librosa ``center=True``)."""
-    return 1 + n_samples // hop
+def num_frames(n_samples: int, hop: int, n_fft: int = 512) -> int:
+    """Centred STFT frame count (librosa ``center=True`` pads ``n_fft // 2`` on both sides): ``1 + (N + 2 (n_fft // 2) - n_fft) // hop``,
+    i.e. ``1 + N // hop`` for even transform sizes."""
+    return 1 + (n_samples - (n_fft & 1)) // hop
 
 
 def stft_ref(y: np.ndarray, n_fft: int = 512, hop: int = 256, block: int = 8192) -> np.ndarray:
@@ -39,7 +40,7 @@ def stft_ref(y: np.ndarray, n_fft: int = 512, hop: int = 256, block: int = 8192)
     y = np.asarray(y, dtype=np.float32)
     pad = n_fft // 2
     yp = np.pad(y, (pad, pad), mode="constant")
-    T = num_frames(len(y), hop)
+    T = num_frames(len(y), hop, n_fft)
     win = hann_window(n_fft)
     out = np.empty((1 + n_fft // 2, T), dtype=np.complex64)
     frames = np.lib.stride_tricks.sliding_window_view(yp, n_fft)[::hop]

@@ -440,6 +440,58 @@ __global__ __launch_bounds__(256) void stft_any_kernel(const float* __restrict__
   if (tid == 0) atomicMax(&ws->pmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
+// ---------------------------------------------------------------- STFT + dB for ANY transform size 2 .. 4096 (odd, 500, 1000 ...: the reference passes
+// whatever the parameter file says to librosa.stft, spectrogram.py:34-39; no shipped file uses one).  A direct DFT, O(nfft^2) per frame: one workgroup per
+// frame, the windowed frame and the nfft twiddles exp(-2 pi i j / nfft) as float64 in dynamic LDS (96 KB at 4096), thread = bin, the twiddle index stepped
+// by k modulo nfft, float64 accumulation (numpy's rfft, which librosa calls, is float64 too).  Completeness, not speed: ~1 s per hour of audio at nfft 1000.
+__global__ __launch_bounds__(256) void stft_dft_kernel(const float* __restrict__ pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop,
+                                                        float* __restrict__ out_db, Workspace* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) double dft_lds[];  // [n_fft] frame, then [n_fft][2] twiddles
+  __shared__ float wmax[4];
+  double* xw = dft_lds;
+  double2* tw = reinterpret_cast<double2*>(dft_lds + n_fft + (n_fft & 1));
+  const int tid = threadIdx.x;
+  const int half = n_fft >> 1;
+  for (int j = tid; j < n_fft; j += 256) {
+    double sn, cs;
+    sincospi(2.0 * (double)j / (double)n_fft, &sn, &cs);
+    tw[j] = make_double2(cs, -sn);
+  }
+  __syncthreads();
+  float pmax = 0.0f;
+  for (int64_t t = blockIdx.x; t < n_frames; t += gridDim.x) {
+    const int64_t s0 = t * hop - half;
+    for (int n = tid; n < n_fft; n += 256) {
+      const int64_t i = s0 + n;
+      const double x = (i >= 0 && i < n_samples) ? (double)pcm[i] : 0.0;
+      xw[n] = x * (0.5 - 0.5 * tw[n].x);  // periodic Hann
+    }
+    __syncthreads();
+    for (int k = tid; k <= half; k += 256) {
+      double re = 0.0, im = 0.0;
+      int idx = 0;
+      for (int n = 0; n < n_fft; ++n) {
+        const double2 w = tw[idx];
+        const double x = xw[n];
+        re = fma(x, w.x, re);
+        im = fma(x, w.y, im);
+        idx += k;
+        idx -= idx >= n_fft ? n_fft : 0;
+      }
+      const float fr = (float)re, fi = (float)im;  // complex64, as librosa stores the transform
+      const float p = fmaf(fr, fr, fi * fi);
+      pmax = fmaxf(pmax, p);
+      if (k < k_crop) out_db[t * (int64_t)k_crop + k] = power_to_db(p);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64));
+  if ((tid & 63) == 0) wmax[tid >> 6] = pmax;
+  __syncthreads();
+  if (tid == 0) atomicMax(&ws->pmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 // ---------------------------------------------------------------- generic level-1 histogram
 __global__ __launch_bounds__(256) void hist1_kernel(const float* __restrict__ x, int64_t n, Workspace* __restrict__ ws) {
   __shared__ uint32_t h[NB1_PAD];
@@ -727,10 +779,30 @@ int orcai_frontend_reset(void* workspace, void* stream) {
 int orcai_stft_db(const float* pcm, int64_t n_samples, int n_fft, int hop, int64_t n_frames, int k_crop, float* out_db, void* workspace,
                   void* stream) {
   if (!pcm || !out_db || !workspace || n_samples <= 0 || hop <= 0 || k_crop < 1 || n_fft < 2 || k_crop > 1 + n_fft / 2) return ORCAI_E_BADARG;
-  if (n_frames != 1 + n_samples / hop) return ORCAI_E_BADARG;
+  if (n_frames != 1 + (n_samples - (n_fft & 1)) / hop) return ORCAI_E_BADARG;  // librosa, center = True: 1 + (n + 2 (n_fft / 2) - n_fft) / hop
   if (((uintptr_t)out_db & 15) || ((uintptr_t)pcm & 15)) return ORCAI_E_BADARG;
-  if (n_fft != NFFT) {  // any other power of two from 32 to 4096: the plain kernel + a separate level-1 histogram pass
-    if (n_fft < 32 || n_fft > NFFT_ANY_MAX || (n_fft & (n_fft - 1))) return ORCAI_E_UNSUPPORTED;
+  if (n_fft != NFFT) {  // any other size up to 4096: the plain radix-2 kernel (powers of two from 32) or the direct transform, + a separate level-1 histogram pass
+    if (n_fft > NFFT_ANY_MAX) return ORCAI_E_UNSUPPORTED;
+    if (n_fft < 32 || (n_fft & (n_fft - 1))) {  // not a power of two (or a tiny one): the direct transform
+      const size_t lds = sizeof(double) * ((size_t)n_fft + (n_fft & 1) + 2 * (size_t)n_fft);
+      if (lds > 48 * 1024) {
+        static bool opted_dev[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 0 || dev >= 64) return ORCAI_E_UNSUPPORTED;
+        if (!opted_dev[dev]) {
+          e = hipFuncSetAttribute((const void*)stft_dft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NFFT_ANY_MAX * (int)sizeof(double));
+          if (e != hipSuccess) return (int)e;
+          opted_dev[dev] = true;
+        }
+      }
+      const int64_t blocks = n_frames < 256 * 4 ? n_frames : 256 * 4;
+      hipLaunchKernelGGL(stft_dft_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, pcm, n_samples, n_fft, hop, n_frames, k_crop, out_db, (Workspace*)workspace);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      return orcai_hist_level1(out_db, n_frames * (int64_t)k_crop, workspace, stream);
+    }
     int log2n = 0;
     while ((1 << log2n) < n_fft) ++log2n;
     const int64_t blocks = n_frames < 256 * 16 ? n_frames : 256 * 16;

@@ -53,12 +53,13 @@ class FrontEnd:
     @staticmethod
     def _check_nfft(n_fft: int) -> None:
         """The reference reads nfft from the parameter file (spectrogram.py:34-39).  512 -- orcai-V1 and default_orcai_parameter.json -- runs the
-        tuned STFT kernel, any other power of two from 32 to 4096 a plain radix-2 kernel; say what is not covered instead of a bare error code."""
+        tuned STFT kernel, any other power of two from 32 to 4096 a plain radix-2 kernel, every other size from 2 to 4096 a direct transform (slow,
+        exact); say what is not covered instead of a bare error code."""
         n = int(n_fft)
-        if n < 32 or n > 4096 or (n & (n - 1)):
-            raise NotImplementedError(f"spectrogram parameter nfft = {n_fft}: the MI355X front end implements powers of two from 32 to 4096 "
-                                      "(512, the value of orcai-V1 and of default_orcai_parameter.json, on the tuned kernel); other transform "
-                                      "sizes need the reference's CPU path")
+        if n < 2 or n > 4096:
+            raise NotImplementedError(f"spectrogram parameter nfft = {n_fft}: the MI355X front end implements transform sizes from 2 to 4096 "
+                                      "(512, the value of orcai-V1 and of default_orcai_parameter.json, on the tuned kernel); larger transforms "
+                                      "need the reference's CPU path")
 
     # -- the whole of make_spectrogram after decode (spectrogram.py:90-147) -----------------
     def make_spectrogram(self, pcm: torch.Tensor, spectrogram_parameter: dict) -> torch.Tensor:
@@ -73,7 +74,7 @@ class FrontEnd:
             raise NotImplementedError("HIP front end keeps leading bins only (reference crop start is always bin 0)")
         pcm = self._check_pcm(pcm)
         n = pcm.numel()
-        T = 1 + n // hop
+        T = 1 + (n - (n_fft & 1)) // hop  # librosa, center=True: 1 + (n + 2 (nfft // 2) - nfft) // hop
         K = f_hi
         out = torch.empty((T, K), dtype=torch.float32, device=self.device)
         total = T * K
@@ -91,7 +92,7 @@ class FrontEnd:
         self._check_nfft(n_fft)
         pcm = self._check_pcm(pcm)
         n = pcm.numel()
-        T = 1 + n // hop
+        T = 1 + (n - (n_fft & 1)) // hop  # librosa, center=True: 1 + (n + 2 (nfft // 2) - nfft) // hop
         K = 1 + n_fft // 2
         out = torch.empty((T, K), dtype=torch.float32, device=self.device)
         s = N.stream_ptr()
