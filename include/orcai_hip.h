@@ -543,6 +543,11 @@ int orcai_ema_update(float* moving, const float* batch, int n, float momentum, v
  * arguments as orcai_conv0_affine. */
 int orcai_h_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift, int relu,
                          void* out, void* stream);
+/* The same with the entry BatchNorm + ReLU in the same pass (training forward): v_out = the pre-normalisation conv (as orcai_h_conv0_affine with relu = 0),
+ * y_out = relu(BatchNorm(v_out)) formed from the f16 value just stored -- bit-identical to orcai_h_conv0_affine + orcai_h_bn_planes_apply(relu = 1) -- with the
+ * batch statistics the caller took from the snippet (orcai_conv0_stats_march + orcai_bn_finish_sharded; architectures.py:164-168). */
+int orcai_h_conv0_affine_bn(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                            const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* v_out, void* y_out, void* stream);
 
 /* [ReLU] -> depthwise ktap x ktap -> pointwise -> * scale + shift -> [ReLU] on f16 octet planes padded for ksize_planes
  * (architectures.py:174-189, 198-206): orcai_sepconv_planes_u of the f32 path.  out_layout 0: f16 octet planes; 1: f32

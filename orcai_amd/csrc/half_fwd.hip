@@ -19,10 +19,16 @@ using namespace orcai_half;
 
 // ---------------------------------------------------------------- entry conv: Conv2D(16, k x k, same) on the 1-channel f32 snippet
 // out f16 planes of 16 channels (2 octets), y = [relu](conv * scale + shift)   (architectures.py:164-168)
-template <int KS>
+// BN (training forward, orcai_h_conv0_affine_bn): the pre-normalisation tensor goes to `out` as before and y = relu(BatchNorm(out)) -- formed from the f16
+// value just stored, with bn_planes_apply_h_kernel's arithmetic, bit for bit -- to y_out in the same pass: the separate apply pass (read + write of the 16
+// channels) is gone.  The batch statistics come from the snippet (orcai_conv0_stats_march), so they exist before this launch.
+template <int KS, bool BN = false>
 __global__ __launch_bounds__(256) void conv0_h_kernel(const float* __restrict__ in, int64_t snippet_stride, int H, int W, int WP,
                                                        const float* __restrict__ w /*[KS*KS][16]*/, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, h16* __restrict__ out /*[B][2][HP][WP][8]*/, int relu) {
+                                                       const float* __restrict__ shift, h16* __restrict__ out /*[B][2][HP][WP][8]*/, int relu,
+                                                       const float* __restrict__ bn_mean = nullptr, const float* __restrict__ bn_var = nullptr,
+                                                       const float* __restrict__ bn_gamma = nullptr, const float* __restrict__ bn_beta = nullptr, float bn_eps = 0.0f,
+                                                       h16* __restrict__ y_out = nullptr) {
   constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
   __shared__ float halo[HH][HP_];
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
@@ -58,7 +64,19 @@ __global__ __launch_bounds__(256) void conv0_h_kernel(const float* __restrict__ 
         v[e] = fmaf(acc[8 * q + e], scale[8 * q + e], shift[8 * q + e]);
         if (relu) v[e] = fmaxf(v[e], 0.0f);
       }
-      o[(int64_t)q * plane] = pack8(v);
+      const h16x8 stored = pack8(v);
+      o[(int64_t)q * plane] = stored;
+      if (BN) {
+        float a[8], r[8];
+        unpack8(stored, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = 8 * q + e;
+          const float sc = bn_gamma[c] * rsqrtf(bn_var[c] + bn_eps);
+          r[e] = fmaxf(fmaf(a[e], sc, bn_beta[c] - bn_mean[c] * sc), 0.0f);
+        }
+        (reinterpret_cast<h16x8*>(y_out) + (int64_t)b * 2 * plane + (int64_t)(y + R) * WP + x)[(int64_t)q * plane] = pack8(r);
+      }
     }
   }
 }
@@ -743,9 +761,24 @@ int orcai_h_conv0_affine(const float* in, int64_t snippet_stride, int B, int H, 
   const int WP = orcai_padded_width(W, ksize);
   h16* o = (h16*)out;
   switch (ksize) {
-    case 3: hipLaunchKernelGGL(conv0_h_kernel<3>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu); break;
-    case 5: hipLaunchKernelGGL(conv0_h_kernel<5>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu); break;
-    case 7: hipLaunchKernelGGL(conv0_h_kernel<7>, grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu); break;
+    case 3: hipLaunchKernelGGL((conv0_h_kernel<3, false>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, (h16*)nullptr); break;
+    case 5: hipLaunchKernelGGL((conv0_h_kernel<5, false>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, (h16*)nullptr); break;
+    case 7: hipLaunchKernelGGL((conv0_h_kernel<7, false>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, o, relu, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, (h16*)nullptr); break;
+    default: return ORCAI_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int orcai_h_conv0_affine_bn(const float* in, int64_t snippet_stride, int B, int H, int W, int ksize, const float* w, const float* scale, const float* shift,
+                            const float* bn_mean, const float* bn_var, const float* bn_gamma, const float* bn_beta, float bn_eps, void* v_out, void* y_out, void* stream) {
+  if (!in || !w || !scale || !shift || !bn_mean || !bn_var || !bn_gamma || !bn_beta || !v_out || !y_out || B <= 0 || H <= 0 || W <= 0) return ORCAI_E_BADARG;
+  dim3 grid((W + 31) / 32, (H + 7) / 8, B);
+  hipStream_t st = (hipStream_t)stream;
+  const int WP = orcai_padded_width(W, ksize);
+  switch (ksize) {
+    case 3: hipLaunchKernelGGL((conv0_h_kernel<3, true>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, (h16*)v_out, 0, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, (h16*)y_out); break;
+    case 5: hipLaunchKernelGGL((conv0_h_kernel<5, true>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, (h16*)v_out, 0, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, (h16*)y_out); break;
+    case 7: hipLaunchKernelGGL((conv0_h_kernel<7, true>), grid, dim3(256), 0, st, in, snippet_stride, H, W, WP, w, scale, shift, (h16*)v_out, 0, bn_mean, bn_var, bn_gamma, bn_beta, bn_eps, (h16*)y_out); break;
     default: return ORCAI_E_UNSUPPORTED;
   }
   return (int)hipGetLastError();

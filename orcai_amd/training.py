@@ -638,9 +638,11 @@ class TrunkTrainer:
         shapes = m.stage_shapes()
         self.v0_stored = self.half or not self.conv0_two_pass
         if self.v0_stored:
-            N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
-                                             0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
-            if self.half and self.conv0_stats_from_input and self.conv0_march and k == 3:
+            stats_first = bool(self.half and self.conv0_stats_from_input and self.conv0_march and k == 3)
+            if not stats_first:
+                N.check(self._fn("conv0_affine")(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                                 0, b["v0"].data_ptr(), st), "orcai_conv0_affine")
+            if stats_first:
                 # bn0's batch statistics from the 1-channel snippet (the f32 path's marching statistics pass: 4 bytes per pixel read) instead of a pass over
                 # the stored 16-channel v0 (32 bytes per pixel).  They are the statistics of the conv BEFORE its rounding to f16: the mean moves by < 2^-12 of
                 # a standard deviation, the variance by 2^-24 relative -- below what the f16 storage of v0 itself does to the normalised values
@@ -650,7 +652,10 @@ class TrunkTrainer:
                                                     self.scratch.data_ptr(), st), "conv0_stats_march")
                 N.check(lib.orcai_bn_finish_sharded(self.scratch.data_ptr(), B, 16, H, W, mean0.data_ptr(), var0.data_ptr(), st), "bn_finish_sharded")
                 self.stats["bn0"] = (mean0, var0)
-                self._bn_apply(b["v0"], "bn0", 16, H, W, 1, b["y0"])
+                # v0 (kept for the backward pass) and y0 = relu(bn0(v0)) from one launch: the statistics already exist
+                N.check(lib.orcai_h_conv0_affine_bn(src.data_ptr(), snippet_stride, B, H, W, k, P.W("conv0/kernel").data_ptr(), self._ones(16).data_ptr(), P.W("conv0/bias").data_ptr(),
+                                                    mean0.data_ptr(), var0.data_ptr(), P.W("bn0/gamma").data_ptr(), P.W("bn0/beta").data_ptr(), BN_EPS, b["v0"].data_ptr(),
+                                                    b["y0"].data_ptr(), st), "orcai_h_conv0_affine_bn")
             else:
                 self._bn_fwd(b["v0"], "bn0", 16, H, W, 1, b["y0"])
         else:

@@ -427,7 +427,9 @@ def test_half_training_step_at_the_benchmarked_shapes(filters):
     names = sorted({n for n, _, _ in rec.calls})
     print(f"launchers of the f16 training step {filters}:", {n: (len(rec.rcs(n)), sum(rc == N.E_UNSUPPORTED for rc in rec.rcs(n))) for n in names})
     # every k = 3 separable conv of the blocks: statistics in the epilogue, the second conv of a block with bn_a + ReLU on load (y_a is never written)
-    assert rec.rcs("orcai_h_sepconv_stats") == [0] * 4 and rec.rcs("orcai_h_sepconv_stats_bn") == [0] * 4 and not rec.rcs("orcai_h_bn_planes_apply")[1:]
+    assert rec.rcs("orcai_h_sepconv_stats") == [0] * 4 and rec.rcs("orcai_h_sepconv_stats_bn") == [0] * 4 and not rec.rcs("orcai_h_bn_planes_apply")
+    # the entry conv: bn0's statistics from the snippet, then v0 and y0 = relu(bn0(v0)) from one launch
+    assert rec.rcs("orcai_conv0_stats_march") == [0] and rec.rcs("orcai_h_conv0_affine_bn") == [0] and not rec.rcs("orcai_h_conv0_affine")
     assert rec.rcs("orcai_h_dw_bwd_fused") == [0] * 8 and rec.rcs("orcai_h_dw_bwd_fused_res") == [0] and rec.rcs("orcai_h_conv0_bn_bwd_ready") == [0]
     assert not rec.rcs("orcai_h_dw_wgrad") and not rec.rcs("orcai_h_planes_relu_bwd")
     # block 1: BatchNorm backward + du + pointwise weight gradient in one pass (dv never written); the residual bias gradients inside the pooling backward
@@ -853,3 +855,29 @@ def test_depthwise_backward_h_in_one_marching_pass(C, H, W, B, mode):
         s = shards.cpu().numpy()
         tol_s = 3e-6 * np.sqrt(n) * max(1.0, np.abs(got_dr).max() * 3) + 1e-3 * np.sqrt(n) * 2e-3  # + a few gate decisions within f32 rounding of zero
         assert np.abs(s[:C] - db_ref).max() <= tol_s and np.abs(s[8 * CO : 8 * CO + C] - dg_ref).max() <= tol_s, (np.abs(s[:C] - db_ref).max(), np.abs(s[8 * CO : 8 * CO + C] - dg_ref).max(), tol_s)
+
+
+@pytest.mark.parametrize("k,H,W", [(3, 21, 171), (5, 9, 40), (7, 8, 33)])
+def test_entry_conv_with_batchnorm_twin(k, H, W):
+    """orcai_h_conv0_affine_bn (round 4: the pre-normalisation v0 AND y0 = relu(bn0(v0)) from one pass over the snippet) against orcai_h_conv0_affine +
+    orcai_h_bn_planes_apply: both tensors bit for bit (y0 is formed from the f16 value just stored, negative scales included)."""
+    from orcai_amd import _native as N
+
+    lib, st, B = N.lib(), N.stream_ptr(), 3
+    rng = np.random.default_rng(k * 100 + W)
+    x = torch.from_numpy(rng.random((B, H, W)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((k * k, 16)) / k).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(16).astype(np.float32) * 0.2).cuda()
+    ones = torch.ones(16, device="cuda")
+    dev = lambda a: torch.from_numpy(a.astype(np.float32)).cuda()  # noqa: E731
+    mean, var, gamma, beta = dev(rng.standard_normal(16) * 0.3), dev(0.5 + rng.random(16)), dev(rng.standard_normal(16)), dev(rng.standard_normal(16) * 0.5)
+    WP = (W + k // 2 + 3) & ~3
+    shape = (B, 2, H + 2 * (k // 2), WP, 8)
+    v_a, y_a, v_b, y_b = (torch.zeros(shape, dtype=torch.float16, device="cuda") for _ in range(4))
+    N.check(lib.orcai_h_conv0_affine(N.ptr(x), H * W, B, H, W, k, N.ptr(w), N.ptr(ones), N.ptr(bias), 0, N.ptr(v_a), st), "h_conv0_affine")
+    N.check(lib.orcai_h_bn_planes_apply(N.ptr(v_a), B, 16, H, W, k, N.ptr(mean), N.ptr(var), N.ptr(gamma), N.ptr(beta), 1e-3, 1, N.ptr(y_a), st), "h_bn_planes_apply")
+    N.check(lib.orcai_h_conv0_affine_bn(N.ptr(x), H * W, B, H, W, k, N.ptr(w), N.ptr(ones), N.ptr(bias), N.ptr(mean), N.ptr(var), N.ptr(gamma), N.ptr(beta), 1e-3,
+                                        N.ptr(v_b), N.ptr(y_b), st), "h_conv0_affine_bn")
+    torch.cuda.synchronize()
+    assert torch.equal(v_a, v_b) and torch.equal(y_a, y_b)
+    assert float(y_a.float().abs().max()) > 0.3 and 0.1 < float((y_a[:, :, k // 2 : k // 2 + H, :W] == 0).float().mean()) < 0.9  # the ReLU cut something, not everything
