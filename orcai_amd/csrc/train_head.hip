@@ -634,6 +634,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f); }
 
+
+// The gate stage of a training-recurrence step, shared by the three kernels below.  After the MFMAs lane (lk, lj) holds, for its rows 4 lk + r, the
+// pre-activations of column lj of the wave's two 16-column tiles: tile 0 = gate i of unit lj (lj < 8) or f of unit lj - 8, tile 1 = g or o.  Every lane
+// activates its OWN eight values (and stores them: the gate tensor of the backward pass), then the two half-rows trade what the other needs -- i, g of rows
+// 2, 3 go up, f, o of rows 0, 1 go down, four DPP row rotations -- and each finishes TWO (row, unit) cells: 10 exponential / reciprocal pairs per lane and
+// step.  (The first version exchanged the pre-activations and let both half-rows evaluate all four gates of all four rows: 20 pairs, half of them thrown
+// away, in a step whose SIMDs were busy 96 % of the time with exactly these.)  Same functions of the same numbers: the results are bit-identical.
+__device__ __forceinline__ float dpp_xor8(float v) {  // lane l <- lane l ^ 8 (rotation by 8 within a row of 16 lanes)
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128 /*row_ror:8*/, 0xf, 0xf, true));
+}
+template <class StoreGates, class StoreState>
+__device__ __forceinline__ void lstm_gate_stage(const float (&z0)[4], const float (&z1)[4], float (&cst)[4], int lj, StoreGates store_gates, StoreState store_state) {
+  const bool low = lj < 8;
+  const float m1 = low ? 2.0f : -1.0f;  // tile 1: tanh (g) on the low half-row, sigmoid (o) on the high one -- one exponential / reciprocal either way
+  float a0[4], a1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a0[r] = sigmoidf_(z0[r]);
+    const float rc = __builtin_amdgcn_rcpf(__expf(m1 * z1[r]) + 1.0f);
+    a1[r] = low ? fmaf(-2.0f, rc, 1.0f) : rc;  // tanhf_ / sigmoidf_ to the bit
+    store_gates(r, a0[r], a1[r]);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float got0 = dpp_xor8(low ? a0[2 + j] : a0[j]), got1 = dpp_xor8(low ? a1[2 + j] : a1[j]);
+    const float gi = low ? a0[j] : got0, gf = low ? got0 : a0[2 + j];
+    const float gg = low ? a1[j] : got1, go = low ? got1 : a1[2 + j];
+    const float c = gf * cst[j] + gi * gg;
+    const float h = go * tanhf_(c);
+    cst[j] = c;
+    store_state(j, low, h, c);  // row 4 lk + (low ? j : 2 + j); j is a compile-time constant after unrolling
+  }
+}
+
 template <int U>
 __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
                                                                 int B, int T, float* __restrict__ out /*[B][T][2U]*/,
@@ -677,29 +711,26 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_kernel(const float* __re
       acc[0] = mfma16(a, ufrag[0][kk], acc[0]);
       acc[1] = mfma16(a, ufrag[1][kk], acc[1]);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mine0 = acc[0][r], mine1 = acc[1][r];
-      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
-      const bool low = lj < 8;
-      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
-      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
-      const float c = gf * cst[r] + gi * gg;
-      const float h = go * tanhf_(c);
-      cst[r] = c;
-      const int row = lk * 4 + r, bb = b0 + row;
-      if (bb < B) {  // this lane's own two gate columns: tile 0 column lj (i or f), tile 1 column lj (g or o)
-        float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
-        gp[0] = low ? gi : gf;
-        gp[16] = low ? gg : go;
-      }
-      if (low) {
-        hbuf[cur ^ 1][row][unit] = h;
-        if (bb < B) {
-          out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
-          cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
-        }
-      }
+    {
+      const float z0[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]}, z1[4] = {acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+      lstm_gate_stage(
+          z0, z1, cst, lj,
+          [&](int r, float g0, float g1) {  // this lane's own two gate columns: tile 0 column lj (i or f), tile 1 column lj (g or o)
+            const int bb = b0 + lk * 4 + r;
+            if (bb < B) {
+              float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
+              gp[0] = g0;
+              gp[16] = g1;
+            }
+          },
+          [&](int j, bool low, float h, float c) {
+            const int row = lk * 4 + (low ? j : 2 + j), bb = b0 + row;
+            hbuf[cur ^ 1][row][unit] = h;
+            if (bb < B) {
+              out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+              cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
+            }
+          });
     }
     __syncthreads();
   }
@@ -756,29 +787,26 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_h_kernel(const float* __
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ufrag[0][kb], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ufrag[1][kb], acc[1], 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mine0 = acc[0][r], mine1 = acc[1][r];
-      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
-      const bool low = lj < 8;
-      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
-      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
-      const float c = gf * cst[r] + gi * gg;
-      const float h = go * tanhf_(c);
-      cst[r] = c;
-      const int row = lk * 4 + r, bb = b0 + row;
-      if (bb < B) {
-        float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
-        gp[0] = low ? gi : gf;
-        gp[16] = low ? gg : go;
-      }
-      if (low) {
-        hbuf[cur ^ 1][row][unit] = (lh16)h;
-        if (bb < B) {
-          out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
-          cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
-        }
-      }
+    {
+      const float z0[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]}, z1[4] = {acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+      lstm_gate_stage(
+          z0, z1, cst, lj,
+          [&](int r, float g0, float g1) {
+            const int bb = b0 + lk * 4 + r;
+            if (bb < B) {
+              float* gp = gates + (((int64_t)bb * T + t) * 2 + dir) * (4 * U) + wave * 32 + lj;
+              gp[0] = g0;
+              gp[16] = g1;
+            }
+          },
+          [&](int j, bool low, float h, float c) {
+            const int row = lk * 4 + (low ? j : 2 + j), bb = b0 + row;
+            hbuf[cur ^ 1][row][unit] = (lh16)h;
+            if (bb < B) {
+              out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
+              cstate[(((int64_t)bb * T + t) * 2 + dir) * U + unit] = c;
+            }
+          });
     }
     __syncthreads();
   }
@@ -868,32 +896,33 @@ __global__ __launch_bounds__(U * 8) void lstm_train_fwd_split_kernel(const float
         acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uhi[nt][kb], acl[nt], 0, 0, 0);
       }
     }
+    {
+      float z0[4], z1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mine0 = fmaf(acl[0][r], LO_INV, acc[0][r]), mine1 = fmaf(acl[1][r], LO_INV, acc[1][r]);
-      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
-      const bool low = lj < 8;
-      const float gi = sigmoidf_(low ? mine0 : oth0), gf = sigmoidf_(low ? oth0 : mine0);
-      const float gg = tanhf_(low ? mine1 : oth1), go = sigmoidf_(low ? oth1 : mine1);
-      const float c = gf * cst[r] + gi * gg;
-      const float h = go * tanhf_(c);
-      cst[r] = c;
-      const int row = lk * 4 + r;
-      if (rowok[r]) {
-        float* gp = gates + (xo[r] + (uint32_t)t * (uint32_t)(8 * U));
-        gp[0] = low ? gi : gf;
-        gp[16] = low ? gg : go;
+      for (int r = 0; r < 4; ++r) {
+        z0[r] = fmaf(acl[0][r], LO_INV, acc[0][r]);
+        z1[r] = fmaf(acl[1][r], LO_INV, acc[1][r]);
       }
-      if (low) {
-        lh16 hh, hl;
-        split_f16(h, hh, hl);
-        hhi[cur ^ 1][row][unit] = hh;
-        hlo[cur ^ 1][row][unit] = hl;
-        if (rowok[r]) {
-          out[oo[r] + (uint32_t)t * (uint32_t)(2 * U)] = h;
-          cstate[co[r] + (uint32_t)t * (uint32_t)(2 * U)] = c;
-        }
-      }
+      lstm_gate_stage(
+          z0, z1, cst, lj,
+          [&](int r, float g0, float g1) {
+            if (rowok[r]) {
+              float* gp = gates + (xo[r] + (uint32_t)t * (uint32_t)(8 * U));
+              gp[0] = g0;
+              gp[16] = g1;
+            }
+          },
+          [&](int j, bool low, float h, float c) {
+            const int row = lk * 4 + (low ? j : 2 + j);
+            lh16 hh, hl;
+            split_f16(h, hh, hl);
+            hhi[cur ^ 1][row][unit] = hh;
+            hlo[cur ^ 1][row][unit] = hl;
+            if (low ? rowok[j] : rowok[2 + j]) {
+              out[(low ? oo[j] : oo[2 + j]) + (uint32_t)t * (uint32_t)(2 * U)] = h;
+              cstate[(low ? co[j] : co[2 + j]) + (uint32_t)t * (uint32_t)(2 * U)] = c;
+            }
+          });
     }
     __syncthreads();
   }
@@ -1325,9 +1354,9 @@ __global__ __launch_bounds__(256) void pack_lstm_kernel(const float* __restrict_
   const int* d = desc + blockIdx.x * 7;
   const int rows = d[2], u = d[3], ld = d[4], col_off = d[5], mode = d[6];
   const float* src = w + d[0];
-  const int64_t n = (int64_t)rows * 4 * u;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) {
-    const int r = (int)(i / (4 * u)), p = (int)(i - (int64_t)r * 4 * u);
+  const uint32_t n = (uint32_t)rows * 4u * (uint32_t)u, u4 = 4u * (uint32_t)u;  // (< 2^31: the launcher's descriptors are weight matrices; 32-bit index arithmetic)
+  for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+    const int r = (int)(i / u4), p = (int)(i - (uint32_t)r * u4);
     const float v = src[(int64_t)r * 4 * u + lstm_perm(p, u)];
     if (mode == 0) out32[d[1] + (int64_t)r * ld + col_off + p] = v;
     else out16[d[1] + (int64_t)(col_off + p) * ld + r] = (_Float16)v;
@@ -1353,9 +1382,9 @@ struct UnpackBatch {
 };
 __global__ __launch_bounds__(256) void unpack_lstm_grads_kernel(UnpackBatch b, int u) {
   const orcai_unpack_desc d = b.d[blockIdx.y];
-  const int64_t n = (int64_t)d.rows * 4 * u;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int r = (int)(i / (4 * u)), p = (int)(i - (int64_t)r * 4 * u);
+  const uint32_t n = (uint32_t)d.rows * 4u * (uint32_t)u, u4 = 4u * (uint32_t)u;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = (int)(i / u4), p = (int)(i - (uint32_t)r * u4);
     const int64_t k = (int64_t)r * 4 * u + lstm_perm(p, u);
     float v = d.src[(int64_t)r * d.ld_src + d.col_off + p];
     if (d.W) v = fmaf(d.l2g, d.W[k], v);
@@ -1684,7 +1713,7 @@ int orcai_lstm_bwd(const float* dH, const float* gates, const float* cstate, con
 
 int orcai_pack_lstm(const float* w, const int* desc, int n_desc, float* out32, void* out16, void* stream) {
   if (!w || !desc || n_desc <= 0 || (!out32 && !out16)) return ORCAI_E_BADARG;
-  hipLaunchKernelGGL(pack_lstm_kernel, dim3(n_desc, 16), dim3(256), 0, (hipStream_t)stream, w, desc, out32, (_Float16*)out16);
+  hipLaunchKernelGGL(pack_lstm_kernel, dim3(n_desc, 64), dim3(256), 0, (hipStream_t)stream, w, desc, out32, (_Float16*)out16);
   return (int)hipGetLastError();
 }
 
