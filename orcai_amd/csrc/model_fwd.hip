@@ -1956,6 +1956,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f), 1.0f); }
 
+// The gate stage of a recurrence step (the training kernels' lstm_gate_stage, train_head.hip, without the gate store): every lane activates its OWN eight
+// pre-activations -- tile 0 column lj = gate i (lj < 8) or f, tile 1 = g or o, rows 4 lk + r -- then the half-rows trade what the other needs (four DPP row
+// rotations) and each finishes two (row, unit) cells: 10 exponential / reciprocal pairs per lane and step instead of 20, the same functions of the same numbers.
+__device__ __forceinline__ float dpp_xor8(float v) {  // lane l <- lane l ^ 8
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128 /*row_ror:8*/, 0xf, 0xf, true));
+}
+template <class StoreState>
+__device__ __forceinline__ void lstm_gate_stage(const float (&z0)[4], const float (&z1)[4], float (&cst)[4], int lj, StoreState store_state) {
+  const bool low = lj < 8;
+  const float m1 = low ? 2.0f : -1.0f;  // tile 1: tanh (g) on the low half-row, sigmoid (o) on the high one
+  float a0[4], a1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    a0[r] = sigmoidf_(z0[r]);
+    const float rc = __builtin_amdgcn_rcpf(__expf(m1 * z1[r]) + 1.0f);
+    a1[r] = low ? fmaf(-2.0f, rc, 1.0f) : rc;  // tanhf_ / sigmoidf_ to the bit
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float got0 = dpp_xor8(low ? a0[2 + j] : a0[j]), got1 = dpp_xor8(low ? a1[2 + j] : a1[j]);
+    const float gi = low ? a0[j] : got0, gf = low ? got0 : a0[2 + j];
+    const float gg = low ? a1[j] : got1, go = low ? got1 : a1[2 + j];
+    const float c = gf * cst[j] + gi * gg;
+    const float h = go * tanhf_(c);
+    cst[j] = c;
+    store_state(low ? j : 2 + j, h);
+  }
+}
+
 template <int U>
 __global__ __launch_bounds__(U * 8) void lstm_kernel(const float* __restrict__ xz /*[B][T][2][4U] permuted*/, const float* __restrict__ Uw /*[2][U][4U] permuted*/,
                                                       int B, int T, float* __restrict__ out /*[B][T][2U]*/) {
@@ -2001,22 +2030,14 @@ __global__ __launch_bounds__(U * 8) void lstm_kernel(const float* __restrict__ x
       acc[1] = mfma16(a, ufrag[1][kk], acc[1]);
     }
     // lane j<8 holds (i, g), lane j+8 holds (f, o) of the same unit: swap across the pair
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mine0 = acc[0][r], mine1 = acc[1][r];
-      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
-      const bool low = lj < 8;
-      const float zi = low ? mine0 : oth0, zf = low ? oth0 : mine0;
-      const float zg = low ? mine1 : oth1, zo = low ? oth1 : mine1;
-      const float c = sigmoidf_(zf) * cst[r] + sigmoidf_(zi) * tanhf_(zg);
-      const float h = sigmoidf_(zo) * tanhf_(c);
-      cst[r] = c;
-      if (low) {
+    {
+      const float z0[4] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]}, z1[4] = {acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+      lstm_gate_stage(z0, z1, cst, lj, [&](int r, float h) {
         const int row = lk * 4 + r;
         hbuf[cur ^ 1][row][unit] = h;
         const int bb = b0 + row;
         if (bb < B) out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
-      }
+      });
     }
     __syncthreads();
   }
@@ -2089,17 +2110,14 @@ __global__ __launch_bounds__(U * 8) void lstm_split_kernel(const float* __restri
         acl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, uhi[nt][kb], acl[nt], 0, 0, 0);
       }
     }
+    {
+      float z0[4], z1[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float mine0 = fmaf(acl[0][r], LO_INV, acc[0][r]), mine1 = fmaf(acl[1][r], LO_INV, acc[1][r]);
-      const float oth0 = __shfl_xor(mine0, 8, 64), oth1 = __shfl_xor(mine1, 8, 64);
-      const bool low = lj < 8;
-      const float zi = low ? mine0 : oth0, zf = low ? oth0 : mine0;
-      const float zg = low ? mine1 : oth1, zo = low ? oth1 : mine1;
-      const float c = sigmoidf_(zf) * cst[r] + sigmoidf_(zi) * tanhf_(zg);
-      const float h = sigmoidf_(zo) * tanhf_(c);
-      cst[r] = c;
-      if (low) {
+      for (int r = 0; r < 4; ++r) {
+        z0[r] = fmaf(acl[0][r], LO_INV, acc[0][r]);
+        z1[r] = fmaf(acl[1][r], LO_INV, acc[1][r]);
+      }
+      lstm_gate_stage(z0, z1, cst, lj, [&](int r, float h) {
         const int row = lk * 4 + r;
         mh16 hh, hl;
         split_f16_m(h, hh, hl);
@@ -2107,7 +2125,7 @@ __global__ __launch_bounds__(U * 8) void lstm_split_kernel(const float* __restri
         hlo[cur ^ 1][row][unit] = hl;
         const int bb = b0 + row;
         if (bb < B) out[((int64_t)bb * T + t) * (2 * U) + dir * U + unit] = h;
-      }
+      });
     }
     __syncthreads();
   }
