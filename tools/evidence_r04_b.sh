@@ -4,7 +4,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ev4
-mkdir -p $O
+mkdir -p $O && rm -rf $O/pmc_*   # (a merge of two runs would average kernels of different builds)
 cd /tmp && export TMPDIR=/tmp
 # every bench line ends with its CPU baseline (10-15 s of 16 busy host threads); the training steps are ~270 launches per 15 ms and slow
 # down by 10-15 % when the NEXT process starts on host cores that are still hot from it (measured: 15.5 -> 17.0-18.2 ms with identical
