@@ -207,6 +207,34 @@ __global__ __launch_bounds__(256) void bn_planes_bwd_sums_h_kernel(const h16* __
 }
 
 // ---------------------------------------------------------------- BN backward apply fused with the transposed pointwise conv
+// The per-channel constants of a BatchNorm backward, once per workgroup in LDS: tab[c] = {mean, inv = rsqrt(var + eps), gamma, beta | A = gamma inv,
+// c1 = dbeta / N, c2 = dgamma / N, 0} (zeros for c >= C: dv = 0 there).  Formed inside the pixel loop they are wave-uniform arithmetic the compiler
+// spreads over scalar loads, double -> float conversions and v_rsq on the vector ALU: a quarter of the fused weight-gradient kernel's 1 000 vector
+// instructions per 256-pixel pass (profiles/r04_pmc_issue_hps.json: VALU issuing on 81 % of SIMD cycles).  Two broadcast 16-byte LDS reads per channel instead.
+template <class Row0, class Row1>
+__device__ __forceinline__ void fill_bn_bwd_table(Row0 row0, Row1 row1, int Cpad, int C, const float* __restrict__ mean, const float* __restrict__ var,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, const double* __restrict__ dbeta,
+                                                  const double* __restrict__ dgamma, float inv_count, int tid, int nthreads) {
+  for (int c = tid; c < Cpad; c += nthreads) {
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
+    if (c < C) {
+      const float inv = rsqrtf(var[c] + eps);
+      k0 = make_float4(mean[c], inv, gamma[c], beta[c]);
+      k1 = make_float4(gamma[c] * inv, (float)dbeta[c] * inv_count, (float)dgamma[c] * inv_count, 0.0f);
+    }
+    *row0(c) = k0;
+    *row1(c) = k1;
+  }
+}
+// dv of one channel value from the table row (the arithmetic of the original in-loop form, operation for operation)
+__device__ __forceinline__ float bn_bwd_value(const float4* __restrict__ r0, const float4* __restrict__ r1, float vv, float dd, int relu, bool live) {
+  const float4 k0 = *r0, k1 = *r1;
+  const float xh = (vv - k0.x) * k0.y;
+  float de = dd;
+  if (relu && !(fmaf(xh, k0.z, k0.w) > 0.0f)) de = 0.0f;
+  return live ? k1.x * (de - k1.y - xh * k1.z) : 0.0f;
+}
+
 // dv = gamma*inv*(dy_eff - dbeta/N - xhat*dgamma/N) (stored, f16) AND du = Wpw dv in one pass: one wave = 64 consecutive flat pixels.
 // wtf: A fragments of the TRANSPOSED pointwise weights, [KG of the conv-OUTPUT channels][MT of the conv-INPUT channels][64][8].
 template <int MT>
@@ -215,12 +243,17 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_h_kernel(const h16* dy, const h
                                                            const float* __restrict__ beta, float eps, int relu, const double* __restrict__ dbeta,
                                                            const double* __restrict__ dgamma, float inv_count, const h16* __restrict__ wtf, int Cin,
                                                            h16* dv /*may alias dy*/, h16* __restrict__ du, int tasks, uint32_t magic_WP) {
+  __shared__ __attribute__((aligned(16))) float bnk[64 * 8];  // BatchNorm backward constants of the <= 64 channels (fill_bn_bwd_table)
   const int lane = threadIdx.x & 63;
   const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int CO = (C + 7) >> 3, COi = (Cin + 7) >> 3, KG = (CO + 3) >> 2;
+  auto bn0 = [&](int c) { return reinterpret_cast<float4*>(bnk + c * 8); };
+  auto bn1 = [&](int c) { return reinterpret_cast<float4*>(bnk + c * 8 + 4); };
+  fill_bn_bwd_table(bn0, bn1, CO * 8, C, mean, var, gamma, beta, eps, dbeta, dgamma, inv_count, threadIdx.x, 256);
+  __syncthreads();
   if (task >= tasks) return;
   const int b = blockIdx.y;
   const int lk = lane >> 4, lj = lane & 15;
-  const int CO = (C + 7) >> 3, COi = (Cin + 7) >> 3, KG = (CO + 3) >> 2;
   const int plane = (H + 2 * R) * WP;
   const int qbase = R * WP + task * 64;
   const int q = qbase + lane;
@@ -242,18 +275,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_h_kernel(const h16* dy, const h
         const O8 dd = ld8(dy, base + (int64_t)o * plane), vv = ld8(v, base + (int64_t)o * plane);
         O8 r;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int c = o * 8 + k;
-          if (c < C) {
-            const float inv = rsqrtf(var[c] + eps);
-            const float xh = (vv.v[k] - mean[c]) * inv;
-            float de = dd.v[k];
-            if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
-            r.v[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
-          } else {
-            r.v[k] = 0.0f;
-          }
-        }
+        for (int k = 0; k < 8; ++k) r.v[k] = bn_bwd_value(bn0(o * 8 + k), bn1(o * 8 + k), vv.v[k], dd.v[k], relu, live);
         const h16x8 packed = pack8(r.v);
         if (live) reinterpret_cast<h16x8*>(dv)[base + (int64_t)o * plane] = packed;
         d[oo] = as_u(packed);
@@ -570,7 +592,14 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_h_kernel(const h16* __res
   const int plane = (H + 2 * R) * WP;
   for (int i = tid; i < 256 * pa_h / 2; i += 256) reinterpret_cast<uint32_t*>(As)[i] = 0u;
   for (int i = tid; i < 256 * pb_h / 2; i += 256) reinterpret_cast<uint32_t*>(Bs)[i] = 0u;
-  // BatchNorm constants of this lane's 8 * COB output channels stay in registers? no: they are wave-uniform per channel -> scalar loads inside the pass
+  // BatchNorm backward constants of conv-output channel c live in the 16 padding bytes of row c of the two images (the passes write halves [0, 16 MT) and
+  // [0, 16 NT) of a row only): a table of its own would be the 33rd LDS granule of a workgroup that fits a compute unit exactly four times at 32
+  static_assert(NT * 16 <= 256, "one image row per channel");
+  auto bn0 = [&](int c) { return reinterpret_cast<float4*>(As + c * pa_h + MT * 16); };
+  auto bn1 = [&](int c) { return reinterpret_cast<float4*>(Bs + c * pb_h + NT * 16); };
+  __syncthreads();  // the zero fill is done
+  fill_bn_bwd_table(bn0, bn1, NT * 16, C, mean, var, gamma, beta, eps, dbeta, dgamma, inv_count, tid, 256);
+  __syncthreads();
   const int chunks_per_plane = (H * WP + 255) >> 8;  // 256-pixel chunks covering the H image rows of a plane (start at row R)
   const int64_t nchunks = (int64_t)B * chunks_per_plane;
   f32x4 wacc = (f32x4){0.f, 0.f, 0.f, 0.f};  // this wave's tile of dW: tile index = wave (< MT * NT)
@@ -605,18 +634,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_h_kernel(const h16* __res
         unpack8(rdy[o], dd);
         unpack8(rv[o], vv);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int c = o * 8 + k;
-          if (c < C) {
-            const float inv = rsqrtf(var[c] + eps);
-            const float xh = (vv[k] - mean[c]) * inv;
-            float de = dd[k];
-            if (relu && !(fmaf(xh, gamma[c], beta[c]) > 0.0f)) de = 0.0f;
-            r[k] = live ? gamma[c] * inv * (de - (float)dbeta[c] * inv_count - xh * ((float)dgamma[c] * inv_count)) : 0.0f;
-          } else {
-            r[k] = 0.0f;
-          }
-        }
+        for (int k = 0; k < 8; ++k) r[k] = bn_bwd_value(bn0(o * 8 + k), bn1(o * 8 + k), vv[k], dd[k], relu, live);
         dvo[o < COB ? o : 0] = pack8(r);
         d[o] = as_u(dvo[o < COB ? o : 0]);
       } else {

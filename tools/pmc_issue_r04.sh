@@ -15,6 +15,7 @@ for what in ${1:-fused twolaunch train}; do
     case $what in
       fused)     ORCAI_POOL_FUSED=12 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/tools/debug_predict.py 300 128 > $d.log 2>&1 && echo $what-pass-$i-ok ;;
       twolaunch) ORCAI_POOL_FUSED=0  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/tools/debug_predict.py 300 128 > $d.log 2>&1 && echo $what-pass-$i-ok ;;
+      hps)       ORCAI_HPS_VARIANTS=set3 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --workload hpsearch --steps 1 --warmup 1 --no-cpu-baseline --no-loss-curves > $d.log 2>&1 && echo $what-pass-$i-ok ;;
       train)     rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/tools/debug_train.py 64 > $d.log 2>&1 && echo $what-pass-$i-ok ;;
     esac
   done
