@@ -173,7 +173,7 @@ def allreduce_probe(dist, wl) -> dict:
     return {"allreduce_us": round((time.perf_counter() - t1) / 20 * 1e6, 1), "allreduce_bytes": int(g.numel() * 4)}
 
 
-def measure_secondary(device, rank, world, dist, steps=10, warmup=2):
+def measure_secondary(device, rank, world, dist, steps=20, warmup=3):
     """BASELINE.json's metric has a second half -- training snippets/s at 1/2/4/8 GPUs -- that a single JSON line cannot carry as
     `value`.  After the headline measurement every rank also times the training step (configs[3]: batch 64 per GPU, data parallel,
     one RCCL all-reduce of the flat gradient bucket per step) the same way (warm-up, barrier + synchronize on both sides, MAX over
@@ -373,6 +373,7 @@ def main():
     secondary = None
     secondary2 = None
     if args.workload == "predict" and "train" in WORKLOADS and not args.no_secondary:
+        torch.cuda.empty_cache()  # the headline workload's cached blocks back to the driver: the training buffers get fresh, contiguous ranges as in a stand-alone run
         secondary = measure_secondary(device, rank, world, dist)
         torch.cuda.empty_cache()
         secondary2 = measure_sweep(device, rank, world, dist)
