@@ -47,6 +47,9 @@ def main():
     print(f"{f.name}: {len(rows)} dispatches over {wall / 1e6:.2f} ms; device busy {busy / 1e6:.2f} ms = {busy / wall:.3f}; sum of durations {sum(ksum.values()) / 1e6:.2f} ms; idle {(wall - busy) / 1e6:.2f} ms")
     big = [g for g in gaps.values()]
     print(f"gaps: {sum(gap_n.values())} totalling {sum(big) / 1e6:.2f} ms; mean {sum(big) / max(1, sum(gap_n.values())) / 1e3:.2f} us")
+    print(f"{'kernel':70s} {'n':>6s} {'total ms':>9s} {'mean us':>8s}")
+    for n, t in sorted(ksum.items(), key=lambda kv: -kv[1])[:top]:
+        print(f"{n[:70]:70s} {kn[n]:6d} {t / 1e6:9.3f} {t / kn[n] / 1e3:8.1f}")
     print(f"{'gap BEFORE kernel':70s} {'n':>6s} {'gap ms':>8s} {'mean us':>8s} {'kernel mean us':>14s}")
     for n, g in sorted(gaps.items(), key=lambda kv: -kv[1])[:top]:
         print(f"{n[:70]:70s} {gap_n[n]:6d} {g / 1e6:8.3f} {g / gap_n[n] / 1e3:8.2f} {ksum[n] / kn[n] / 1e3:14.1f}")
