@@ -811,6 +811,18 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
   }
 }
 
+// Sum of v over the 64 lanes, delivered in lane 63: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals
+// across rows -- six v_add_f32 with a DPP operand instead of six ds_bpermute + six adds per value (a marching wave reduces 88 accumulators when it ends).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x118 /*row_shr:8*/, 0xf, 0xf, true));  // lane 15 of every row: the row's sum
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142 /*row_bcast:15*/, 0xa, 0xf, false));  // rows 1, 3 += lane 15 of rows 0, 2
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143 /*row_bcast:31*/, 0xc, 0xf, false));  // rows 2, 3 += lane 31
+  return v;
+}
+
 // ---------------------------------------------------------------- depthwise backward in ONE marching pass (k = 3), f16 octet planes
 // The f16 twin of train_trunk.hip's dw_bwd_march_kernel: the input gradient dr = du (*) reversed taps (what orcai_h_sepconv computes with the
 // identity pointwise factor: packed-f16 products, f16 output), its epilogue extra (EPI 2: backward sums of the BatchNorm whose pre-normalisation
@@ -963,18 +975,14 @@ __global__ __launch_bounds__(256) void dw_bwd_march_h_kernel(const h16* __restri
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   if (EPI == 2) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      float v = j < 8 ? s1[j & 7] : s2[j & 7];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][8 * KK + j] = v;
+      const float v = wave_sum_lane63(j < 8 ? s1[j & 7] : s2[j & 7]);
+      if (lane == 63) red[threadIdx.x >> 6][8 * KK + j] = v;
     }
   }
   __syncthreads();
@@ -1007,7 +1015,10 @@ int launch_dw_bwd_h(hipStream_t st, const h16* x, const h16* du, int B, int C, i
   constexpr int NSUB = 64 / SW;
   const int CO = (C + 7) / 8;
   const int64_t per_seg = (int64_t)B * CO * nstrip;
-  int nseg = (int)((16384ll * NSUB + per_seg - 1) / per_seg);
+  // segments: ~6 waves per SIMD over the chip in total.  A wave ends with the cross-lane reduction of its 72 (+16) f32 accumulators -- 617 LDS
+  // permutes + 542 adds, 12 % of its instructions at 36-row segments -- so longer segments pay until the last round's imbalance takes it back:
+  // 16 384 waves 16.32 ms per sweep step, 8 192 16.05-16.2, 6 144 16.11, 4 096 16.14, 2 048 16.19 (profiles/r04_ab_march_waves.log; the f32 twin is flat)
+  int nseg = (int)((6144ll * NSUB + per_seg - 1) / per_seg);
   if (nseg < 1) nseg = 1;
   if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;
   int rps = (H + nseg - 1) / nseg;

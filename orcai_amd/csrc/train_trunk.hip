@@ -1695,7 +1695,7 @@ static int launch_dw_bwd(hipStream_t st, const float* x, const float* du, int B,
   constexpr int NSUB = 64 / SW;
   const int CQ = (C + 3) / 4;
   const int64_t per_seg = (int64_t)B * CQ * nstrip;
-  int nseg = (int)((16384ll * NSUB + per_seg - 1) / per_seg);  // ~16 waves per SIMD over the chip in total
+  int nseg = (int)((16384ll * NSUB + per_seg - 1) / per_seg);  // ~16 waves per SIMD over the chip in total (8 192 ... 24 576 measured: flat, profiles/r04_ab_march_waves.log)
   if (nseg < 1) nseg = 1;
   if (nseg > (H + 23) / 24) nseg = (H + 23) / 24;  // at least 24 rows per segment: two halo rows of du are re-read per segment
   int rps = (H + nseg - 1) / nseg;
