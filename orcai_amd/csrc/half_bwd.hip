@@ -13,6 +13,19 @@
 
 namespace {
 
+// Sum of v over the 64 lanes, delivered in lane 63: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals
+// across rows -- six v_add_f32 with a DPP operand instead of six ds_bpermute + six adds per value (a marching wave reduces 88 accumulators when it ends).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x118 /*row_shr:8*/, 0xf, 0xf, true));  // lane 15 of every row: the row's sum
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142 /*row_bcast:15*/, 0xa, 0xf, false));  // rows 1, 3 += lane 15 of rows 0, 2
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143 /*row_bcast:31*/, 0xc, 0xf, false));  // rows 2, 3 += lane 31
+  return v;
+}
+
+
 using namespace orcai_half;
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -798,10 +811,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
   for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   __syncthreads();
   if (threadIdx.x < NCH * KK) {
@@ -809,18 +820,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_h_kernel(const h16* __restrict__
     const int c = co * 8 + c0 + j;
     if (c < C) atomicAdd(&dW[t * C + c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
   }
-}
-
-// Sum of v over the 64 lanes, delivered in lane 63: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals
-// across rows -- six v_add_f32 with a DPP operand instead of six ds_bpermute + six adds per value (a marching wave reduces 88 accumulators when it ends).
-__device__ __forceinline__ float wave_sum_lane63(float v) {
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x118 /*row_shr:8*/, 0xf, 0xf, true));  // lane 15 of every row: the row's sum
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142 /*row_bcast:15*/, 0xa, 0xf, false));  // rows 1, 3 += lane 15 of rows 0, 2
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143 /*row_bcast:31*/, 0xc, 0xf, false));  // rows 2, 3 += lane 31
-  return v;
 }
 
 // ---------------------------------------------------------------- depthwise backward in ONE marching pass (k = 3), f16 octet planes
@@ -1091,10 +1090,8 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_h_kernel(const float* __re
   for (int j = 0; j < NCH; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float s2 = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-      if (lane == 0) red[wave][j * KK + t] = s2;
+      const float s2 = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[wave][j * KK + t] = s2;
     }
   __syncthreads();
   if (threadIdx.x < NCH * KK) {

@@ -12,6 +12,19 @@
 
 namespace {
 
+// Sum of v over the 64 lanes, delivered in lane 63: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals
+// across rows -- DPP operands instead of six ds_bpermute per value (a marching wave reduces dozens of accumulators when it ends).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x111 /*row_shr:1*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x112 /*row_shr:2*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x114 /*row_shr:4*/, 0xf, 0xf, true));
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x118 /*row_shr:8*/, 0xf, 0xf, true));  // lane 15 of every row: the row's sum
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x142 /*row_bcast:15*/, 0xa, 0xf, false));  // rows 1, 3 += lane 15 of rows 0, 2
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x143 /*row_bcast:31*/, 0xc, 0xf, false));  // rows 2, 3 += lane 31
+  return v;
+}
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 inline uint32_t magic_for(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
@@ -889,10 +902,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   __syncthreads();
   if (threadIdx.x < 4 * KK) {
@@ -994,10 +1005,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_march_kernel(const float* __rest
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   __syncthreads();
   if (threadIdx.x < 4 * KK) {
@@ -1226,18 +1235,14 @@ __global__ __launch_bounds__(256) void dw_bwd_march_kernel(const float* __restri
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[threadIdx.x >> 6][j * KK + t] = v;
     }
   if (EPI == 2) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float v = j < 4 ? s1[j & 3] : s2[j & 3];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[threadIdx.x >> 6][4 * KK + j] = v;
+      const float v = wave_sum_lane63(j < 4 ? s1[j & 3] : s2[j & 3]);
+      if (lane == 63) red[threadIdx.x >> 6][4 * KK + j] = v;
     }
   }
   __syncthreads();
@@ -1359,10 +1364,8 @@ __global__ __launch_bounds__(256) void conv0_march_kernel(const float* __restric
   __shared__ float red[4][NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    float v = acc[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) red[threadIdx.x >> 6][i] = v;
+    const float v = wave_sum_lane63(acc[i]);
+    if (lane == 63) red[threadIdx.x >> 6][i] = v;
   }
   __syncthreads();
   if (threadIdx.x < NACC) {
@@ -1428,10 +1431,8 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float v = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) red[wave][j * KK + t] = v;
+      const float v = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[wave][j * KK + t] = v;
     }
   __syncthreads();
   if (threadIdx.x < 4 * KK) {
@@ -1497,10 +1498,8 @@ __global__ __launch_bounds__(256) void conv0_bn_wgrad_kernel(const float* __rest
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      float s2 = acc[j][t];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
-      if (lane == 0) red[wave][j * KK + t] = s2;
+      const float s2 = wave_sum_lane63(acc[j][t]);
+      if (lane == 63) red[wave][j * KK + t] = s2;
     }
   __syncthreads();
   if (threadIdx.x < 4 * KK) {
@@ -1612,10 +1611,8 @@ __global__ __launch_bounds__(256) void conv0_bn_bwd_x_kernel(const float* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    float v = acc[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) red[wave][i] = v;
+    const float v = wave_sum_lane63(acc[i]);
+    if (lane == 63) red[wave][i] = v;
   }
   __syncthreads();
   if (threadIdx.x < NACC) {
