@@ -25,6 +25,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// The same for a double (the two halves travel as 32-bit DPP moves): the float64 block reductions of the pooling backward were LDS trees of
+// eight barrier-separated levels over a [256][8 .. 12] double image (16 .. 24 KB of LDS per workgroup, nine barriers per reduction).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint32_t lo = (uint32_t)__double2loint(v), hi = (uint32_t)__double2hiint(v);
+  return __hiloint2double((int)__builtin_amdgcn_update_dpp(0u, hi, CTRL, ROW_MASK, 0xf, BOUND), (int)__builtin_amdgcn_update_dpp(0u, lo, CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_f64<0x111, 0xf, true>(v);
+  v += dpp_f64<0x112, 0xf, true>(v);
+  v += dpp_f64<0x114, 0xf, true>(v);
+  v += dpp_f64<0x118, 0xf, true>(v);
+  v += dpp_f64<0x142, 0xa, false>(v);
+  v += dpp_f64<0x143, 0xc, false>(v);
+  return v;
+}
+
+
 
 using namespace orcai_half;
 
@@ -460,24 +478,21 @@ __global__ __launch_bounds__(256) void pool_bwd_h_kernel(const h16* __restrict__
     if (cx0) emit((int64_t)(rl + R) * WP + x0, c0, t0);
     if (cx1) emit((int64_t)(rl + R) * WP + x1, c1, t1);
   }
-  if (bn_sums) {
-    __shared__ double red[256][8];
-    double a[8];
+  if (bn_sums) {  // workgroup reduction (float64): DPP sums inside each wave, the four waves through 768 bytes of LDS, 16 (+ 8) atomics per workgroup
+    __shared__ double red[4][24];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = (double)bs[k];
-    block_reduce8(red, a);
-    if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&bn_sums[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+    for (int k = 0; k < 24; ++k) {
+      const double v = wave_sum_lane63((double)(k < 8 ? bs[k & 7] : (k < 16 ? bqs[k & 7] : ds[k & 7])));
+      if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6][k] = v;
+    }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = (double)bqs[k];
-    block_reduce8(red, a);
-    if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&bn_sums[8 * CO + co * 8 + threadIdx.x], red[0][threadIdx.x]);
-    if (dout_sums) {
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a[k] = (double)ds[k];
-      block_reduce8(red, a);
-      if (threadIdx.x < 8 && co * 8 + threadIdx.x < C) atomicAdd(&dout_sums[co * 8 + threadIdx.x], red[0][threadIdx.x]);
+    if (threadIdx.x < 24) {
+      const int k = threadIdx.x & 7;
+      const double tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      if (co * 8 + k < C) {
+        if (threadIdx.x < 16) atomicAdd(&bn_sums[(threadIdx.x >> 3) * 8 * CO + co * 8 + k], tot);
+        else if (dout_sums) atomicAdd(&dout_sums[co * 8 + k], tot);
+      }
     }
   }
 }

@@ -24,6 +24,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// The same for a double (the two halves travel as 32-bit DPP moves): the float64 block reductions of the pooling backward were LDS trees of
+// eight barrier-separated levels over a [256][8 .. 12] double image (16 .. 24 KB of LDS per workgroup, nine barriers per reduction).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint32_t lo = (uint32_t)__double2loint(v), hi = (uint32_t)__double2hiint(v);
+  return __hiloint2double((int)__builtin_amdgcn_update_dpp(0u, hi, CTRL, ROW_MASK, 0xf, BOUND), (int)__builtin_amdgcn_update_dpp(0u, lo, CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_f64<0x111, 0xf, true>(v);
+  v += dpp_f64<0x112, 0xf, true>(v);
+  v += dpp_f64<0x114, 0xf, true>(v);
+  v += dpp_f64<0x118, 0xf, true>(v);
+  v += dpp_f64<0x142, 0xa, false>(v);
+  v += dpp_f64<0x143, 0xc, false>(v);
+  return v;
+}
+
+
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -635,22 +653,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     if (cx0) emit((int64_t)(rl + R) * WP + x0, c0, t0);
     if (cx1) emit((int64_t)(rl + R) * WP + x1, c1, t1);
   }
-  if (bn_sums) {  // block reduction (float64) and 8 (+ 4) atomics per workgroup
-    __shared__ double red[256][12];
+  if (bn_sums) {  // workgroup reduction (float64): DPP sums inside each wave, the four waves through 384 bytes of LDS, 8 (+ 4) atomics per workgroup
+    __shared__ double red[4][12];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = (double)bs[k]; red[threadIdx.x][4 + k] = (double)bqs[k]; red[threadIdx.x][8 + k] = (double)ds[k]; }
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
-      __syncthreads();
+    for (int k = 0; k < 12; ++k) {
+      const double v = wave_sum_lane63((double)(k < 4 ? bs[k & 3] : (k < 8 ? bqs[k & 3] : ds[k & 3])));
+      if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6][k] = v;
     }
+    __syncthreads();
     if (threadIdx.x < 12) {
       const int k = threadIdx.x & 3, c = (int)(bq % CQ) * 4 + k;
+      const double tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
       if (c < C) {
-        if (threadIdx.x < 8) atomicAdd(&bn_sums[(threadIdx.x >> 2) * 4 * CQ + c], red[0][threadIdx.x]);
-        else if (dout_sums) atomicAdd(&dout_sums[c], red[0][threadIdx.x]);
+        if (threadIdx.x < 8) atomicAdd(&bn_sums[(threadIdx.x >> 2) * 4 * CQ + c], tot);
+        else if (dout_sums) atomicAdd(&dout_sums[c], tot);
       }
     }
   }
