@@ -326,6 +326,19 @@ __global__ __launch_bounds__(256) void pool_res_add_h_kernel(const h16* __restri
     }
   }
   const int WPx = (Wo + 3) & ~3;
+  // training forward: the folded BatchNorm of this lane's output octets, once per window (the octet of a lane does not change with the tile pair)
+  float bsc[MT][8], bsh[MT][8];
+  if (bn_mean) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (2 * m + (lk >> 1)) * 8 + e, cc = c < C ? c : 0;
+        const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps);
+        bsc[m][e] = sc;
+        bsh[m][e] = bn_beta[cc] - bn_mean[cc] * sc;
+      }
+  }
 #pragma unroll
   for (int tp = 0; tp < 4; tp += 2) {
     const int flat = qbase + 16 * (tp + (lk & 1)) + lj;
@@ -388,11 +401,7 @@ __global__ __launch_bounds__(256) void pool_res_add_h_kernel(const h16* __restri
       for (int e = 0; e < 8; ++e) {
         const int c = oq * 8 + e;
         float pooled = pm[e];
-        if (bn_mean) {
-          const int cc = c < C ? c : 0;
-          const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps);
-          pooled = fmaf(sc >= 0.0f ? pm[e] : pn[e], sc, bn_beta[cc] - bn_mean[cc] * sc);
-        }
+        if (bn_mean) pooled = fmaf(bsc[m][e] >= 0.0f ? pm[e] : pn[e], bsc[m][e], bsh[m][e]);
         o8[e] = c < C ? pooled + res[e] : 0.0f;
       }
       reinterpret_cast<h16x8*>(out)[((int64_t)b * CO + oq) * plane_o + flat] = pack8(o8);

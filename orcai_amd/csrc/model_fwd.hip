@@ -1588,6 +1588,18 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
       const int co = m * 16 + lk * 4 + r;
       br_r[m][r] = co < C ? br[co] : 0.0f;
     }
+  // training forward: the folded BatchNorm of this lane's output channels, once per window (formed inside the tile macro it was four times the loads,
+  // v_rsq and multiplies per channel: the channels of a lane do not change with the tile)
+  float bsc[MT][4], bsh[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = (m * 4 + lk) * 4 + r, cc = c < C ? c : 0;
+      const float sc = bn_mean ? bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps) : 1.0f;  // as bn_planes_apply_kernel
+      bsc[m][r] = sc;
+      bsh[m][r] = bn_mean ? bn_beta[cc] - bn_mean[cc] * sc : 0.0f;
+    }
   const int WPx = (Wo + 3) & ~3;
   // Pooling operands of one 16-pixel tile: 3 (x-pooled) or 3 x 2 values per output quad, ALL requested before the first is used, with
   // clamped coordinates (a duplicated row / column leaves a maximum and a minimum unchanged) instead of a bounds branch around every
@@ -1645,11 +1657,8 @@ __global__ __launch_bounds__(256) void pool_res_add_kernel(const float* __restri
           }                                                                                                     \
         }                                                                                                       \
         if (bn_mean) {                                                                                          \
-          _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
-            const int c = oq * 4 + r, cc = c < C ? c : 0;                                                       \
-            const float sc = bn_gamma[cc] * rsqrtf(bn_var[cc] + bn_eps); /* as bn_planes_apply_kernel */        \
-            mx[r] = fmaf(sc >= 0.0f ? mx[r] : mn[r], sc, bn_beta[cc] - bn_mean[cc] * sc);                       \
-          }                                                                                                     \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
+            mx[r] = fmaf(bsc[m][r] >= 0.0f ? mx[r] : mn[r], bsc[m][r], bsh[m][r]);                              \
         }                                                                                                       \
         float o[4];                                                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) o[r] = (oq * 4 + r < C) ? mx[r] + (acc[m][t][r] + br_r[m][r]) : 0.0f; \
