@@ -31,6 +31,12 @@ __global__ __launch_bounds__(256) void conv0_h_kernel(const float* __restrict__ 
                                                        h16* __restrict__ y_out = nullptr) {
   constexpr int TH = 8, TW = 32, R = KS / 2, HH = TH + KS - 1, HW = TW + KS - 1, HP_ = HW + 1;
   __shared__ float halo[HH][HP_];
+  __shared__ float bn2_s[2][16];  // BN: the folded scale / shift of the 16 channels, once per workgroup (per thread it is 16 v_rsq and 64 loads per PIXEL)
+  if (BN && threadIdx.x < 16) {
+    const float sc = bn_gamma[threadIdx.x] * rsqrtf(bn_var[threadIdx.x] + bn_eps);
+    bn2_s[0][threadIdx.x] = sc;
+    bn2_s[1][threadIdx.x] = bn_beta[threadIdx.x] - bn_mean[threadIdx.x] * sc;
+  }
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const float* src = in + (int64_t)b * snippet_stride;
   for (int i = threadIdx.x; i < HH * HW; i += 256) {
@@ -72,8 +78,7 @@ __global__ __launch_bounds__(256) void conv0_h_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = 8 * q + e;
-          const float sc = bn_gamma[c] * rsqrtf(bn_var[c] + bn_eps);
-          r[e] = fmaxf(fmaf(a[e], sc, bn_beta[c] - bn_mean[c] * sc), 0.0f);
+          r[e] = fmaxf(fmaf(a[e], bn2_s[0][c], bn2_s[1][c]), 0.0f);
         }
         (reinterpret_cast<h16x8*>(y_out) + (int64_t)b * 2 * plane + (int64_t)(y + R) * WP + x)[(int64_t)q * plane] = pack8(r);
       }
