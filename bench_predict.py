@@ -316,6 +316,37 @@ def _per_rank_batch(world: int) -> int:
     return B
 
 
+KERNEL_ONLY_BRACKETS = ("orcai_bn_bwd_pointwise_wgrad", "orcai_h_bn_bwd_pointwise_wgrad")
+
+
+class _RawEvent:
+    """A HIP event owned through the C ABI (orcai_event_*), with torch.cuda.Event's elapsed_time(): what orcai_profile_bracket takes."""
+
+    def __init__(self, lib):
+        import ctypes
+
+        self._lib, h = lib, ctypes.c_void_p()
+        rc = lib.orcai_event_create(ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"orcai_event_create: HIP error {rc}")
+        self.handle = h
+
+    def elapsed_time(self, other) -> float:
+        import ctypes
+
+        ms = ctypes.c_float()
+        rc = self._lib.orcai_event_elapsed_ms(self.handle, other.handle, ctypes.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"orcai_event_elapsed_ms: HIP error {rc}")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self._lib.orcai_event_destroy(self.handle)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class _TimedLib:
     """Wraps the ctypes library handle of a trainer (bench instrumentation only; the product path calls the handle directly).
     mode "dominant": only the launches of the step's dominant kernel symbol -- outer_reduce_kernel, the pointwise / residual weight
@@ -341,6 +372,17 @@ class _TimedLib:
         def call(*args):
             if self.events is None or (self.mode == "dominant" and not self.is_dominant(name, args)):
                 return fn(*args)
+            if name in KERNEL_ONLY_BRACKETS:
+                # the launcher itself records the pair around its MAIN kernel (orcai_profile_bracket): the call enqueues two small kernels after it, and
+                # a bracket around the whole call reads ~35 us above the kernel duration rocprofv3 lists
+                e0, e1 = _RawEvent(self._lib), _RawEvent(self._lib)
+                self._lib.orcai_profile_bracket(e0.handle, e1.handle)
+                rc = fn(*args)
+                if rc == -2:
+                    self._lib.orcai_profile_bracket(None, None)
+                else:
+                    self.events.setdefault(name, []).append((e0, e1, args))
+                return rc
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*args)

@@ -487,6 +487,16 @@ int orcai_counter_advance(uint64_t* counter, void* stream);
  * launcher of a step its own slot (orcai_amd/training.py: TrunkTrainer._fresh); base = NULL unregisters.  Host-side state: one stream, one step at a time.
  * orcai_arena_take is the query the launchers use (1 = skip the fill; marks the slot taken). */
 int orcai_scratch_arena(void* base, size_t bytes, void* stream);
+
+/* Measurement hook (bench.py): the next call of orcai_bn_bwd_pointwise_wgrad / orcai_h_bn_bwd_pointwise_wgrad records the two HIP events (hipEvent_t handles)
+ * on its stream around its MAIN kernel only -- the launcher enqueues two small kernels after it (partial-sum fold, f64 -> f32 gradients), so an event pair
+ * around the whole call reads ~35 us above the kernel duration rocprofv3 --kernel-trace lists.  The registration is consumed by that call; NULLs clear it.
+ * Host-side state, one thread. */
+int orcai_profile_bracket(void* ev_start, void* ev_stop);
+/* the events for it, for callers without a HIP binding of their own: timing enabled; elapsed needs both events completed */
+int orcai_event_create(void** ev);
+int orcai_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int orcai_event_destroy(void* ev);
 int orcai_arena_take(const void* p, size_t bytes);
 
 /* A voided step (the f16 path under its static loss scale: Keras' LossScaleOptimizer skips the update when a gradient is not finite).

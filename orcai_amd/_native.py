@@ -149,6 +149,10 @@ _SIGNATURES = {
     "orcai_counter_advance_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_pack_lstm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orcai_unpack_lstm_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "orcai_profile_bracket": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "orcai_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "orcai_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "orcai_event_destroy": (C.c_int, [C.c_void_p]),
     "orcai_unpack_lstm_grads": (C.c_int, [C.POINTER(UnpackDesc), C.c_int, C.c_int, C.c_void_p]),
     "orcai_l2_values": (C.c_int, [C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "orcai_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),

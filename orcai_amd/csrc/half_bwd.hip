@@ -1298,6 +1298,9 @@ int orcai_h_bn_bwd_pointwise_wgrad(const void* dy, const void* v, const void* u,
   int64_t grid = nchunks < 1024 ? nchunks : 1024;  // four workgroups per compute unit
   if (grid * Cin * C > workspace_floats) grid = workspace_floats / ((int64_t)Cin * C);
   const float inv_count = (float)(1.0 / ((double)B * H * W));
+  void *prof0 = nullptr, *prof1 = nullptr;
+  orcai_profile_take(&prof0, &prof1);  // measurement hook (orcai_profile_bracket): events around the main kernel only
+  if (prof0) (void)hipEventRecord((hipEvent_t)prof0, st);
 #define ORCAI_HBBPW(MT_, NT_)                                                                                                                                       \
   hipLaunchKernelGGL((bn_bwd_pw_wgrad_h_kernel<MT_, NT_>), dim3((unsigned)grid), dim3(256), 0, st, (const h16*)dy, (const h16*)v, (const h16*)u, C, H, W, WP, R, B, mean, var, \
                      gamma, beta, eps, relu, db, dg, inv_count, (const h16*)wtf, Cin, (h16*)du, workspace, magic_for(WP))
@@ -1306,6 +1309,7 @@ int orcai_h_bn_bwd_pointwise_wgrad(const void* dy, const void* v, const void* u,
   else if (NT == 1) ORCAI_HBBPW(2, 1);
   else ORCAI_HBBPW(2, 2);
 #undef ORCAI_HBBPW
+  if (prof1) (void)hipEventRecord((hipEvent_t)prof1, st);
   hipLaunchKernelGGL(add_partials_h_kernel, dim3(blocks_for((int64_t)Cin * C), 8), dim3(256), 0, st, workspace, (int)grid, Cin * C, dWpw);
   hipLaunchKernelGGL(f64_to_f32_pair_h_kernel, dim3((C + 63) / 64), dim3(64), 0, st, db, dbeta, dg, dgamma, C);
   return (int)hipGetLastError();

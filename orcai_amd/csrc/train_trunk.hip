@@ -1877,6 +1877,8 @@ int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u
   const size_t lds = (size_t)NWv * (MTv + NTv) * 16 * 66 * sizeof(float);
   const float inv_count = (float)(1.0 / ((double)B * H * W));
   dim3 grid(gx, B);
+  void *prof0 = nullptr, *prof1 = nullptr;
+  orcai_profile_take(&prof0, &prof1);  // measurement hook (orcai_profile_bracket): events around the main kernel only
 #define ORCAI_BBW(MT_, NT_, NW_)                                                                                                                       \
   {                                                                                                                                                    \
     static bool attr_set = false;                                                                                                                      \
@@ -1885,8 +1887,10 @@ int orcai_bn_bwd_pointwise_wgrad(const float* dy, const float* v, const float* u
       if (e != hipSuccess) return (int)e;                                                                                                              \
       attr_set = true;                                                                                                                                 \
     }                                                                                                                                                  \
+    if (prof0) (void)hipEventRecord((hipEvent_t)prof0, st);                                                                                                \
     hipLaunchKernelGGL((bn_bwd_pw_wgrad_kernel<MT_, NT_, NW_>), grid, dim3(64 * NW_), lds, st, dy, v, u, C, H, W, WP, R, mean, var, gamma, beta, eps, relu, db, \
                        dg, inv_count, wt, Cin, du, tasks, magic_for(WP), workspace);                                                                    \
+    if (prof1) (void)hipEventRecord((hipEvent_t)prof1, st);                                                                                                \
   }
   const int key = MTv * 10 + NTv;
   switch (key) {

@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdint>
 
+extern "C" void orcai_profile_take(void** ev_start, void** ev_stop);  // capi.hip: the event pair registered by orcai_profile_bracket (consumed)
 extern "C" int orcai_arena_take(const void* p, size_t bytes);  // capi.hip: 1 = [p, p + bytes) is a fresh slot of the step's pre-cleared accumulator arena
 
 namespace orcai_zero {
