@@ -356,7 +356,7 @@ class _TimedLib:
     extra steps AFTER the timed region to report where the time goes)."""
 
     def __init__(self, lib, is_dominant=None):
-        self._lib, self.events, self.mode = lib, None, "dominant"
+        self._lib, self.events, self.mode, self.order = lib, None, "dominant", []  # order: (launcher, index into events[launcher]) in call order
         if is_dominant is not None:
             self.is_dominant = is_dominant
 
@@ -382,6 +382,7 @@ class _TimedLib:
                     self._lib.orcai_profile_bracket(None, None)
                 else:
                     self.events.setdefault(name, []).append((e0, e1, args))
+                    self.order.append((name, len(self.events[name]) - 1))
                 return rc
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -389,6 +390,7 @@ class _TimedLib:
             e1.record()
             if rc != -2:  # ORCAI_E_UNSUPPORTED: the launcher refused before touching anything and the caller runs its fallback -- not a launch
                 self.events.setdefault(name, []).append((e0, e1, args))
+                self.order.append((name, len(self.events[name]) - 1))
             return rc
 
         return call

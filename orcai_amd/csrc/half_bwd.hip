@@ -604,7 +604,10 @@ __global__ __launch_bounds__(256) void outer_reduce_h_kernel(const h16* __restri
 // hyper-parameter-search widths); the next pass's 16-byte loads are in flight in registers during the MFMA phase.  Per-workgroup partial products +
 // add_partials_h_kernel.
 template <int MT /*conv-INPUT tiles: rows of du and of dW*/, int NT /*conv-OUTPUT tiles: columns of dW*/>
-__global__ __launch_bounds__(256) void bn_bwd_pw_wgrad_h_kernel(const h16* __restrict__ dy, const h16* __restrict__ v, const h16* __restrict__ u, int C, int H, int W, int WP, int R,
+// (256, 4): at most 128 registers -- without the hint the compiler took 152 of the 256 a 256-thread workgroup may have, which is three waves per SIMD where the
+// 40 KB of LDS allow four: 0.46 -> 0.40 ms on block 1 (30 -> 30); same-box A/B of the same hint on ten other kernels of the step: none moved by more than its noise
+// (tools/ab_so.sh; the marching depthwise backward and the f16 pooling backward would spill)
+__global__ __launch_bounds__(256, 4) void bn_bwd_pw_wgrad_h_kernel(const h16* __restrict__ dy, const h16* __restrict__ v, const h16* __restrict__ u, int C, int H, int W, int WP, int R,
                                                                  int B, const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, int relu, const double* __restrict__ dbeta,
                                                                  const double* __restrict__ dgamma, float inv_count, const h16* __restrict__ wtf, int Cin,

@@ -22,24 +22,18 @@ else:
 for _ in range(3):
     tr.train_step(w.x, 736 * 171, w.B, w.y, world_size=1)
 torch.cuda.synchronize()
-order = []
-tl.mode, tl.events = "all", {}
-real_get = type(tl).__getattr__
+tl.mode, tl.events, tl.order = "all", {}, []
 REP = 3
 for _ in range(REP):
     tr.train_step(w.x, 736 * 171, w.B, w.y, world_size=1)
 torch.cuda.synchronize()
-# launch order: events are created in call order; sort all calls of the first repetition by their start relative to the step's first event
+# launch order = call order of the first repetition (tl.order); the time of a call = its fastest repetition
+per_rep = len(tl.order) // REP
 calls = []
-for name, lst in tl.events.items():
-    n = len(lst) // REP
-    for i in range(n):
-        reps = [lst[i + r * n] for r in range(REP)]
-        ms = min(a.elapsed_time(b) for a, b, _ in reps)
-        calls.append((name, reps[0], ms))
-first = min((c[1][0] for c in calls), key=lambda e: 0)  # any event: ordering below uses elapsed_time from one anchor
-anchor = calls[0][1][0]
-calls.sort(key=lambda c: anchor.elapsed_time(c[1][0]))
+for name, idx in tl.order[:per_rep]:
+    n = len(tl.events[name]) // REP
+    reps = [tl.events[name][idx + r * n] for r in range(REP)]
+    calls.append((name, reps[0], min(a.elapsed_time(b) for a, b, _ in reps)))
 tot = 0.0
 print(f"{'launcher':34s} {'symbol':58s} {'ms':>7s} {'MB':>8s} {'TB/s':>6s}  shape")
 for name, (e0, e1, a), ms in calls:
