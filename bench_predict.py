@@ -347,6 +347,26 @@ class _RawEvent:
             pass
 
 
+def bracket_overhead_ms() -> float:
+    """What an EMPTY pair of torch events reads on the current stream (median of 30 pairs): a bracket around a launcher call contains the second event's own
+    dispatch, ~8-10 us -- nothing beside a 0.8 ms kernel, but ten of them make a ten-launch symbol outrank a one-launch symbol of the same kernel time.
+    The fully bracketed tables subtract it per call (not from the kernel-only brackets, whose events the launcher records back to back with its kernel)."""
+    pairs = []
+    torch.cuda.synchronize()
+    for _ in range(30):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
+
+def _net(name, e0, e1, overhead):
+    t = e0.elapsed_time(e1)
+    return t if name in KERNEL_ONLY_BRACKETS else max(t - overhead, 0.0)
+
+
 class _TimedLib:
     """Wraps the ctypes library handle of a trainer (bench instrumentation only; the product path calls the handle directly).
     mode "dominant": only the launches of the step's dominant kernel symbol -- outer_reduce_kernel, the pointwise / residual weight
@@ -572,13 +592,15 @@ class TrainWorkload:
             self.trainer.train_step(self.x, 736 * 171, self.B, self.y, world_size=1)
         torch.cuda.synchronize()
         table, by_symbol = {}, {}
+        overhead = bracket_overhead_ms()
+        out["bracket_overhead_us_subtracted_per_call"] = round(overhead * 1e3, 1)
         for name, calls in self.timed.events.items():
-            t = sum(a.elapsed_time(b) for a, b, _ in calls) / 2
+            t = sum(_net(name, a, b, overhead) for a, b, _ in calls) / 2
             by = [_train_call_bytes(name, args) for _, _, args in calls]
             table[name] = (t, None if any(b is None for b in by) else sum(by) / 2, len(calls) // 2)
             for (e0, e1, args), b in zip(calls, by):  # the same calls by kernel SYMBOL: what rocprofv3 --stats ranks
                 d = by_symbol.setdefault(_train_call_symbol(name, args), {"ms": 0.0, "bytes": 0.0, "n": 0, "launcher": name, "priced": True})
-                d["ms"] += e0.elapsed_time(e1) / 2
+                d["ms"] += _net(name, e0, e1, overhead) / 2
                 d["n"] += 0.5
                 d["priced"] = d["priced"] and b is not None
                 d["bytes"] += (b or 0.0) / 2
@@ -783,12 +805,13 @@ class HpsearchWorkload:
             self.world = world
         torch.cuda.synchronize()
         by_symbol = {}
+        overhead = bracket_overhead_ms()
         for v in self.variants:
             for name, calls in self.timed[v].events.items():
                 for e0, e1, args in calls:
                     sym, by = _h_call_symbol(name, args), _h_call_bytes(name, args)
                     d = by_symbol.setdefault(sym, {"ms": 0.0, "bytes": 0.0, "n": 0, "priced": True, "launcher": name})
-                    d["ms"] += e0.elapsed_time(e1)
+                    d["ms"] += _net(name, e0, e1, overhead)
                     d["n"] += 1
                     d["priced"] = d["priced"] and by is not None
                     d["bytes"] += by or 0.0
